@@ -1,0 +1,111 @@
+"""ctypes binding of libgespmm.so (the C ABI declared in include/gespmm.h).
+
+This is the reference-side binding a maintainer would write (INTEGRATION.md shows
+the same stub). It never falls back to a CPU implementation: a missing library is
+an ImportError, a failing call is a RuntimeError carrying gespmm_error_string().
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgespmm.so")
+
+VARIANT_AUTO = -1
+VARIANT_NAIVE = 0
+VARIANT_CRC = 1
+VARIANT_CRC_CWM2 = 2
+VARIANT_CRC_CWM4 = 3
+VARIANT_CRC_CWM8 = 4
+VARIANT_PARREDUCE = 5
+NUM_VARIANTS = 6
+
+FLAG_NO_XCD_REMAP = 0x1
+FLAG_NT_STORE = 0x2
+FLAG_FORCE_IDX64 = 0x4
+
+# Every symbol include/gespmm.h declares; tests check the library exports all of them.
+EXPORTS = [
+    "gespmm_version",
+    "gespmm_error_string",
+    "gespmm_csr_spmm_f32",
+    "gespmm_csr_spmm_max_f32",
+    "gespmm_select_variant",
+    "gespmm_csr_spmm_f32_cfg",
+    "gespmm_sddmm_coo_f32",
+    "gespmm_sddmm_csr_f32",
+    "gespmm_csr2csc_workspace_bytes",
+    "gespmm_csr2csc_f32",
+    "gespmm_mtx_read",
+    "gespmm_mtx_free",
+    "gespmm_coo_to_csr",
+    "gespmm_row_partition",
+]
+
+
+class LaunchCfg(Structure):
+    _fields_ = [("vec", c_int32), ("strips", c_int32), ("group", c_int32), ("flags", c_int32)]
+
+
+class Coo(Structure):
+    _fields_ = [
+        ("nrows", c_int32),
+        ("ncols", c_int32),
+        ("nnz", c_int64),
+        ("row", POINTER(c_int32)),
+        ("col", POINTER(c_int32)),
+        ("val", POINTER(c_float)),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gespmm_amd: %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ge-spmm_amd/csrc`). There is no CPU fallback." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    p = c_void_p
+    lib.gespmm_version.restype = c_char_p
+    lib.gespmm_error_string.restype = c_char_p
+    lib.gespmm_error_string.argtypes = [c_int]
+    lib.gespmm_csr_spmm_f32.restype = c_int
+    lib.gespmm_csr_spmm_f32.argtypes = [p, p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_int, p]
+    lib.gespmm_csr_spmm_f32_cfg.restype = c_int
+    lib.gespmm_csr_spmm_f32_cfg.argtypes = [p, p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                            POINTER(LaunchCfg), p]
+    lib.gespmm_csr_spmm_max_f32.restype = c_int
+    lib.gespmm_csr_spmm_max_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_float, c_int, p]
+    lib.gespmm_select_variant.restype = c_int
+    lib.gespmm_select_variant.argtypes = [c_int64, c_int64, c_int64]
+    lib.gespmm_sddmm_coo_f32.restype = c_int
+    lib.gespmm_sddmm_coo_f32.argtypes = [p, p, p, p, p, c_int64, c_int64, p]
+    lib.gespmm_sddmm_csr_f32.restype = c_int
+    lib.gespmm_sddmm_csr_f32.argtypes = [p, p, p, p, p, c_int64, c_int64, c_int64, p]
+    lib.gespmm_csr2csc_workspace_bytes.restype = c_int64
+    lib.gespmm_csr2csc_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
+    lib.gespmm_csr2csc_f32.restype = c_int
+    lib.gespmm_csr2csc_f32.argtypes = [p, p, p, p, p, p, c_int64, c_int64, c_int64, p, p]
+    lib.gespmm_mtx_read.restype = c_int
+    lib.gespmm_mtx_read.argtypes = [c_char_p, POINTER(Coo)]
+    lib.gespmm_mtx_free.restype = None
+    lib.gespmm_mtx_free.argtypes = [POINTER(Coo)]
+    lib.gespmm_coo_to_csr.restype = c_int
+    lib.gespmm_coo_to_csr.argtypes = [c_int32, c_int32, c_int64, p, p, p, p, p, p]
+    lib.gespmm_row_partition.restype = c_int
+    lib.gespmm_row_partition.argtypes = [p, c_int64, c_int32, p]
+    return lib
+
+
+lib = _load()
+
+
+class GespmmError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s failed: %s (code %d)" % (where, lib.gespmm_error_string(code).decode(), code))
+
+
+def check(code, where):
+    if code != 0:
+        raise GespmmError(code, where)

@@ -1,0 +1,168 @@
+// capi.cpp — the extern "C" boundary declared in include/gespmm.h.
+//
+// Argument validation, variant -> launch-geometry selection, and the hand-off to
+// the HIP launchers. Nothing here touches device memory; the only HIP calls are
+// the kernel launches themselves. There is deliberately no CPU fallback: on a
+// machine without a HIP device the launch fails and its hipError_t is returned.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/gespmm.h"
+#include "select.h"
+#include "spmm_kernels.h"
+
+namespace {
+
+using gespmm::Geometry;
+using gespmm::SpmmArgs;
+
+inline bool aligned_to(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int check_common(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, const float* C,
+                 int64_t M, int64_t K, int64_t N, int64_t nnz) {
+    if (M < 0 || K < 0 || N < 0 || nnz < -1) return GESPMM_EINVAL;
+    if (M > 0x7fffffffLL - 64 || K > 0x7fffffffLL || N > 0x7fffffffLL / 4 || nnz > 0x7fffffffLL) return GESPMM_ERANGE;
+    if (M == 0 || N == 0) return 0;  // nothing to do; pointers may be null
+    if (!rowptr || !C) return GESPMM_EINVAL;
+    if ((nnz != 0) && (!colind || !B)) return GESPMM_EINVAL;
+    if (!aligned_to(rowptr, 4) || !aligned_to(colind, 4) || !aligned_to(val, 4) || !aligned_to(B, 4) ||
+        !aligned_to(C, 4))
+        return GESPMM_EALIGN;
+    return 0;
+}
+
+int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
+             int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
+             void* stream) {
+    const int rc = check_common(rowptr, colind, val, B, C, M, K, N, nnz);
+    if (rc != 0) return rc;
+    if (M == 0 || N == 0) return 0;
+    if (variant < GESPMM_VARIANT_AUTO || variant >= GESPMM_NUM_VARIANTS) return GESPMM_EINVAL;
+    if (reduce == gespmm::kReduceMax && (val != nullptr || variant == GESPMM_VARIANT_PARREDUCE ||
+                                         variant == GESPMM_VARIANT_NAIVE))
+        return GESPMM_EINVAL;
+
+    // Vector width is limited by what both B and C rows can be addressed with.
+    int max_vec = 4;
+    while (max_vec > 1 && ((N % max_vec) != 0 || !aligned_to(B, 4u * max_vec) || !aligned_to(C, 4u * max_vec)))
+        max_vec >>= 1;
+
+    gespmm::Selection sel;
+    int flags = 0;
+    if (cfg) flags = cfg->flags;
+    const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
+                                             cfg ? cfg->strips : 0, cfg ? cfg->group : 0, flags, &sel);
+    if (src != 0) return src;
+    sel.geo.reduce = reduce;
+
+    SpmmArgs a;
+    a.rowptr = rowptr;
+    a.colind = colind;
+    a.val = val;
+    a.B = B;
+    a.C = C;
+    a.M = (int32_t)M;
+    a.N = (int32_t)N;
+    a.nblk = 0;
+    a.ntile = 0;
+    a.flags = flags;
+    a.empty = empty;
+
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);
+    else e = gespmm::launch_spmm_rowgroup(a, sel.geo, st);
+    return (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gespmm_version(void) {
+    static char buf[64];
+    if (!buf[0]) snprintf(buf, sizeof buf, "gespmm %d.%d (gfx950)", GESPMM_VERSION_MAJOR, GESPMM_VERSION_MINOR);
+    return buf;
+}
+
+const char* gespmm_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case GESPMM_EINVAL: return "gespmm: invalid argument";
+        case GESPMM_EALIGN: return "gespmm: pointer not 4-byte aligned";
+        case GESPMM_ERANGE: return "gespmm: size exceeds int32 CSR addressing";
+        case GESPMM_EIO: return "gespmm: file not found or unreadable";
+        case GESPMM_EFORMAT: return "gespmm: could not process Matrix Market banner or size line";
+        case GESPMM_ENOMEM: return "gespmm: host allocation failed";
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "gespmm: unknown error code";
+}
+
+int gespmm_csr_spmm_f32(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C,
+                        int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, void* stream) {
+    return run_spmm(rowptr, colind, val, B, C, M, K, N, nnz, variant, nullptr, gespmm::kReduceSum, 0.0f, stream);
+}
+
+int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B,
+                            float* C, int64_t M, int64_t K, int64_t N, int64_t nnz, int variant,
+                            const gespmm_launch_cfg* cfg, void* stream) {
+    return run_spmm(rowptr, colind, val, B, C, M, K, N, nnz, variant, cfg, gespmm::kReduceSum, 0.0f, stream);
+}
+
+int gespmm_csr_spmm_max_f32(const int32_t* rowptr, const int32_t* colind, const float* B, float* C, int64_t M,
+                            int64_t K, int64_t N, int64_t nnz, float empty_value, int variant, void* stream) {
+    return run_spmm(rowptr, colind, nullptr, B, C, M, K, N, nnz, variant, nullptr, gespmm::kReduceMax, empty_value,
+                    stream);
+}
+
+int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N) { return gespmm::auto_variant(M, nnz, N); }
+
+int gespmm_sddmm_coo_f32(const int32_t* rowind, const int32_t* colind, const float* D1, const float* D2, float* out,
+                         int64_t nnz, int64_t N, void* stream) {
+    if (nnz < 0 || N < 0) return GESPMM_EINVAL;
+    if (nnz > 0x7fffffffLL || N > 0x7fffffffLL / 4) return GESPMM_ERANGE;
+    if (nnz == 0) return 0;
+    if (!rowind || !colind || !out || (N > 0 && (!D1 || !D2))) return GESPMM_EINVAL;
+    if (!aligned_to(rowind, 4) || !aligned_to(colind, 4) || !aligned_to(D1, 4) || !aligned_to(D2, 4) ||
+        !aligned_to(out, 4))
+        return GESPMM_EALIGN;
+    return (int)gespmm::launch_sddmm(rowind, false, colind, D1, D2, out, 0, nnz, N,
+                                     reinterpret_cast<hipStream_t>(stream));
+}
+
+int gespmm_sddmm_csr_f32(const int32_t* rowptr, const int32_t* colind, const float* D1, const float* D2, float* out,
+                         int64_t M, int64_t nnz, int64_t N, void* stream) {
+    if (M < 0 || nnz < 0 || N < 0) return GESPMM_EINVAL;
+    if (M > 0x7fffffffLL - 1 || nnz > 0x7fffffffLL || N > 0x7fffffffLL / 4) return GESPMM_ERANGE;
+    if (nnz == 0) return 0;
+    if (!rowptr || !colind || !out || (N > 0 && (!D1 || !D2))) return GESPMM_EINVAL;
+    if (!aligned_to(rowptr, 4) || !aligned_to(colind, 4) || !aligned_to(D1, 4) || !aligned_to(D2, 4) ||
+        !aligned_to(out, 4))
+        return GESPMM_EALIGN;
+    return (int)gespmm::launch_sddmm(rowptr, true, colind, D1, D2, out, M, nnz, N,
+                                     reinterpret_cast<hipStream_t>(stream));
+}
+
+int64_t gespmm_csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
+    if (M < 0 || K < 0 || nnz < 0) return GESPMM_EINVAL;
+    return gespmm::csr2csc_workspace_bytes(M, K, nnz);
+}
+
+int gespmm_csr2csc_f32(const int32_t* rowptr, const int32_t* colind, const float* csr_val, int32_t* colptr,
+                       int32_t* rowind, float* csc_val, int64_t M, int64_t K, int64_t nnz, void* workspace,
+                       void* stream) {
+    if (M < 0 || K < 0 || nnz < 0) return GESPMM_EINVAL;
+    if (M > 0x7fffffffLL - 1 || K > 0x7fffffffLL - 1 || nnz > 0x7fffffffLL) return GESPMM_ERANGE;
+    if (!rowptr || !colptr) return GESPMM_EINVAL;
+    if (nnz > 0 && (!colind || !rowind || !workspace)) return GESPMM_EINVAL;
+    if ((csr_val == nullptr) != (csc_val == nullptr)) return GESPMM_EINVAL;
+    return (int)gespmm::launch_csr2csc(rowptr, colind, csr_val, colptr, rowind, csc_val, M, K, nnz, workspace,
+                                       reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

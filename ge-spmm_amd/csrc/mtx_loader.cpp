@@ -1,0 +1,303 @@
+// mtx_loader.cpp — host side of the path: MatrixMarket loader, COO->CSR, row partition.
+//
+// Behavioural contract = the reference's readMtx<float>() (util/util.hpp:286-333,
+// readTuples 104-216, makeSymmetric 218-284, customSort 75-102) on top of NIST
+// mmio's mm_read_banner / mm_read_mtx_crd_size (util/mmio.hpp:215-298, 308-336):
+//   * whitespace-separated token stream (what fscanf consumes), 1-based -> 0-based;
+//   * `integer` and `real` carry a value token, `pattern` means value 1.0;
+//   * ONLY the `symmetric` flag is expanded (hermitian / skew are read as stored):
+//     every off-diagonal entry is mirrored, the list is sorted by (row, col), and
+//     self-loops and repeated (row, col) pairs are dropped;
+//   * `general` files keep duplicates and self-loops;
+//   * the result is sorted by (row, col).
+// Deliberate differences (reference quirks that are bugs):
+//   * never exit()s — errors are return codes;
+//   * values stay attached to their entries through the symmetric compaction (the
+//     reference moves row/col but not val, util.hpp:268-277); ties keep file order;
+//   * `complex` and `array` files are rejected with GESPMM_EFORMAT (the reference
+//     silently returns empty vectors with a non-zero nnz).
+// The implementation shares nothing with the reference's: the file is read in one
+// block, tokens are parsed in place, and ordering is an LSD radix sort on a
+// packed 64-bit (row, col) key — O(nnz), stable, no per-entry allocation.
+
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gespmm.h"
+
+namespace {
+
+enum class Field { Real, Integer, Pattern };
+
+struct Cursor {
+    const char* p;
+    const char* end;
+    void skip_ws() {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\v' || *p == '\f')) ++p;
+    }
+    bool at_end() {
+        skip_ws();
+        return p >= end;
+    }
+    // Decimal integer token. Returns false when no digits are present.
+    bool read_int(long long* out) {
+        skip_ws();
+        if (p >= end) return false;
+        const char* q = p;
+        bool neg = false;
+        if (*q == '-' || *q == '+') {
+            neg = (*q == '-');
+            ++q;
+        }
+        if (q >= end || *q < '0' || *q > '9') return false;
+        long long v = 0;
+        while (q < end && *q >= '0' && *q <= '9') {
+            v = v * 10 + (*q - '0');
+            ++q;
+        }
+        p = q;
+        *out = neg ? -v : v;
+        return true;
+    }
+    bool read_float(float* out) {
+        skip_ws();
+        if (p >= end) return false;
+        char* e = nullptr;
+        const float v = strtof(p, &e);  // buffer is NUL-terminated by the caller
+        if (e == p) return false;
+        p = e;
+        *out = v;
+        return true;
+    }
+};
+
+std::string lower(std::string s) {
+    for (auto& c : s) c = (char)tolower((unsigned char)c);
+    return s;
+}
+
+// Stable LSD radix sort of `idx` by keys[idx], 16-bit digits, only the digits that
+// can differ.
+void radix_sort_by_key(const std::vector<uint64_t>& keys, std::vector<uint32_t>& idx) {
+    const size_t n = idx.size();
+    if (n < 2) return;
+    uint64_t ormask = 0;
+    for (size_t i = 0; i < n; ++i) ormask |= keys[i];
+    std::vector<uint32_t> tmp(n);
+    std::vector<size_t> count(65536 + 1);
+    for (int shift = 0; shift < 64; shift += 16) {
+        if (((ormask >> shift) & 0xffffu) == 0) continue;
+        std::fill(count.begin(), count.end(), 0);
+        for (size_t i = 0; i < n; ++i) ++count[((keys[idx[i]] >> shift) & 0xffffu) + 1];
+        for (size_t d = 0; d < 65536; ++d) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; ++i) tmp[count[(keys[idx[i]] >> shift) & 0xffffu]++] = idx[i];
+        idx.swap(tmp);
+    }
+}
+
+inline uint64_t pack(int32_t r, int32_t c) { return ((uint64_t)(uint32_t)r << 32) | (uint32_t)c; }
+
+}  // namespace
+
+extern "C" {
+
+void gespmm_mtx_free(gespmm_coo* coo) {
+    if (!coo) return;
+    free(coo->row);
+    free(coo->col);
+    free(coo->val);
+    coo->row = coo->col = nullptr;
+    coo->val = nullptr;
+    coo->nnz = 0;
+}
+
+int gespmm_mtx_read(const char* path, gespmm_coo* out) {
+    if (!path || !out) return GESPMM_EINVAL;
+    memset(out, 0, sizeof *out);
+
+    FILE* f = fopen(path, "rb");
+    if (!f) return GESPMM_EIO;
+    std::string buf;
+    {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) buf.append(chunk, got);
+        fclose(f);
+    }
+    const char* base = buf.c_str();  // NUL-terminated
+    const char* end = base + buf.size();
+
+    // ---- banner: first line, five tokens (mmio.hpp:215-298)
+    const char* eol = (const char*)memchr(base, '\n', buf.size());
+    if (!eol) eol = end;
+    std::string tok[5];
+    {
+        Cursor c{base, eol};
+        for (int i = 0; i < 5; ++i) {
+            c.skip_ws();
+            const char* s = c.p;
+            while (c.p < eol && !isspace((unsigned char)*c.p)) ++c.p;
+            if (c.p == s) return GESPMM_EFORMAT;
+            tok[i].assign(s, c.p - s);
+        }
+    }
+    if (tok[0].compare(0, 14, "%%MatrixMarket") != 0) return GESPMM_EFORMAT;
+    if (lower(tok[1]) != "matrix") return GESPMM_EFORMAT;
+    if (lower(tok[2]) != "coordinate") return GESPMM_EFORMAT;  // dense `array` is not an SpMM input
+    Field field;
+    {
+        const std::string t = lower(tok[3]);
+        if (t == "real") field = Field::Real;
+        else if (t == "integer") field = Field::Integer;
+        else if (t == "pattern") field = Field::Pattern;
+        else return GESPMM_EFORMAT;  // complex / unknown
+    }
+    bool symmetric;
+    {
+        const std::string t = lower(tok[4]);
+        if (t == "general" || t == "hermitian" || t == "skew-symmetric") symmetric = false;
+        else if (t == "symmetric") symmetric = true;
+        else return GESPMM_EFORMAT;
+    }
+
+    // ---- size line: skip lines starting with '%', then three integers (mmio.hpp:308-336)
+    const char* p = (eol < end) ? eol + 1 : end;
+    for (;;) {
+        if (p >= end) return GESPMM_EFORMAT;
+        if (*p != '%') break;
+        const char* nl = (const char*)memchr(p, '\n', end - p);
+        p = nl ? nl + 1 : end;
+    }
+    Cursor cur{p, end};
+    long long M, K, NZ;
+    if (!cur.read_int(&M) || !cur.read_int(&K) || !cur.read_int(&NZ)) return GESPMM_EFORMAT;
+    if (M < 0 || K < 0 || NZ < 0 || M > 0x7fffffffLL || K > 0x7fffffffLL || NZ > 0x3fffffffLL) return GESPMM_ERANGE;
+
+    // ---- entries (util.hpp:104-216). Fewer entries than promised is not an error
+    // in the reference ("Error: not enough rows in mtx file." and carry on).
+    std::vector<int32_t> row, col;
+    std::vector<float> val;
+    row.reserve((size_t)NZ * (symmetric ? 2 : 1));
+    col.reserve((size_t)NZ * (symmetric ? 2 : 1));
+    val.reserve((size_t)NZ * (symmetric ? 2 : 1));
+    for (long long i = 0; i < NZ; ++i) {
+        long long r, c;
+        if (cur.at_end()) {
+            fprintf(stdout, "Error: not enough rows in mtx file.\n");
+            break;
+        }
+        if (!cur.read_int(&r) || !cur.read_int(&c)) return GESPMM_EFORMAT;
+        float v = 1.0f;
+        if (field == Field::Real) {
+            if (!cur.read_float(&v)) return GESPMM_EFORMAT;
+        } else if (field == Field::Integer) {
+            long long iv;
+            if (!cur.read_int(&iv)) return GESPMM_EFORMAT;
+            v = (float)(int)iv;
+        }
+        if (r < 1 || c < 1 || r > 0x7fffffffLL || c > 0x7fffffffLL) return GESPMM_EFORMAT;
+        row.push_back((int32_t)(r - 1));
+        col.push_back((int32_t)(c - 1));
+        val.push_back(v);
+    }
+
+    // ---- symmetric expansion (util.hpp:218-284)
+    if (symmetric) {
+        const size_t n0 = row.size();
+        for (size_t i = 0; i < n0; ++i)
+            if (row[i] != col[i]) {
+                row.push_back(col[i]);
+                col.push_back(row[i]);
+                val.push_back(val[i]);
+            }
+    }
+
+    // ---- order by (row, col), stable
+    const size_t n = row.size();
+    std::vector<uint64_t> keys(n);
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; ++i) {
+        keys[i] = pack(row[i], col[i]);
+        idx[i] = (uint32_t)i;
+    }
+    radix_sort_by_key(keys, idx);
+
+    // ---- emit, dropping self-loops and duplicates for symmetric files
+    int32_t* orow = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    int32_t* ocol = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    float* oval = (float*)malloc((n ? n : 1) * sizeof(float));
+    if (!orow || !ocol || !oval) {
+        free(orow);
+        free(ocol);
+        free(oval);
+        return GESPMM_ENOMEM;
+    }
+    size_t m = 0;
+    uint64_t prev = ~0ull;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t j = idx[i];
+        if (symmetric) {
+            if (row[j] == col[j]) continue;                 // self-loop
+            if (i > 0 && keys[j] == prev) continue;         // duplicate of the previous sorted entry
+            prev = keys[j];
+        }
+        orow[m] = row[j];
+        ocol[m] = col[j];
+        oval[m] = val[j];
+        ++m;
+    }
+    out->nrows = (int32_t)M;
+    out->ncols = (int32_t)K;
+    out->nnz = (int64_t)m;
+    out->row = orow;
+    out->col = ocol;
+    out->val = oval;
+    return 0;
+}
+
+int gespmm_coo_to_csr(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t* row, const int32_t* col,
+                      const float* val_in, int32_t* rowptr, int32_t* colind, float* val_out) {
+    if (nrows < 0 || ncols < 0 || nnz < 0 || !rowptr) return GESPMM_EINVAL;
+    if (nnz > 0x7fffffffLL) return GESPMM_ERANGE;
+    if (nnz > 0 && (!row || !col || !colind)) return GESPMM_EINVAL;
+    for (int32_t i = 0; i <= nrows; ++i) rowptr[i] = 0;
+    for (int64_t n = 0; n < nnz; ++n) {
+        if (row[n] < 0 || row[n] >= nrows || col[n] < 0 || col[n] >= ncols) return GESPMM_EINVAL;
+        ++rowptr[row[n] + 1];
+    }
+    for (int32_t i = 0; i < nrows; ++i) rowptr[i + 1] += rowptr[i];
+    // rowptr[r] is now the start of row r; fill with a moving cursor per row and
+    // restore the starts afterwards (same effect as spmm_test.cu:568-581).
+    std::vector<int32_t> next(rowptr, rowptr + nrows);
+    for (int64_t n = 0; n < nnz; ++n) {
+        const int32_t dst = next[row[n]]++;
+        colind[dst] = col[n];
+        if (val_out) val_out[dst] = val_in ? val_in[n] : 1.0f;
+    }
+    return 0;
+}
+
+int gespmm_row_partition(const int32_t* rowptr, int64_t M, int32_t parts, int64_t* cut) {
+    if (!rowptr || !cut || M < 0 || parts < 1) return GESPMM_EINVAL;
+    const int64_t nnz = rowptr[M] - rowptr[0];
+    cut[0] = 0;
+    for (int32_t p = 1; p < parts; ++p) {
+        const int64_t target = rowptr[0] + (nnz * p) / parts;
+        int64_t lo = cut[p - 1], hi = M;  // first row r >= cut[p-1] with rowptr[r] >= target
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rowptr[mid] >= target) hi = mid;
+            else lo = mid + 1;
+        }
+        cut[p] = lo;
+    }
+    cut[parts] = M;
+    return 0;
+}
+
+}  // extern "C"

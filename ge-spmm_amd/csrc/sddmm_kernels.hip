@@ -1,0 +1,117 @@
+// sddmm_kernels.hip — sampled dense-dense product on a sparse pattern (gfx950).
+//
+//     out[e] = sum_{j < N} D1[row(e), j] * D2[col(e), j]        (pattern order)
+//
+// Reference semantics: pytorch-custom/sddmm.cu:7-424 + computeUtil.h:11-28,115-124
+// (COO: row(e) = rowind[e]; CSR: row(e) found by binary search in rowptr). The
+// reference packs 4 edges per 8/16/32-lane slice of a 32-lane warp and needs
+// 16-byte-aligned index arrays plus single-edge tail blocks; none of that shape
+// is kept. Here a W-lane group of a 64-lane wavefront owns one edge, every lane
+// reads V contiguous floats of both rows per step (dwordx4 when N % 4 == 0), and
+// the W partial dot products meet in an xor butterfly (cross-lane ds_bpermute /
+// DPP moves). Edges of a wavefront are consecutive, so the out[] stores and the
+// index loads coalesce. Summation order is not sequential (neither is the
+// reference's shuffle tree): parity for SDDMM is tolerance-based.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spmm_kernels.h"
+
+namespace gespmm {
+
+template <int V> struct SdVec;
+template <> struct SdVec<1> { using type = float; };
+template <> struct SdVec<2> { using type = float __attribute__((ext_vector_type(2))); };
+template <> struct SdVec<4> { using type = float __attribute__((ext_vector_type(4))); };
+
+// Row that owns CSR position e: largest r with rowptr[r] <= e (empty rows skipped).
+__device__ __forceinline__ int row_of_edge(const int32_t* __restrict__ rowptr, int M, int e) {
+    int lo = 0, hi = M;  // invariant: rowptr[lo] <= e < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+template <int V, int W, bool CSR>
+__global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restrict__ rows,
+                                                          const int32_t* __restrict__ colind,
+                                                          const float* __restrict__ D1,
+                                                          const float* __restrict__ D2, float* __restrict__ out,
+                                                          int M, int nnz, int N) {
+    constexpr int G = 64 / W;
+    using T = typename SdVec<V>::type;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / W;
+    const int l = lane % W;
+    const int e = (blockIdx.x * kWaves + wave) * G + g;
+    const bool ok = e < nnz;
+    float part = 0.0f;
+    if (ok) {
+        const int r = CSR ? row_of_edge(rows, M, e) : rows[e];
+        const int c = colind[e];
+        const float* p1 = D1 + (size_t)r * (size_t)N;
+        const float* p2 = D2 + (size_t)c * (size_t)N;
+        for (int j = l * V; j < N; j += W * V) {
+            const T x = *reinterpret_cast<const T*>(p1 + j);
+            const T y = *reinterpret_cast<const T*>(p2 + j);
+            if constexpr (V == 1) {
+                part = __builtin_fmaf(x, y, part);
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (ok && l == 0) out[e] = part;
+}
+
+template <int V, bool CSR>
+static hipError_t sddmm_w(int W, const int32_t* rows, const int32_t* colind, const float* D1, const float* D2,
+                          float* out, int M, int nnz, int N, hipStream_t st) {
+#define GESPMM_SD(WW)                                                                                         \
+    case WW: {                                                                                                 \
+        constexpr int G = 64 / WW;                                                                             \
+        const int nblk = (int)(((int64_t)nnz + kWaves * G - 1) / (kWaves * G));                                \
+        hipLaunchKernelGGL((sddmm_kernel<V, WW, CSR>), dim3(nblk), dim3(kThreads), 0, st, rows, colind, D1, D2, \
+                           out, M, nnz, N);                                                                    \
+        return hipGetLastError();                                                                              \
+    }
+    switch (W) {
+        GESPMM_SD(4)
+        GESPMM_SD(8)
+        GESPMM_SD(16)
+        GESPMM_SD(32)
+        GESPMM_SD(64)
+    }
+#undef GESPMM_SD
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, const float* D1, const float* D2,
+                        float* out, int64_t M, int64_t nnz, int64_t N, hipStream_t st) {
+    if (nnz == 0) return hipSuccess;
+    int V = 4;
+    while (V > 1 && ((N % V) != 0 || (reinterpret_cast<uintptr_t>(D1) % (4u * V)) != 0 ||
+                     (reinterpret_cast<uintptr_t>(D2) % (4u * V)) != 0))
+        V >>= 1;
+    int W = 4;
+    while (W < 64 && (int64_t)W * V < N) W <<= 1;
+    const int m = (int)M, z = (int)nnz, n = (int)N;
+    if (csr) {
+        if (V == 4) return sddmm_w<4, true>(W, rows, colind, D1, D2, out, m, z, n, st);
+        if (V == 2) return sddmm_w<2, true>(W, rows, colind, D1, D2, out, m, z, n, st);
+        return sddmm_w<1, true>(W, rows, colind, D1, D2, out, m, z, n, st);
+    }
+    if (V == 4) return sddmm_w<4, false>(W, rows, colind, D1, D2, out, m, z, n, st);
+    if (V == 2) return sddmm_w<2, false>(W, rows, colind, D1, D2, out, m, z, n, st);
+    return sddmm_w<1, false>(W, rows, colind, D1, D2, out, m, z, n, st);
+}
+
+}  // namespace gespmm

@@ -1,0 +1,58 @@
+// spmm_kernels.h — internal interface between the C ABI (capi.cpp) and the HIP
+// kernel translation units. Not installed; the public surface is include/gespmm.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gespmm {
+
+constexpr int kThreads = 256;  // workgroup = 4 wavefronts of 64 lanes
+constexpr int kWaves = 4;
+constexpr int kTile = 64;      // CSR entries staged in LDS per wavefront refill
+
+constexpr int kReduceSum = 0;
+constexpr int kReduceMax = 1;
+
+constexpr int kFlagNoXcdRemap = 0x1;  // == GESPMM_FLAG_NO_XCD_REMAP
+constexpr int kFlagNtStore = 0x2;     // == GESPMM_FLAG_NT_STORE
+constexpr int kFlagForceIdx64 = 0x4;  // == GESPMM_FLAG_FORCE_IDX64
+
+struct SpmmArgs {
+    const int32_t* rowptr;
+    const int32_t* colind;
+    const float* val;  // nullptr: A == 1 on its pattern
+    const float* B;
+    float* C;
+    int32_t M;
+    int32_t N;
+    int32_t nblk;   // row blocks (filled in by the launcher)
+    int32_t ntile;  // column tiles (filled in by the launcher)
+    int32_t flags;
+    float empty;    // max reducer: value of rows without non-zeros / initial accumulator
+};
+
+// Launch geometry resolved by the host-side selector (select.cpp).
+struct Geometry {
+    int vec;      // V: floats per lane per strip (1, 2, 4)
+    int strips;   // S: strips per lane (1, 2)
+    int group;    // W: lanes per row (4..64)
+    bool crc;     // LDS-staged CSR tiles (variants 1-4) vs naive (variant 0)
+    bool idx64;   // 64-bit byte offsets into B
+    int reduce;   // kReduceSum / kReduceMax
+};
+
+hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+
+// sddmm_kernels.hip
+hipError_t launch_sddmm(const int32_t* rowind_or_rowptr, bool csr, const int32_t* colind,
+                        const float* D1, const float* D2, float* out,
+                        int64_t M, int64_t nnz, int64_t N, hipStream_t st);
+
+// csr2csc.hip
+int64_t csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
+hipError_t launch_csr2csc(const int32_t* rowptr, const int32_t* colind, const float* csr_val,
+                          int32_t* colptr, int32_t* rowind, float* csc_val,
+                          int64_t M, int64_t K, int64_t nnz, void* workspace, hipStream_t st);
+
+}  // namespace gespmm

@@ -1,0 +1,401 @@
+// spmm_kernels.hip — CSR x dense row-product SpMM for MI355X (gfx950, wave64).
+//
+// What is computed (reference semantics, spmm_test.cu:64-236 / spmm_kernel.cu:31-379):
+//     C[r, c] = sum_{p = rowptr[r]}^{rowptr[r+1]-1} val[p] * B[colind[p], c]
+// accumulated in ONE fp32 register per output element, ascending p, one fused
+// multiply-add per non-zero (what nvcc emits for `acc += a*b`), rows without
+// non-zeros write 0, C fully overwritten.
+//
+// How it is laid out on CDNA4 (this is a re-design, not a translation of the
+// reference's 32-lane kernels):
+//
+//  * Row groups. A 64-lane wavefront is split into G = 64/W groups of W lanes;
+//    each group owns one row, each lane owns S strips of V CONTIGUOUS output
+//    columns (one dwordx{V} load / store per strip). The reference's "coarse-
+//    grained warp merging" (CWM, lane owns columns c, c+32, ...) becomes
+//    CF = V*S with contiguous vectors, so a group reads/writes W*V*4 contiguous
+//    bytes of a B/C row per instruction (N=128: W=32,V=4 -> 512 B per half-wave).
+//    W is sized to N, so N=32 runs 8 rows per wavefront instead of idling lanes.
+//
+//  * Coalesced Row Caching (CRC) in LDS. The G rows of one wavefront are
+//    consecutive, so their CSR entries are ONE contiguous range. The wavefront
+//    streams that range through a private 64-entry LDS tile with a single
+//    coalesced load per 64 entries (column index pre-scaled to a byte offset into
+//    B, as the reference pre-multiplies by N at spmm_test.cu:124), and every
+//    group then walks its own sub-range with LDS broadcast reads. The next tile's
+//    entries are prefetched into registers while the current tile is consumed.
+//
+//  * Memory-level parallelism. The walk is unrolled U-wide: U LDS reads, U
+//    independent B-row gathers, then U FMAs in CSR order — the order of the
+//    additions is unchanged, so results stay bit-identical across variants.
+//
+//  * XCD-aware mapping. The hardware deals workgroup b to XCD b % 8; we remap so
+//    that each XCD (private 4 MiB L2) sweeps one contiguous eighth of the rows,
+//    and the column tiles of a row block run back-to-back on the same XCD.
+//
+// No MFMA: the inner product is a gather, not a dense contraction.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "spmm_kernels.h"
+
+namespace gespmm {
+
+// ----------------------------------------------------------------------------- small helpers
+
+template <int V> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float __attribute__((ext_vector_type(2))); };
+template <> struct VecT<4> { using type = float __attribute__((ext_vector_type(4))); };
+
+template <int V>
+__device__ __forceinline__ void load_vec(float (&dst)[V], const char* base) {
+    using T = typename VecT<V>::type;
+    T v = *reinterpret_cast<const T*>(base);
+    if constexpr (V == 1) {
+        dst[0] = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = v[i];
+    }
+}
+
+template <int V, bool NT>
+__device__ __forceinline__ void store_vec(float* p, const float (&src)[V]) {
+    using T = typename VecT<V>::type;
+    T v;
+    if constexpr (V == 1) {
+        v = src[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = src[i];
+    }
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+    else *reinterpret_cast<T*>(p) = v;
+}
+
+// Workgroup id -> work item id such that XCD x (which receives ids == x mod 8)
+// gets a contiguous slice of the item range. Bijective for every n.
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// Ordering of a wavefront's own LDS traffic (write by lane i, read by lane j of
+// the same wavefront). DS operations of one wavefront execute in issue order, so
+// no hardware barrier is needed — only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int RED, bool VALUED>
+__device__ __forceinline__ float combine(float acc, float a, float b) {
+    if constexpr (RED == kReduceMax) {
+        return fmaxf(acc, b);
+    } else if constexpr (VALUED) {
+        return __builtin_fmaf(a, b, acc);
+    } else {
+        return acc + b;  // A == 1: identical to fma(1, b, acc)
+    }
+}
+
+constexpr int unroll_for(int cf) { return cf >= 8 ? 2 : (cf >= 4 ? 4 : 8); }
+
+// ----------------------------------------------------------------------------- CRC (+CWM) kernel
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC, bool NTS>
+__global__ __launch_bounds__(kThreads) void spmm_rowgroup_kernel(SpmmArgs a) {
+    constexpr int G = 64 / W;  // rows per wavefront
+    constexpr int U = unroll_for(V * S);
+    using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
+
+    __shared__ off_t s_off[CRC ? kWaves : 1][CRC ? kTile : 1];
+    __shared__ float s_val[(CRC && VALUED) ? kWaves : 1][(CRC && VALUED) ? kTile : 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / W;
+    const int l = lane % W;
+
+    const int nitems = a.nblk * a.ntile;
+    const int item = (a.flags & kFlagNoXcdRemap) ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, nitems);
+    const int tile = item % a.ntile;
+    const int rb = item / a.ntile;
+
+    const int row0 = (rb * kWaves + wave) * G;  // first row of this wavefront
+    if (row0 >= a.M) return;                    // whole wavefront leaves together
+    const int row = row0 + g;
+    const int col0 = tile * (W * V * S) + l * V;
+
+    bool colok[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) colok[s] = (col0 + s * W * V) < a.N;
+    const bool rowok = row < a.M;
+
+    int lb = 0, hb = 0;
+    if (rowok) {
+        lb = a.rowptr[row];
+        hb = a.rowptr[row + 1];
+    }
+    // CSR range covered by the whole wavefront (its G rows are consecutive).
+    const int lastg = (a.M - row0 < G ? a.M - row0 : G) - 1;
+    const int wb = __builtin_amdgcn_readfirstlane(lb);
+    const int we = __builtin_amdgcn_readlane(hb, lastg * W);
+    if constexpr (G == 1) {  // one row per wavefront: bounds are wave-uniform, keep them scalar
+        lb = wb;
+        hb = we;
+    }
+    const float init = (RED == kReduceMax) ? a.empty : 0.0f;
+    float acc[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[s][i] = init;
+
+    // Lanes/strips that fall outside N in the last column tile gather from column 0
+    // instead (always valid, same cache line as lane 0) and simply skip the store:
+    // the inner loop carries no per-lane predicate and stays wave-uniform for G == 1.
+    // Addresses are formed as (uniform base) + (off_t byte offset): with 32-bit
+    // offsets that is the SGPR-base + 32-bit-VGPR-offset form of global_load.
+    const char* Bbase = reinterpret_cast<const char*>(a.B);
+    off_t cbytes[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
+    const off_t rowbytes = (off_t)a.N * 4u;
+
+    auto gather_steps = [&](auto fetch, int kb, int ke) {
+        // fetch(k, off, v): entry k -> byte offset of its B row, its value
+        int k = kb;
+        for (; k + U <= ke; k += U) {
+            off_t off[U];
+            float v[U];
+            float b[U][S][V];
+#pragma unroll
+            for (int j = 0; j < U; ++j) fetch(k + j, off[j], v[j]);
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+#pragma unroll
+                for (int s = 0; s < S; ++s) load_vec<V>(b[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], b[j][s][i]);
+        }
+        for (; k < ke; ++k) {
+            off_t off;
+            float v;
+            float b[S][V];
+            fetch(k, off, v);
+#pragma unroll
+            for (int s = 0; s < S; ++s) load_vec<V>(b[s], Bbase + (off_t)(off + cbytes[s]));
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v, b[s][i]);
+        }
+    };
+
+    if constexpr (CRC) {
+        // Register prefetch of the first tile.
+        int pc = 0;
+        float pv = 0.0f;
+        {
+            const int p = wb + lane;
+            if (p < we) {
+                pc = __builtin_nontemporal_load(a.colind + p);
+                if constexpr (VALUED) pv = __builtin_nontemporal_load(a.val + p);
+            }
+        }
+        for (int cb = wb; cb < we; cb += kTile) {
+            s_off[wave][lane] = (off_t)(uint32_t)pc * rowbytes;
+            if constexpr (VALUED) s_val[wave][lane] = pv;
+            {  // prefetch the next tile while this one is consumed
+                const int p = cb + kTile + lane;
+                if (p < we) {
+                    pc = __builtin_nontemporal_load(a.colind + p);
+                    if constexpr (VALUED) pv = __builtin_nontemporal_load(a.val + p);
+                }
+            }
+            wave_lds_sync();
+            const int kb = (lb > cb ? lb : cb) - cb;
+            const int ke = (hb < cb + kTile ? hb : cb + kTile) - cb;
+            gather_steps(
+                [&](int k, off_t& off, float& v) {
+                    off = s_off[wave][k];
+                    if constexpr (VALUED) v = s_val[wave][k];
+                    else v = 1.0f;
+                },
+                kb, ke);
+            wave_lds_sync();
+        }
+    } else {
+        // Naive variant (reference method 0): every lane reads colind/val itself.
+        gather_steps(
+            [&](int k, off_t& off, float& v) {
+                off = (off_t)(uint32_t)a.colind[k] * rowbytes;
+                if constexpr (VALUED) v = a.val[k];
+                else v = 1.0f;
+            },
+            lb, hb);
+    }
+
+    if (rowok) {
+        float* Crow = a.C + (size_t)row * (size_t)a.N + col0;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (colok[s]) store_vec<V, NTS>(Crow + s * (W * V), acc[s]);
+    }
+}
+
+// ----------------------------------------------------------------------------- parallel-reduction kernel
+//
+// Lanes of a W-wide group stride over the row's non-zeros; each lane keeps NC
+// partial sums (NC output columns per pass) and the group combines them with an
+// xor butterfly (ds_bpermute / DPP cross-lane moves, no LDS storage). Meant for
+// narrow N (GCN's class-logit layer, N = 3..8) and long rows, where the row-group
+// kernel would leave most lanes idle. The summation order differs from the
+// reference, so this variant is tolerance-checked, never bit-checked.
+
+template <int W, int NC, bool VALUED, bool IDX64>
+__global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
+    constexpr int G = 64 / W;
+    using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / W;
+    const int l = lane % W;
+    const int item = (a.flags & kFlagNoXcdRemap) ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, a.nblk);
+    const int row = (item * kWaves + wave) * G + g;
+    const bool rowok = row < a.M;
+    int lb = 0, hb = 0;
+    if (rowok) {
+        lb = a.rowptr[row];
+        hb = a.rowptr[row + 1];
+    }
+    for (int c0 = 0; c0 < a.N; c0 += NC) {
+        float part[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) part[i] = 0.0f;
+        for (int k = lb + l; k < hb; k += W) {
+            const off_t off = (off_t)(uint32_t)a.colind[k] * (off_t)a.N + (off_t)c0;
+            const float v = VALUED ? a.val[k] : 1.0f;
+            const float* brow = a.B + off;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (c0 + i < a.N) part[i] = __builtin_fmaf(v, brow[i], part[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int m = W >> 1; m > 0; m >>= 1) part[i] += __shfl_xor(part[i], m, 64);
+        if (rowok && l == 0) {
+            float* crow = a.C + (size_t)row * (size_t)a.N + c0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (c0 + i < a.N) crow[i] = part[i];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- host-side launch table
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC>
+static hipError_t launch_rowgroup(const SpmmArgs& a, bool nts, hipStream_t st) {
+    constexpr int G = 64 / W;
+    SpmmArgs args = a;
+    args.nblk = (int)(((int64_t)a.M + kWaves * G - 1) / (kWaves * G));
+    args.ntile = (a.N + W * V * S - 1) / (W * V * S);
+    const int64_t nitems = (int64_t)args.nblk * args.ntile;
+    if (nitems <= 0) return hipSuccess;
+    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    dim3 grid((unsigned)nitems), block(kThreads);
+    if (nts) hipLaunchKernelGGL((spmm_rowgroup_kernel<V, S, W, VALUED, IDX64, RED, CRC, true>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((spmm_rowgroup_kernel<V, S, W, VALUED, IDX64, RED, CRC, false>), grid, block, 0, st, args);
+    return hipGetLastError();
+}
+
+template <int V, int S, bool VALUED, bool IDX64, int RED, bool CRC>
+static hipError_t dispatch_w(const SpmmArgs& a, int W, bool nts, hipStream_t st) {
+    switch (W) {
+        case 4: return launch_rowgroup<V, S, 4, VALUED, IDX64, RED, CRC>(a, nts, st);
+        case 8: return launch_rowgroup<V, S, 8, VALUED, IDX64, RED, CRC>(a, nts, st);
+        case 16: return launch_rowgroup<V, S, 16, VALUED, IDX64, RED, CRC>(a, nts, st);
+        case 32: return launch_rowgroup<V, S, 32, VALUED, IDX64, RED, CRC>(a, nts, st);
+        case 64: return launch_rowgroup<V, S, 64, VALUED, IDX64, RED, CRC>(a, nts, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <bool VALUED, bool IDX64, int RED, bool CRC>
+static hipError_t dispatch_vs(const SpmmArgs& a, int V, int S, int W, bool nts, hipStream_t st) {
+    if (S == 2) {
+        if (V == 4) return dispatch_w<4, 2, VALUED, IDX64, RED, CRC>(a, W, nts, st);
+        return hipErrorInvalidValue;
+    }
+    switch (V) {
+        case 1: return dispatch_w<1, 1, VALUED, IDX64, RED, CRC>(a, W, nts, st);
+        case 2: return dispatch_w<2, 1, VALUED, IDX64, RED, CRC>(a, W, nts, st);
+        case 4: return dispatch_w<4, 1, VALUED, IDX64, RED, CRC>(a, W, nts, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+    const bool valued = a.val != nullptr;
+    const bool nts = (a.flags & kFlagNtStore) != 0;
+    if (geo.reduce == kReduceMax) {
+        // max reducer exists for the unweighted CRC path only (binary_reduce_max.cu).
+        if (valued || !geo.crc) return hipErrorInvalidValue;
+        if (geo.idx64) return dispatch_vs<false, true, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, nts, st);
+        return dispatch_vs<false, false, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, nts, st);
+    }
+#define GESPMM_DISPATCH(VAL, I64, CRCF) \
+    return dispatch_vs<VAL, I64, kReduceSum, CRCF>(a, geo.vec, geo.strips, geo.group, nts, st)
+    if (geo.crc) {
+        if (valued) { if (geo.idx64) GESPMM_DISPATCH(true, true, true); else GESPMM_DISPATCH(true, false, true); }
+        else        { if (geo.idx64) GESPMM_DISPATCH(false, true, true); else GESPMM_DISPATCH(false, false, true); }
+    } else {
+        if (valued) { if (geo.idx64) GESPMM_DISPATCH(true, true, false); else GESPMM_DISPATCH(true, false, false); }
+        else        { if (geo.idx64) GESPMM_DISPATCH(false, true, false); else GESPMM_DISPATCH(false, false, false); }
+    }
+#undef GESPMM_DISPATCH
+}
+
+template <int W, bool VALUED, bool IDX64>
+static hipError_t launch_parreduce_w(const SpmmArgs& a, hipStream_t st) {
+    constexpr int G = 64 / W;
+    SpmmArgs args = a;
+    args.nblk = (int)(((int64_t)a.M + kWaves * G - 1) / (kWaves * G));
+    args.ntile = 1;
+    if (args.nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL((spmm_parreduce_kernel<W, 4, VALUED, IDX64>), dim3(args.nblk), dim3(kThreads), 0, st, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+    const bool valued = a.val != nullptr;
+#define GESPMM_PR(W)                                                                         \
+    case W:                                                                                   \
+        if (valued) return geo.idx64 ? launch_parreduce_w<W, true, true>(a, st) : launch_parreduce_w<W, true, false>(a, st); \
+        return geo.idx64 ? launch_parreduce_w<W, false, true>(a, st) : launch_parreduce_w<W, false, false>(a, st);
+    switch (geo.group) {
+        GESPMM_PR(4)
+        GESPMM_PR(8)
+        GESPMM_PR(16)
+        GESPMM_PR(32)
+        GESPMM_PR(64)
+    }
+#undef GESPMM_PR
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gespmm

@@ -1,0 +1,323 @@
+// spmm_test.cpp — the benchmark driver (drop-in boundary #1).
+//
+// Same command line, stdout lines, CSV side file and exit behaviour as the
+// reference's driver (spmm_test.cu:495-826, built by compile.sh:1, looped by
+// run_test.sh:5-29):
+//
+//     ./spmm_test <file.mtx> [device_id=0]
+//
+//   stdout:  "reading file ...", "read file ok. N=%d nnz=%d", "max_ncols = %d",
+//            "running tests..."
+//   appends to ./spmm_test_out.out, for N in {128,256,512} (<= max_ncols), the pair
+//            "<vendor GFLOP/s>,<GE-SpMM GFLOP/s>," with no newline (run_test.sh adds
+//            the matrix name and the newline). The vendor column is rocSPARSE-less
+//            in this build and prints 0.000000 (a "next" row).
+//   exit 1 on a missing file / bad banner (util.hpp:300-313), EXIT_FAILURE on a
+//   device error, 0 otherwise. Device allocation failure halves max_ncols and
+//   retries, like spmm_test.cu:619-634.
+//
+// Everything device-side goes through the C ABI (include/gespmm.h); this file only
+// owns host buffers, device buffers, events and the CSV. Options the reference
+// hard-codes are flags here, with the reference's values as defaults:
+//   --ncols a,b,c   feature widths to time           (default 128,256,512; spmm_test.cu:726)
+//   --method m      kernel variant, -1 = library pick (default 2 = CRC+CWM2; spmm_test.cu:756)
+//   --iters n       timed launches per width          (default 200; spmm_test.cu:714)
+//   --seed s        srand seed for B                  (default time(0); spmm_test.cu:587)
+//   --use-values    keep the file's values            (default: all ones; spmm_test.cu:574)
+//   --validate      run every variant at N=max_ncols against an in-driver CPU loop and
+//                   print "kernel<m> WA: ..." on |diff| > 1e-2 (the reference's
+//                   `#define VALIDATE` block, spmm_test.cu:595-605, 671-698). The CPU
+//                   loop only CHECKS device output; it never produces results.
+//   --cpu-baseline  time that CPU loop (1 thread) and print its GFLOP/s
+//   --out path      CSV side file                     (default spmm_test_out.out)
+//
+// There is no CPU fallback: without a HIP device the driver fails with EXIT_FAILURE.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../include/gespmm.h"
+
+__global__ void warmup() {}
+
+namespace {
+
+struct Buffers {
+    gespmm_coo coo{};
+    int32_t* indptr = nullptr;
+    int32_t* indices = nullptr;
+    float* data = nullptr;
+    float* B = nullptr;
+    float* C = nullptr;
+    float* golden = nullptr;
+    int32_t* indptr_dev = nullptr;
+    int32_t* indices_dev = nullptr;
+    float* data_dev = nullptr;
+    float* B_dev = nullptr;
+    float* C_dev = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+    FILE* fpo = nullptr;
+    void release() {
+        gespmm_mtx_free(&coo);
+        free(indptr);
+        free(indices);
+        free(data);
+        free(B);
+        free(C);
+        free(golden);
+        if (indptr_dev) (void)hipFree(indptr_dev);
+        if (indices_dev) (void)hipFree(indices_dev);
+        if (data_dev) (void)hipFree(data_dev);
+        if (B_dev) (void)hipFree(B_dev);
+        if (C_dev) (void)hipFree(C_dev);
+        if (start) (void)hipEventDestroy(start);
+        if (stop) (void)hipEventDestroy(stop);
+        if (fpo) fclose(fpo);
+        fflush(stdout);
+    }
+};
+
+Buffers g;
+
+[[noreturn]] void die_hip(hipError_t e, int line) {
+    fprintf(stderr, "HIP runtime error in line %d of file %s : %s \n", line, __FILE__, hipGetErrorString(e));
+    printf("Exit.");
+    g.release();
+    exit(EXIT_FAILURE);
+}
+#define CHECK_HIP(x)                              \
+    do {                                          \
+        hipError_t e_ = (x);                      \
+        if (e_ != hipSuccess) die_hip(e_, __LINE__); \
+    } while (0)
+
+[[noreturn]] void die_gespmm(int rc, int line) {
+    fprintf(stderr, "gespmm error in line %d of file %s : %s \n", line, __FILE__, gespmm_error_string(rc));
+    printf("Exit.");
+    g.release();
+    exit(EXIT_FAILURE);
+}
+#define CHECK_GE(x)                         \
+    do {                                    \
+        int rc_ = (x);                      \
+        if (rc_ != 0) die_gespmm(rc_, __LINE__); \
+    } while (0)
+
+// The reference's validation loop (spmm_test.cu:596-604): rows, then columns, then
+// the row's non-zeros in CSR order, fp32 accumulator. Checker only.
+void cpu_check_loop(int M, int N, const int32_t* indptr, const int32_t* indices, const float* data, const float* B,
+                    float* out) {
+    for (int i = 0; i < M; i++)
+        for (int k = 0; k < N; k++) {
+            float acc = 0.0f;
+            for (int p = indptr[i]; p < indptr[i + 1]; p++) acc += data[p] * B[(size_t)N * indices[p] + k];
+            out[(size_t)N * i + k] = acc;
+        }
+}
+
+std::vector<int> parse_list(const char* s) {
+    std::vector<int> v;
+    while (*s) {
+        char* e;
+        long x = strtol(s, &e, 10);
+        if (e == s) break;
+        v.push_back((int)x);
+        s = (*e == ',') ? e + 1 : e;
+    }
+    return v;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    int max_ncols = 512;
+    int dev_id = 0;
+    int method = GESPMM_VARIANT_CRC_CWM2;
+    int iters = 200;
+    bool validate = false, cpu_baseline = false, use_values = false, seed_given = false;
+    unsigned seed = 0;
+    std::vector<int> ncols_list;
+    const char* out_path = "spmm_test_out.out";
+    const char* mtx_path = nullptr;
+    int positional = 0;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&](const char* flag) -> const char* {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "%s needs a value\n", flag);
+                exit(EXIT_FAILURE);
+            }
+            return argv[++i];
+        };
+        if (a == "--ncols") ncols_list = parse_list(next("--ncols"));
+        else if (a == "--method") method = atoi(next("--method"));
+        else if (a == "--iters") iters = atoi(next("--iters"));
+        else if (a == "--seed") { seed = (unsigned)strtoul(next("--seed"), nullptr, 10); seed_given = true; }
+        else if (a == "--out") out_path = next("--out");
+        else if (a == "--validate") validate = true;
+        else if (a == "--cpu-baseline") cpu_baseline = true;
+        else if (a == "--use-values") use_values = true;
+        else if (positional == 0) { mtx_path = argv[i]; positional++; }
+        else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
+    }
+    if (!mtx_path) {
+        fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
+                        "[--use-values] [--validate] [--cpu-baseline] [--out path]\n", argv[0]);
+        return EXIT_FAILURE;
+    }
+    if (iters < 1) iters = 1;
+
+    g.fpo = fopen(out_path, "a");
+    printf("reading file ...\n");
+    int rc = gespmm_mtx_read(mtx_path, &g.coo);
+    if (rc == GESPMM_EIO) {
+        printf("File %s not found", mtx_path);
+        g.release();
+        exit(1);
+    }
+    if (rc == GESPMM_EFORMAT) {
+        printf("Could not process Matrix Market banner.\n");
+        g.release();
+        exit(1);
+    }
+    if (rc != 0) {
+        printf("%s\n", gespmm_error_string(rc));
+        g.release();
+        exit(1);
+    }
+    const int M = g.coo.nrows, K = g.coo.ncols;
+    const int nnz = (int)g.coo.nnz;
+
+    if (!ncols_list.empty())
+        for (int n : ncols_list)
+            if (n > max_ncols) max_ncols = n;
+
+    g.data = (float*)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+    g.indptr = (int32_t*)malloc(((size_t)M + 1) * sizeof(int32_t));
+    g.indices = (int32_t*)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
+    g.B = (float*)malloc((size_t)max_ncols * (size_t)K * sizeof(float));
+    if (validate || cpu_baseline) {
+        g.C = (float*)malloc((size_t)M * (size_t)max_ncols * sizeof(float));
+        g.golden = (float*)malloc((size_t)M * (size_t)max_ncols * sizeof(float));
+        if (!g.C || !g.golden) {
+            printf("Host malloc failed\n");
+            g.release();
+            return 1;
+        }
+    }
+    if (!g.data || !g.indices || !g.indptr || !g.B) {
+        printf("Host malloc failed\n");
+        g.release();
+        return 1;
+    }
+
+    rc = gespmm_coo_to_csr(M, K, nnz, g.coo.row, g.coo.col, use_values ? g.coo.val : nullptr, g.indptr, g.indices,
+                           g.data);
+    if (rc != 0) {
+        fprintf(stderr, "out of bound row or column\n");
+        g.release();
+        return 1;
+    }
+    printf("read file ok. N=%d nnz=%d\n", M, nnz);
+
+    if (!seed_given) seed = (unsigned)time(0);
+    srand(seed);
+    for (size_t i = 0; i < (size_t)max_ncols * (size_t)K; i++) g.B[i] = float(rand() % 100 - 50) / 100;
+
+    double cpu_gflops = 0.0;
+    if (validate || cpu_baseline) {
+        const auto t0 = std::chrono::steady_clock::now();
+        cpu_check_loop(M, max_ncols, g.indptr, g.indices, g.data, g.B, g.golden);
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        cpu_gflops = 2.0 * nnz * max_ncols / s / 1e9;
+    }
+
+    CHECK_HIP(hipSetDevice(dev_id));
+    for (;;) {
+        hipError_t s1 = hipMalloc((void**)&g.indptr_dev, ((size_t)M + 1) * sizeof(int32_t));
+        hipError_t s2 = hipMalloc((void**)&g.indices_dev, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
+        hipError_t s3 = hipMalloc((void**)&g.data_dev, (size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+        hipError_t s4 = hipMalloc((void**)&g.B_dev, (size_t)max_ncols * (size_t)K * sizeof(float));
+        hipError_t s5 = hipMalloc((void**)&g.C_dev, (size_t)M * (size_t)max_ncols * sizeof(float));
+        if (s1 == hipSuccess && s2 == hipSuccess && s3 == hipSuccess && s4 == hipSuccess && s5 == hipSuccess) break;
+        if (s1 == hipErrorNoDevice || s1 == hipErrorInvalidDevice) die_hip(s1, __LINE__);
+        (void)hipGetLastError();
+        if (g.indptr_dev) { (void)hipFree(g.indptr_dev); g.indptr_dev = nullptr; }
+        if (g.indices_dev) { (void)hipFree(g.indices_dev); g.indices_dev = nullptr; }
+        if (g.data_dev) { (void)hipFree(g.data_dev); g.data_dev = nullptr; }
+        if (g.B_dev) { (void)hipFree(g.B_dev); g.B_dev = nullptr; }
+        if (g.C_dev) { (void)hipFree(g.C_dev); g.C_dev = nullptr; }
+        max_ncols /= 2;
+        if (max_ncols < 1) die_hip(hipErrorOutOfMemory, __LINE__);
+    }
+    printf("max_ncols = %d\n", max_ncols);
+
+    CHECK_HIP(hipMemcpy(g.indptr_dev, g.indptr, ((size_t)M + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        CHECK_HIP(hipMemcpy(g.indices_dev, g.indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(g.data_dev, g.data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // B holds max_ncols columns at upload time; every timed width N re-reads it with
+    // leading dimension N (spmm_test.cu:732,757 do exactly that with the same buffer).
+    CHECK_HIP(hipMemcpy(g.B_dev, g.B, (size_t)max_ncols * (size_t)K * sizeof(float), hipMemcpyHostToDevice));
+
+    hipLaunchKernelGGL(warmup, dim3(1), dim3(1), 0, 0);
+    CHECK_HIP(hipDeviceSynchronize());
+
+    if (validate) {
+        const int N = max_ncols;
+        for (int m = 0; m < GESPMM_NUM_VARIANTS; m++) {
+            CHECK_HIP(hipMemset(g.C_dev, 0, (size_t)M * N * sizeof(float)));
+            CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, m,
+                                         nullptr));
+            CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
+            for (int i = 0; i < M; i++)
+                for (int j = 0; j < N; j++)
+                    if (fabs(g.C[(size_t)i * N + j] - g.golden[(size_t)i * N + j]) > 1e-2) {
+                        printf("kernel%d WA: C[%d, %d] = %f, golden = %f\n", m, i, j, g.C[(size_t)i * N + j],
+                               g.golden[(size_t)i * N + j]);
+                        break;
+                    }
+        }
+        printf("validate done (%d variants, N=%d)\n", GESPMM_NUM_VARIANTS, N);
+    }
+    if (cpu_baseline) printf("cpu golden loop: %f GFLOP/s (1 thread, N=%d)\n", cpu_gflops, max_ncols);
+
+    CHECK_HIP(hipEventCreate(&g.start));
+    CHECK_HIP(hipEventCreate(&g.stop));
+    for (int i = 0; i < 200; i++) hipLaunchKernelGGL(warmup, dim3(1), dim3(1), 0, 0);
+    printf("running tests...\n");
+
+    if (ncols_list.empty())
+        for (int n = 128; n <= max_ncols; n *= 2) ncols_list.push_back(n);
+    for (int N : ncols_list) {
+        if (N > max_ncols || N < 1) continue;
+        const double gflop = (double)nnz * 2 / 1000000 * N;
+        float rt = 0.0f;
+        // vendor column (reference: cusparseScsrmm2, spmm_test.cu:730-738): not built in
+        if (g.fpo) fprintf(g.fpo, "%f,", 0.0);
+
+        CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, method,
+                                     nullptr));
+        CHECK_HIP(hipEventRecord(g.start, 0));
+        for (int i = 0; i < iters; i++)
+            CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz,
+                                         method, nullptr));
+        CHECK_HIP(hipEventRecord(g.stop, 0));
+        CHECK_HIP(hipEventSynchronize(g.stop));
+        CHECK_HIP(hipEventElapsedTime(&rt, g.start, g.stop));
+        if (g.fpo) fprintf(g.fpo, "%f,", gflop / (rt / iters));
+        printf("N=%d method=%d: %f ms/iter, %f GFLOP/s\n", N, method, rt / iters, gflop / (rt / iters));
+    }
+
+    g.release();
+    return 0;
+}

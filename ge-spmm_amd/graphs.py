@@ -1,0 +1,247 @@
+"""Graph inputs for the SpMM path: MatrixMarket files through the C ABI, and seeded
+synthetic stand-ins for the SNAP / DGL / OGB graphs BASELINE.json names (there is no
+network on either box).
+
+Loader side (host memory, numpy):
+    read_mtx(path)                       <- readMtx<float>()          util/util.hpp:286-333
+    coo_to_csr(nrows, ncols, row, col)   <- inline COO->CSR           spmm_test.cu:557-581
+    load_mtx_as_csr(path)                =  both, values forced to 1  spmm_test.cu:574
+
+Synthetic side (torch, runs on whatever device the generator is given — the big
+graphs are built on the GPU). Every generator is a pure function of (name, seed):
+    synthetic_graph("com-amazon-like" | "cit-hepth-like" | "reddit-like" |
+                    "products-like" | "pubmed-selfloop-like", ...)
+Node ids carry NO locality by default (ids are scrambled by an affine bijection):
+the reference's own spreadsheet numbers for com-Amazon/pubmed are consistent with
+every B-row gather missing a 2.75 MB L2 (DESIGN.md "Synthetic graphs"), so the
+stand-ins do not assume an id ordering that would flatter the caches. ``locality``
+> 0 re-introduces a banded community structure for sensitivity runs.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from ._lib import Coo, check, lib
+
+# name -> (M, nnz, symmetric, gamma)   sizes from SURVEY.md §8 config table
+SPECS = {
+    "cit-hepth-like": (27770, 352807, False, 1.5),
+    "com-amazon-like": (334863, 1851744, True, 1.55),  # max degree ~550 like the SNAP graph
+    "reddit-like": (232965, 114615892, True, 1.5),
+    "products-like": (2449029, 123718280, True, 1.5),
+    "pubmed-like": (19717, 88648, True, 1.5),
+}
+
+
+# ----------------------------------------------------------------------------- MatrixMarket via the C ABI
+
+def read_mtx(path):
+    """Returns dict(nrows, ncols, nnz, row, col, val) with numpy arrays (0-based,
+    sorted by (row, col); symmetric files expanded, self-loops/duplicates dropped)."""
+    coo = Coo()
+    check(lib.gespmm_mtx_read(str(path).encode(), ctypes.byref(coo)), "gespmm_mtx_read(%s)" % path)
+    try:
+        n = int(coo.nnz)
+        if n:
+            row = np.ctypeslib.as_array(coo.row, shape=(n,)).copy()
+            col = np.ctypeslib.as_array(coo.col, shape=(n,)).copy()
+            val = np.ctypeslib.as_array(coo.val, shape=(n,)).copy()
+        else:
+            row = np.zeros(0, np.int32)
+            col = np.zeros(0, np.int32)
+            val = np.zeros(0, np.float32)
+        return {"nrows": int(coo.nrows), "ncols": int(coo.ncols), "nnz": n, "row": row, "col": col, "val": val}
+    finally:
+        lib.gespmm_mtx_free(ctypes.byref(coo))
+
+
+def coo_to_csr(nrows, ncols, row, col, val=None):
+    """Counting sort by row, input order kept inside a row. val=None -> all ones
+    (what the reference driver does with file values, spmm_test.cu:574)."""
+    row = np.ascontiguousarray(row, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    nnz = row.shape[0]
+    if col.shape[0] != nnz:
+        raise ValueError("row and col must have the same length")
+    rowptr = np.empty(nrows + 1, dtype=np.int32)
+    colind = np.empty(max(nnz, 1), dtype=np.int32)
+    vals = np.empty(max(nnz, 1), dtype=np.float32)
+    vin = None
+    if val is not None:
+        vin = np.ascontiguousarray(val, dtype=np.float32)
+    rc = lib.gespmm_coo_to_csr(nrows, ncols, nnz, row.ctypes.data, col.ctypes.data,
+                               vin.ctypes.data if vin is not None else None, rowptr.ctypes.data,
+                               colind.ctypes.data, vals.ctypes.data)
+    check(rc, "gespmm_coo_to_csr")
+    return rowptr, colind[:nnz], vals[:nnz]
+
+
+def load_mtx_as_csr(path, use_values=False):
+    coo = read_mtx(path)
+    rowptr, colind, vals = coo_to_csr(coo["nrows"], coo["ncols"], coo["row"], coo["col"],
+                                      coo["val"] if use_values else None)
+    return {"M": coo["nrows"], "K": coo["ncols"], "nnz": coo["nnz"], "rowptr": rowptr, "colind": colind,
+            "val": vals}
+
+
+def row_partition(rowptr, parts):
+    """nnz-balanced contiguous row ranges: returns cut[parts+1] (numpy int64)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    cut = np.empty(parts + 1, dtype=np.int64)
+    check(lib.gespmm_row_partition(rowptr.ctypes.data, rowptr.shape[0] - 1, parts, cut.ctypes.data),
+          "gespmm_row_partition")
+    return cut
+
+
+# ----------------------------------------------------------------------------- synthetic graphs
+
+def _coprime_multiplier(M, seed):
+    a = (2654435761 * (seed + 1)) % M
+    a = max(a, 1)
+    while math.gcd(a, M) != 1:
+        a += 1
+    return a
+
+
+def _endpoints(n, M, gamma, gen, device):
+    """n node ids with a power-law-ish popularity: floor(M * u^gamma), then scrambled
+    so that popular nodes are spread over the id range."""
+    u = torch.rand(n, generator=gen, device=device, dtype=torch.float64)
+    idx = torch.clamp((u.pow(gamma) * M).to(torch.int64), max=M - 1)
+    return idx
+
+
+def _scramble(idx, M, seed):
+    a = _coprime_multiplier(M, seed)
+    b = (97 * (seed + 7)) % M
+    return (idx * a + b) % M
+
+
+def synthetic_csr(M, nnz, symmetric=True, gamma=1.5, seed=42, device="cpu", locality=0.0, band=2000, K=None,
+                  col_offset=0):
+    """Seeded random graph with EXACTLY ``nnz`` stored entries and no duplicates.
+
+    symmetric: undirected edges (i != j) stored in both directions (nnz must be even);
+               otherwise directed, self-loops allowed.
+    gamma:     popularity skew of the endpoints (1 = uniform, larger = heavier tail).
+    locality:  fraction of edges whose second endpoint is drawn within a Laplace(band)
+               window of the first (in id space) instead of by popularity. 0 = none.
+    K / col_offset: rectangular use (multi-GPU row shards): columns live in
+               [col_offset, col_offset + M) of a K-column matrix.
+    Returns (rowptr int32[M+1], colind int32[nnz]) torch tensors on ``device``;
+    column indices are ascending inside every row.
+    """
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    if symmetric and nnz % 2:
+        raise ValueError("symmetric graphs need an even nnz")
+    target = nnz // 2 if symmetric else nnz
+    if target > (M * (M - 1) // 2 if symmetric else M * M):
+        raise ValueError("nnz exceeds the number of distinct entries")
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    want = target
+    rounds = 0
+    while keys.numel() < target:
+        rounds += 1
+        n = int(want * 1.15) + 1024
+        u = _scramble(_endpoints(n, M, gamma, gen, device), M, seed)
+        v = _scramble(_endpoints(n, M, gamma, gen, device), M, seed)
+        if locality > 0.0:
+            is_local = torch.rand(n, generator=gen, device=device) < locality
+            # Laplace(band) offset = difference of two exponentials
+            e1 = -torch.log1p(-torch.rand(n, generator=gen, device=device, dtype=torch.float64))
+            e2 = -torch.log1p(-torch.rand(n, generator=gen, device=device, dtype=torch.float64))
+            off = ((e1 - e2) * band).to(torch.int64)
+            v = torch.where(is_local, (u + off) % M, v)
+        if symmetric:
+            lo = torch.minimum(u, v)
+            hi = torch.maximum(u, v)
+            k = lo * M + hi
+            k = k[lo != hi]
+        else:
+            k = u * M + v
+        keys = torch.unique(torch.cat([keys, k]))
+        want = max(target - keys.numel(), 0)
+        if rounds > 64:
+            raise RuntimeError("synthetic_csr did not converge")
+    if keys.numel() > target:
+        sel = torch.randperm(keys.numel(), generator=gen, device=device)[:target]
+        keys = keys[sel]
+    r = keys // M
+    c = keys % M
+    if symmetric:
+        r, c = torch.cat([r, c]), torch.cat([c, r])
+    order = torch.argsort(r * M + c)
+    r = r[order]
+    c = c[order]
+    counts = torch.bincount(r, minlength=M)
+    rowptr = torch.zeros(M + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    if K is not None:
+        c = c + int(col_offset)
+    return rowptr.to(torch.int32), c.to(torch.int32)
+
+
+def synthetic_graph(name, seed=42, device="cpu", locality=0.0, band=2000, scale=1.0):
+    """One of the named stand-ins. ``scale`` < 1 shrinks M and nnz
+    proportionally (CPU-sized tests); scale == 1 reproduces the exact M / nnz."""
+    if name == "pubmed-selfloop-like":
+        M, nnz, sym, gamma = SPECS["pubmed-like"]
+    else:
+        M, nnz, sym, gamma = SPECS[name]
+    if scale != 1.0:
+        M = max(int(M * scale), 8)
+        nnz = max(int(nnz * scale), 8)
+        if sym:
+            nnz -= nnz % 2
+    rowptr, colind = synthetic_csr(M, nnz, sym, gamma, seed, device, locality, band)
+    if name == "pubmed-selfloop-like":  # gcn_custom.py:29-36 adds one self-loop per node
+        rowptr, colind = add_self_loops(rowptr, colind)
+    return {"name": name, "M": M, "K": M, "nnz": int(colind.numel()), "rowptr": rowptr, "colind": colind}
+
+
+def add_self_loops(rowptr, colind):
+    """A + I on a CSR pattern without existing self-loops (columns stay sorted)."""
+    M = rowptr.numel() - 1
+    dev = rowptr.device
+    counts = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(M, device=dev), counts)
+    r = torch.cat([rows, torch.arange(M, device=dev)])
+    c = torch.cat([colind.to(torch.int64), torch.arange(M, device=dev)])
+    order = torch.argsort(r * M + c)
+    r = r[order]
+    c = c[order]
+    newptr = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+    newptr[1:] = torch.cumsum(torch.bincount(r, minlength=M), 0)
+    return newptr.to(torch.int32), c.to(torch.int32)
+
+
+def transpose_csr(rowptr, colind, K=None, val=None):
+    """CSC arrays (colptr, rowind[, cscval]) of a CSR pattern, rows ascending inside a
+    column — host-side helper for callers that build both orders once, like
+    gcn_custom.py:39-46 does with scipy. Pure index manipulation with torch ops."""
+    M = rowptr.numel() - 1
+    K = M if K is None else K
+    dev = rowptr.device
+    counts = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(M, device=dev), counts)
+    key = colind.to(torch.int64) * M + rows
+    order = torch.argsort(key)
+    colptr = torch.zeros(K + 1, dtype=torch.int64, device=dev)
+    colptr[1:] = torch.cumsum(torch.bincount(colind.to(torch.int64), minlength=K), 0)
+    rowind = rows[order].to(torch.int32)
+    if val is not None:
+        return colptr.to(torch.int32), rowind, val[order]
+    return colptr.to(torch.int32), rowind
+
+
+def reference_B(K, N, seed=1, device="cpu"):
+    """Dense operand with the reference driver's value set, float(r % 100 - 50) / 100
+    (spmm_test.cu:586-594), from a seeded torch generator instead of libc rand()."""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(int(seed))
+    r = torch.randint(0, 100, (K, N), generator=gen, dtype=torch.int32)
+    return ((r - 50).to(torch.float32) / 100).to(device)

@@ -1,0 +1,140 @@
+"""SPMMFunction and GCNConv — mirror of the reference's pytorch-custom/op.py.
+
+    SPMMFunction.apply(rowptr, colind, colptr, rowind, feat,
+                       edge_weight_csr=None, edge_weight_csc=None)        op.py:8-36
+    GCNConv(in_channels, out_channels, improved=False, cached=False,
+            bias=True, normalize=True).forward(x, rowptr, colind, colptr, rowind,
+            edge_weight_csr=None, edge_weight_csc=None)                   op.py:77-152
+
+Semantics kept from the reference:
+  * forward picks the unweighted kernel iff ``edge_weight_csr is None`` (op.py:11-14);
+  * backward is the same SpMM on the caller-supplied CSC arrays, i.e.
+    grad_feat = A^T @ grad_out (op.py:20-36); index tensors get no gradient;
+  * giving ``edge_weight_csr`` without ``edge_weight_csc`` raises RuntimeError in
+    backward (op.py:22-27);
+  * edge weights are treated as constants (op.py:30-31 prints
+    "[I] Treat edge weight as no_grad." — printed once per process here, not once
+    per backward call).
+One optional extension (off by default, so default behaviour is the reference's):
+``need_edge_grad=True`` as an 8th argument returns d loss / d edge_weight_csr via
+SDDMM, grad_w[e] = <grad_out[row(e), :], feat[col(e), :]> — the "SpMM fwd + SDDMM
+bwd" pairing BASELINE.json's config 4 names.
+
+GCNConv computes  D_in^-1/2 · A · (D_out^-1/2 ⊙ (X W)) + b  with degrees taken from
+the rowptr / colptr differences (op.py:103-109, 128-147). ``glorot`` / ``zeros`` are
+re-implemented (the reference imports them from torch_geometric, op.py:75).
+The reference's ``normalize=False`` branch raises TypeError (``rowptr.shape(0)``,
+op.py:133-134); here it does what the branch evidently intends: no scaling.
+"""
+import math
+
+import torch
+from torch.nn import Parameter
+
+from . import sddmm as _sddmm
+from . import spmm as _spmm
+
+_warned_no_grad = False
+
+
+class SPMMFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rowptr, colind, colptr, rowind, feat, edge_weight_csr=None, edge_weight_csc=None,
+                need_edge_grad=False):
+        if edge_weight_csr is None:
+            out = _spmm.csr_spmm_no_edge_value(rowptr, colind, feat)
+        else:
+            out = _spmm.csr_spmm(rowptr, colind, edge_weight_csr, feat)
+        ctx.backward_csc = (colptr, rowind, feat, edge_weight_csr, edge_weight_csc)
+        ctx.forward_csr = (rowptr, colind)
+        ctx.need_edge_grad = bool(need_edge_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        global _warned_no_grad
+        colptr, rowind, feat, edge_weight_csr, edge_weight_csc = ctx.backward_csc
+        grad_out = grad_out.contiguous()
+        grad_edge_weight = None
+        if edge_weight_csr is not None:
+            if edge_weight_csc is None:
+                raise RuntimeError(
+                    "Backward of SPMM require edge values in both src-first and dst-first order, "
+                    "and do not support gradients for edge values. Call with SPMMFunction.apply("
+                    "rowptr, colind, colptr, rowind, in_feat, edge_value_row_first, edge_value_col_first")
+            grad_feat = _spmm.csr_spmm(colptr, rowind, edge_weight_csc, grad_out)
+            if ctx.need_edge_grad:
+                rowptr, colind = ctx.forward_csr
+                grad_edge_weight = _sddmm.csr_sddmm(rowptr, colind, grad_out, feat.detach().contiguous())
+            elif not _warned_no_grad:
+                print("[I] Treat edge weight as no_grad.")
+                _warned_no_grad = True
+        else:
+            grad_feat = _spmm.csr_spmm_no_edge_value(colptr, rowind, grad_out)
+        return None, None, None, None, grad_feat, grad_edge_weight, None, None
+
+
+def glorot(tensor):
+    """torch_geometric.nn.inits.glorot: U(-a, a), a = sqrt(6 / (fan_in + fan_out))."""
+    if tensor is not None:
+        stdv = math.sqrt(6.0 / (tensor.size(-2) + tensor.size(-1)))
+        tensor.data.uniform_(-stdv, stdv)
+
+
+def zeros(tensor):
+    if tensor is not None:
+        tensor.data.fill_(0)
+
+
+class GCNConv(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, bias=True, normalize=True,
+                 **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.improved = improved
+        self.cached = cached
+        self.normalize = normalize
+        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot(self.weight)
+        zeros(self.bias)
+        self.cached_result = None
+        self.cached_num_edges = None
+
+    @staticmethod
+    def in_deg_sqrt(indptr):
+        return (1 / torch.sqrt((indptr[1:] - indptr[:-1]).float())).unsqueeze(dim=1)
+
+    @staticmethod
+    def out_deg_sqrt(indptr):
+        return (1 / torch.sqrt((indptr[1:] - indptr[:-1]).float())).unsqueeze(dim=1)
+
+    def forward(self, x, rowptr, colind, colptr, rowind, edge_weight_csr=None, edge_weight_csc=None):
+        x = torch.matmul(x, self.weight)
+        if not self.cached or self.cached_result is None:
+            if self.normalize:
+                in_deg_norm = self.in_deg_sqrt(rowptr)
+                out_deg_norm = self.out_deg_sqrt(colptr)
+            else:
+                in_deg_norm = torch.ones(rowptr.shape[0] - 1, 1, dtype=x.dtype, device=x.device)
+                out_deg_norm = torch.ones(colptr.shape[0] - 1, 1, dtype=x.dtype, device=x.device)
+            self.cached_result = in_deg_norm, out_deg_norm
+        in_deg_norm, out_deg_norm = self.cached_result
+        if self.normalize:
+            x = x * out_deg_norm
+        aggr_out = SPMMFunction.apply(rowptr, colind, colptr, rowind, x, edge_weight_csr, edge_weight_csc)
+        if self.normalize:
+            aggr_out = aggr_out * in_deg_norm
+        if self.bias is not None:
+            aggr_out = aggr_out + self.bias
+        return aggr_out
+
+    def __repr__(self):
+        return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)

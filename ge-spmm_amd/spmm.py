@@ -1,0 +1,151 @@
+"""Mirror of the reference's pybind11 module ``spmm`` (pytorch-custom/spmm.cpp:96-101):
+
+    csr_spmm(rowptr, colind, values, dense)        -> f32[M, N]   spmm.cpp:24-43
+    csr_spmm_no_edge_value(rowptr, colind, dense)  -> f32[M, N]   spmm.cpp:45-60
+    csr2csc(rowptr, colind, colptr, rowind, csr_data) -> f32[nnz] spmm.cpp:70-93
+
+Same names, argument order and meaning. Where the reference only ``assert``s its
+inputs (compiled out under NDEBUG) these functions raise. Outputs are allocated with
+``torch.empty`` on ``dense.device`` like spmm_kernel.cu:183,434; kernels run on the
+CURRENT torch stream (the reference uses the legacy default stream). Extra keyword
+arguments (``variant``, ``cfg``) expose the C ABI's tuning knobs and default to the
+library's choice.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import LaunchCfg, check, lib
+
+
+def _need(t, name, dtype, ndim):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if t.device.type != "cuda":
+        raise RuntimeError("%s must be a HIP (cuda) device tensor; gespmm_amd has no CPU path" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if t.dim() != ndim:
+        raise ValueError("%s must be %d-dimensional" % (name, ndim))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t.device != dev:
+            raise RuntimeError("all tensors must live on the same device")
+    return dev
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _make_cfg(cfg):
+    if cfg is None:
+        return None
+    if isinstance(cfg, LaunchCfg):
+        return cfg
+    return LaunchCfg(int(cfg.get("vec", 0)), int(cfg.get("strips", 0)), int(cfg.get("group", 0)),
+                     int(cfg.get("flags", 0)))
+
+
+def _spmm(rowptr, colind, values, dense, variant, cfg, out):
+    _need(rowptr, "rowptr", torch.int32, 1)
+    _need(colind, "colind", torch.int32, 1)
+    _need(dense, "dense", torch.float32, 2)
+    if values is not None:
+        _need(values, "values", torch.float32, 1)
+        if values.numel() != colind.numel():
+            raise ValueError("values and colind must have the same length")
+        dev = _same_device(dense, rowptr, colind, values)
+    else:
+        dev = _same_device(dense, rowptr, colind)
+    if rowptr.numel() < 1:
+        raise ValueError("rowptr must have M+1 >= 1 entries")
+    M = rowptr.numel() - 1
+    K, N = dense.shape
+    nnz = colind.numel()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    else:
+        _need(out, "out", torch.float32, 2)
+        if tuple(out.shape) != (M, N) or out.device != dev:
+            raise ValueError("out must be f32[M, N] on the same device")
+    c = _make_cfg(cfg)
+    with torch.cuda.device(dev):
+        rc = lib.gespmm_csr_spmm_f32_cfg(_ptr(rowptr), _ptr(colind), _ptr(values) if values is not None else None,
+                                         _ptr(dense), _ptr(out), M, K, N, nnz, int(variant),
+                                         ctypes.byref(c) if c is not None else None, _stream(dev))
+    check(rc, "gespmm_csr_spmm_f32")
+    return out
+
+
+def csr_spmm(rowptr, colind, values, dense, variant=_lib.VARIANT_AUTO, cfg=None, out=None):
+    """C = A @ dense with A = CSR(rowptr, colind, values). Mirrors spmm.cpp:24-43."""
+    if values is None:
+        raise TypeError("csr_spmm needs edge values; use csr_spmm_no_edge_value for A == 1")
+    return _spmm(rowptr, colind, values, dense, variant, cfg, out)
+
+
+def csr_spmm_no_edge_value(rowptr, colind, dense, variant=_lib.VARIANT_AUTO, cfg=None, out=None):
+    """C = A @ dense with A == 1 on its pattern. Mirrors spmm.cpp:45-60."""
+    return _spmm(rowptr, colind, None, dense, variant, cfg, out)
+
+
+def csr_spmm_max(rowptr, colind, dense, empty_value=-10000.0, variant=_lib.VARIANT_AUTO):
+    """C[r, :] = max over neighbours of dense[col, :] (DGL max reducer,
+    binary_reduce_max.cu:182-207; rows without neighbours give ``empty_value``, the
+    reference's hard-coded -10000)."""
+    _need(rowptr, "rowptr", torch.int32, 1)
+    _need(colind, "colind", torch.int32, 1)
+    _need(dense, "dense", torch.float32, 2)
+    dev = _same_device(dense, rowptr, colind)
+    M = rowptr.numel() - 1
+    K, N = dense.shape
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gespmm_csr_spmm_max_f32(_ptr(rowptr), _ptr(colind), _ptr(dense), _ptr(out), M, K, N,
+                                         colind.numel(), float(empty_value), int(variant), _stream(dev))
+    check(rc, "gespmm_csr_spmm_max_f32")
+    return out
+
+
+def csr2csc(rowptr, colind, colptr, rowind, csr_data):
+    """Fill ``colptr`` / ``rowind`` in place with the CSC form of CSR(rowptr, colind)
+    and return the values in CSC order. Mirrors spmm.cpp:70-93 (whose CUDA
+    implementation is unusable as shipped: spmm_kernel.cu:386 uses an uninitialised
+    cuSPARSE handle). The number of columns is ``colptr.numel() - 1``."""
+    _need(rowptr, "rowptr", torch.int32, 1)
+    _need(colind, "colind", torch.int32, 1)
+    _need(colptr, "colptr", torch.int32, 1)
+    _need(rowind, "rowind", torch.int32, 1)
+    _need(csr_data, "csr_data", torch.float32, 1)
+    dev = _same_device(rowptr, colind, colptr, rowind, csr_data)
+    M = rowptr.numel() - 1
+    K = colptr.numel() - 1
+    nnz = colind.numel()
+    if rowind.numel() != nnz or csr_data.numel() != nnz:
+        raise ValueError("rowind and csr_data must have nnz entries")
+    out = torch.empty((nnz,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws_bytes = lib.gespmm_csr2csc_workspace_bytes(M, K, nnz)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "gespmm_csr2csc_workspace_bytes")
+        ws = torch.empty((max(int(ws_bytes), 1),), dtype=torch.uint8, device=dev)
+        rc = lib.gespmm_csr2csc_f32(_ptr(rowptr), _ptr(colind), _ptr(csr_data), _ptr(colptr), _ptr(rowind),
+                                    _ptr(out), M, K, nnz, _ptr(ws), _stream(dev))
+    check(rc, "gespmm_csr2csc_f32")
+    return out
+
+
+def select_variant(M, nnz, N):
+    """The variant VARIANT_AUTO resolves to for this shape (host-only)."""
+    return lib.gespmm_select_variant(int(M), int(nnz), int(N))

@@ -1,0 +1,197 @@
+/*
+ * gespmm.h — C ABI of libgespmm.so, the MI355X (gfx950) GE-SpMM hot path.
+ *
+ * This is the drop-in boundary for the ONE path this repository accelerates:
+ * CSR x dense row-product SpMM (fp32 values, int32 indices), plus the SDDMM and
+ * CSR->CSC helpers the reference's PyTorch op exposes next to it.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference repository hgyhungry/ge-spmm):
+ *
+ *   gespmm_csr_spmm_f32      <- spmmWrapper()                 spmm_test.cu:456-492
+ *                               spmm_cuda()                   pytorch-custom/spmm_kernel.cu:425-458
+ *                               spmm_cuda_no_edge_value()     pytorch-custom/spmm_kernel.cu:175-207
+ *                               XTopoCsrmm<float>()           dgl-custom/binary_reduce_sum.cu:310-335
+ *   gespmm_csr_spmm_max_f32  <- XTopoCsrmmmax<float>()        dgl-custom/binary_reduce_max.cu:182-207
+ *   gespmm_select_variant    <- the N-based 3-way dispatch    pytorch-custom/spmm_kernel.cu:186-206,437-457
+ *   gespmm_sddmm_coo_f32     <- sddmm_cuda_coo()              pytorch-custom/sddmm.cu:427-457
+ *   gespmm_sddmm_csr_f32     <- sddmm_cuda_csr()              pytorch-custom/sddmm.cu:459-484
+ *   gespmm_csr2csc_f32       <- csr2csc_cuda()/csr2cscKernel  pytorch-custom/spmm_kernel.cu:381-476
+ *   gespmm_mtx_read / _free  <- readMtx<float>()              util/util.hpp:286-333 (+ mmio.hpp:215,308)
+ *   gespmm_coo_to_csr        <- inline COO->CSR               spmm_test.cu:557-581
+ *   gespmm_row_partition     <- (new; north_star multi-GPU)   no reference counterpart
+ *
+ * Conventions (all device entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller, except where a
+ *     parameter is documented as host memory (the loader / partitioner);
+ *   - dense matrices are row-major with leading dimension N (B is K x N, C is M x N);
+ *   - C is fully overwritten (alpha = 1, beta = 0, no accumulate, no pre-zeroing);
+ *   - the call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream, which is what the reference launches on);
+ *   - the return value is a hipError_t cast to int (0 = success) or one of the
+ *     negative GESPMM_E* codes below; the library never calls exit();
+ *   - re-entrant; the only global state is cached, immutable device properties.
+ *
+ * There is NO CPU fallback: without a HIP device every compute entry point
+ * returns the HIP error (hipErrorNoDevice = 100).
+ */
+#ifndef GESPMM_H_
+#define GESPMM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GESPMM_VERSION_MAJOR 0
+#define GESPMM_VERSION_MINOR 1
+
+/* Negative return codes (positive values are hipError_t). */
+#define GESPMM_EINVAL   (-1)  /* bad argument (null pointer, negative size, unknown variant) */
+#define GESPMM_EALIGN   (-2)  /* pointer not 4-byte aligned */
+#define GESPMM_ERANGE   (-3)  /* size exceeds what int32 CSR indices can address */
+#define GESPMM_EIO      (-4)  /* loader: file not found / unreadable */
+#define GESPMM_EFORMAT  (-5)  /* loader: bad MatrixMarket banner or size line */
+#define GESPMM_ENOMEM   (-6)  /* host allocation failed */
+
+/*
+ * Kernel variants. Numbers 0..4 keep the reference's `method` numbering
+ * (spmm_test.cu:456-492): 0 naive, 1 CRC, 2/3/4 CRC+CWM with coarsening factor
+ * 2/4/8. 5 is the parallel-reduction variant (lanes over nnz) that north_star
+ * asks for and the reference only has in dgSPARSE. -1 lets the library choose.
+ *
+ * Variants 0-4 accumulate each output element in ONE fp32 register in ascending
+ * CSR position with one fused multiply-add per non-zero (the arithmetic the
+ * reference's device kernels perform); they are bit-identical to each other.
+ * Variant 5 changes the summation order and is tolerance-checked.
+ */
+#define GESPMM_VARIANT_AUTO       (-1)
+#define GESPMM_VARIANT_NAIVE        0
+#define GESPMM_VARIANT_CRC          1
+#define GESPMM_VARIANT_CRC_CWM2     2
+#define GESPMM_VARIANT_CRC_CWM4     3
+#define GESPMM_VARIANT_CRC_CWM8     4
+#define GESPMM_VARIANT_PARREDUCE    5
+#define GESPMM_NUM_VARIANTS         6
+
+const char* gespmm_version(void);
+/* Human-readable string for any return code of this library. */
+const char* gespmm_error_string(int code);
+
+/*
+ * C[M x N] = A[M x K] * B[K x N], A in CSR (rowptr[M+1], colind[nnz], val[nnz]).
+ * val == NULL means A == 1 on its pattern (the "topo"/no_edge_value kernels).
+ * nnz may be passed as -1 when unknown (it only feeds the variant heuristic).
+ */
+int gespmm_csr_spmm_f32(const int32_t* rowptr, const int32_t* colind, const float* val,
+                        const float* B, float* C,
+                        int64_t M, int64_t K, int64_t N, int64_t nnz,
+                        int variant, void* stream);
+
+/*
+ * Same product with the `max` reducer over the row's neighbours (unweighted):
+ * C[r,c] = max_p B[colind[p], c]; rows without non-zeros yield `empty_value`
+ * (the reference hard-codes -10000, binary_reduce_max.cu:22-24).
+ */
+int gespmm_csr_spmm_max_f32(const int32_t* rowptr, const int32_t* colind,
+                            const float* B, float* C,
+                            int64_t M, int64_t K, int64_t N, int64_t nnz,
+                            float empty_value, int variant, void* stream);
+
+/* The variant `GESPMM_VARIANT_AUTO` resolves to for this shape (pure host logic). */
+int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N);
+
+/*
+ * Explicit launch geometry, for tuning sweeps and tests. Fields set to 0 mean
+ * "library default for this variant and N".
+ *   vec      floats per lane per strip (1, 2 or 4) — contiguous, one vector load
+ *   strips   strips per lane (1 or 2); coarsening factor = vec * strips
+ *   group    lanes cooperating on one row (4..64, power of two); a 64-lane
+ *            wavefront therefore carries 64/group rows
+ *   flags    GESPMM_FLAG_* bits
+ */
+typedef struct gespmm_launch_cfg {
+    int32_t vec;
+    int32_t strips;
+    int32_t group;
+    int32_t flags;
+} gespmm_launch_cfg;
+
+#define GESPMM_FLAG_NO_XCD_REMAP   0x1  /* plain blockIdx -> row-block mapping */
+#define GESPMM_FLAG_NT_STORE       0x2  /* non-temporal stores of C */
+#define GESPMM_FLAG_FORCE_IDX64    0x4  /* 64-bit B offsets even when K*N*4 < 2^32 */
+
+int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const float* val,
+                            const float* B, float* C,
+                            int64_t M, int64_t K, int64_t N, int64_t nnz,
+                            int variant, const gespmm_launch_cfg* cfg, void* stream);
+
+/*
+ * SDDMM: out[e] = sum_j D1[row(e), j] * D2[col(e), j], e in pattern order.
+ * COO: row(e) = rowind[e].  CSR: row(e) = the row whose [rowptr[r], rowptr[r+1]) holds e.
+ * D1 is M x N, D2 is K x N, row-major; out has nnz floats.
+ */
+int gespmm_sddmm_coo_f32(const int32_t* rowind, const int32_t* colind,
+                         const float* D1, const float* D2, float* out,
+                         int64_t nnz, int64_t N, void* stream);
+int gespmm_sddmm_csr_f32(const int32_t* rowptr, const int32_t* colind,
+                         const float* D1, const float* D2, float* out,
+                         int64_t M, int64_t nnz, int64_t N, void* stream);
+
+/*
+ * CSR (M x K) -> CSC on the device: fills colptr[K+1], rowind[nnz] and, when
+ * csr_val != NULL, csc_val[nnz]. Entries inside one column keep ascending row
+ * order (stable), which is what makes backward SpMM on the CSC arrays
+ * deterministic. `workspace` must hold gespmm_csr2csc_workspace_bytes() bytes.
+ */
+int64_t gespmm_csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
+int gespmm_csr2csc_f32(const int32_t* rowptr, const int32_t* colind, const float* csr_val,
+                       int32_t* colptr, int32_t* rowind, float* csc_val,
+                       int64_t M, int64_t K, int64_t nnz,
+                       void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ host side */
+
+/*
+ * MatrixMarket coordinate loader with the reference's readMtx semantics
+ * (1-based -> 0-based, `symmetric` expanded with self-loops and duplicates
+ * dropped, result sorted by (row, col); real -> value, integer -> value,
+ * pattern -> 1.0). Output arrays are HOST memory allocated by the library;
+ * release them with gespmm_mtx_free(). Unlike the reference this never exits:
+ * a missing file is GESPMM_EIO, a bad banner/size line GESPMM_EFORMAT.
+ */
+typedef struct gespmm_coo {
+    int32_t  nrows;
+    int32_t  ncols;
+    int64_t  nnz;
+    int32_t* row;   /* [nnz] */
+    int32_t* col;   /* [nnz] */
+    float*   val;   /* [nnz] */
+} gespmm_coo;
+
+int  gespmm_mtx_read(const char* path, gespmm_coo* out);
+void gespmm_mtx_free(gespmm_coo* coo);
+
+/*
+ * COO (any order) -> CSR by counting sort on the row, keeping the input order
+ * inside each row. val_in == NULL writes 1.0f for every entry, which is what
+ * spmm_test.cu:574 does with the file's values. All HOST pointers. An index
+ * outside [0,nrows) x [0,ncols) is GESPMM_EINVAL (the reference only prints
+ * "out of bound row/column", spmm_test.cu:563,571, and corrupts memory).
+ */
+int gespmm_coo_to_csr(int32_t nrows, int32_t ncols, int64_t nnz,
+                      const int32_t* row, const int32_t* col, const float* val_in,
+                      int32_t* rowptr, int32_t* colind, float* val_out);
+
+/*
+ * 1-D row partition of a CSR matrix into `parts` contiguous row ranges with
+ * (nearly) equal non-zero counts: cut[p] = first row of part p, cut[parts] = M.
+ * rowptr is HOST memory (M+1 entries); cut has parts+1 entries.
+ */
+int gespmm_row_partition(const int32_t* rowptr, int64_t M, int32_t parts, int64_t* cut);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GESPMM_H_ */

@@ -1,0 +1,402 @@
+/*
+ * gespmm_oracle.c — CPU restatement of the reference's algorithm for the SpMM hot
+ * path. THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it, and only as the
+ * checker. The product (libgespmm.so) never links or calls anything in here.
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * hgyhungry/ge-spmm). The restatement is deliberately the slow, literal form.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - loader:  pinned against the reference's own recorded data — the nnz that
+ *     matrix_id_info.xlsx implies for cora/citeseer/pubmed (time x throughput =
+ *     2*nnz*N) and the M/nnz/first/last/max-degree facts SURVEY.md §8(c2)
+ *     obtained from the unmodified reference loader (tests/golden/known_answers.json).
+ *   - SpMM / SDDMM arithmetic: the reference ships NO golden vectors and its only
+ *     check (spmm_test.cu:671-698) is compiled out and needs CUDA; the CUDA sources
+ *     cannot be built here (no nvcc/cuSPARSE). PARITY UNPINNED against reference
+ *     outputs; the restatement is cross-checked against scipy (float64) instead.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ SpMM */
+
+/*
+ * The reference's CPU golden, verbatim loop order (spmm_test.cu:595-605):
+ *   for i: for k: acc = 0; for ptr in row i (ascending): acc += A[ptr]*B[N*col[ptr]+k]
+ * fp32 accumulator, separate multiply and add (g++ -O3 on baseline x86-64 emits no
+ * FMA; this file is compiled with -ffp-contract=off to guarantee it).
+ * val == NULL means A == 1 (spmm_test.cu:574 forces that).
+ */
+void oracle_spmm_golden(int M, int N, const int* rowptr, const int* colind, const float* val, const float* B,
+                        float* C) {
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < N; k++) {
+            float acc = 0.0f;
+            for (int ptr = rowptr[i]; ptr < rowptr[i + 1]; ptr++) {
+                const float a = val ? val[ptr] : 1.0f;
+                acc += a * B[(size_t)N * (size_t)colind[ptr] + k];
+            }
+            C[(size_t)N * i + k] = acc;
+        }
+    }
+}
+
+/* Same loop body, rows split over host threads (BASELINE.md §2 "all cores" figure). */
+void oracle_spmm_golden_omp(int M, int N, const int* rowptr, const int* colind, const float* val, const float* B,
+                            float* C) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < N; k++) {
+            float acc = 0.0f;
+            for (int ptr = rowptr[i]; ptr < rowptr[i + 1]; ptr++) {
+                const float a = val ? val[ptr] : 1.0f;
+                acc += a * B[(size_t)N * (size_t)colind[ptr] + k];
+            }
+            C[(size_t)N * i + k] = acc;
+        }
+    }
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/*
+ * The arithmetic of the reference's DEVICE kernels (spmm_test.cu:77-83,118-135,
+ * 182-203; spmm_kernel.cu:210-379): same ascending-ptr chain, but nvcc contracts
+ * `acc += val*B[..]` into one fused multiply-add. This is what the HIP kernels
+ * must reproduce bit for bit. With A == 1 it coincides with oracle_spmm_golden.
+ */
+void oracle_spmm_fma(int M, int N, const int* rowptr, const int* colind, const float* val, const float* B,
+                     float* C) {
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < N; k++) {
+            float acc = 0.0f;
+            for (int ptr = rowptr[i]; ptr < rowptr[i + 1]; ptr++) {
+                const float b = B[(size_t)N * (size_t)colind[ptr] + k];
+                if (val) acc = fmaf(val[ptr], b, acc);
+                else acc = acc + b; /* topo kernels: spmm_kernel.cu:51-58 */
+            }
+            C[(size_t)N * i + k] = acc;
+        }
+    }
+}
+
+/* sum_p |a_p * b_p| per output element in float64: the scale for tolerance checks
+ * of re-ordered summation. */
+void oracle_spmm_abs(int M, int N, const int* rowptr, const int* colind, const float* val, const float* B,
+                     double* S) {
+    for (int i = 0; i < M; i++)
+        for (int k = 0; k < N; k++) {
+            double acc = 0.0;
+            for (int ptr = rowptr[i]; ptr < rowptr[i + 1]; ptr++) {
+                const double a = val ? (double)val[ptr] : 1.0;
+                acc += fabs(a * (double)B[(size_t)N * (size_t)colind[ptr] + k]);
+            }
+            S[(size_t)N * i + k] = acc;
+        }
+}
+
+/*
+ * max reducer of the DGL patch (binary_reduce_max.cu:18-24, 26-168): accumulator
+ * starts at `init` (the reference hard-codes -10000) and takes max with every
+ * neighbour's feature, so empty rows yield `init`.
+ */
+void oracle_spmm_max(int M, int N, const int* rowptr, const int* colind, const float* B, float init, float* C) {
+    for (int i = 0; i < M; i++)
+        for (int k = 0; k < N; k++) {
+            float acc = init;
+            for (int ptr = rowptr[i]; ptr < rowptr[i + 1]; ptr++) {
+                const float b = B[(size_t)N * (size_t)colind[ptr] + k];
+                acc = (b > acc) ? b : acc; /* max(acc, b) as binary_reduce_max.cu:22-24 */
+            }
+            C[(size_t)N * i + k] = acc;
+        }
+}
+
+/* Scatter form of the same product (gunrock-test/app/spmm/spmm_test.cuh:47-87,
+ * CPU_Reference): out[dst, :] += in[src, :] over edges. With A == 1 the sum per
+ * element runs over the same terms in the same (CSR) order, so it must agree with
+ * oracle_spmm_golden exactly — used as a self-consistency check of the oracle. */
+void oracle_spmm_scatter(int M, int N, const int* rowptr, const int* colind, const float* B, float* C) {
+    memset(C, 0, (size_t)M * (size_t)N * sizeof(float));
+    for (int i = 0; i < M; i++)
+        for (int ptr = rowptr[i]; ptr < rowptr[i + 1]; ptr++)
+            for (int k = 0; k < N; k++) C[(size_t)N * i + k] += B[(size_t)N * (size_t)colind[ptr] + k];
+}
+
+/* ------------------------------------------------------------------ inputs */
+
+/* B init of the driver (spmm_test.cu:586-594): srand(seed); B[i] = float(rand()%100-50)/100.
+ * The reference seeds with time(0); the seed is a parameter here so runs reproduce. */
+void oracle_fill_B(unsigned seed, size_t count, float* B) {
+    srand(seed);
+    for (size_t i = 0; i < count; i++) B[i] = (float)(rand() % 100 - 50) / 100;
+}
+
+/*
+ * COO -> CSR exactly as the driver does it (spmm_test.cu:557-581): count, prefix
+ * sum, fill while advancing A_indptr[row], shift A_indptr back by one slot.
+ * use_values == 0 reproduces `A_data[ptr] = 1` (line 574).
+ */
+void oracle_coo_to_csr(int nrows, int nnz, const int* row_indices, const int* col_indices, const float* values,
+                       int use_values, int* A_indptr, int* A_indices, float* A_data) {
+    for (int i = 0; i < nrows + 1; i++) A_indptr[i] = 0;
+    for (int n = 0; n < nnz; n++) A_indptr[row_indices[n] + 1]++;
+    for (int n = 1; n < nrows + 1; n++) A_indptr[n] += A_indptr[n - 1];
+    for (int n = 0; n < nnz; n++) {
+        int ptr = A_indptr[row_indices[n]];
+        A_indices[ptr] = col_indices[n];
+        A_data[ptr] = use_values ? values[n] : 1.0f;
+        ptr++;
+        A_indptr[row_indices[n]] = ptr;
+    }
+    for (int n = nrows - 1; n > 0; n--) A_indptr[n] = A_indptr[n - 1];
+    A_indptr[0] = 0;
+}
+
+/* ------------------------------------------------------------------ loader */
+
+typedef struct {
+    int r, c;
+    float v;
+    int seq;
+} oracle_tuple;
+
+static int cmp_tuple(const void* a, const void* b) {
+    const oracle_tuple* x = (const oracle_tuple*)a;
+    const oracle_tuple* y = (const oracle_tuple*)b;
+    if (x->r != y->r) return x->r < y->r ? -1 : 1;
+    if (x->c != y->c) return x->c < y->c ? -1 : 1;
+    /* util.hpp:56-73 compares (row, col) only; std::sort leaves ties unspecified.
+       The input sequence number breaks ties so the oracle is deterministic. */
+    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+
+static int tok_eq_ci(const char* a, const char* b) {
+    for (; *a && *b; a++, b++) {
+        char ca = *a, cb = *b;
+        if (ca >= 'A' && ca <= 'Z') ca = (char)(ca - 'A' + 'a');
+        if (ca != cb) return 0;
+    }
+    return *a == 0 && *b == 0;
+}
+
+/*
+ * readMtx<float> (util/util.hpp:286-333) on mm_read_banner (mmio.hpp:215-298) and
+ * mm_read_mtx_crd_size (mmio.hpp:308-336). Returns 0 and malloc'ed arrays, or
+ *   1 = file not found (util.hpp:300-303, reference exits 1)
+ *   2 = bad banner     (util.hpp:306-309, reference exits 1)
+ *   3 = bad size line  (util.hpp:312-313, reference exits 1)
+ * Entries are read with fscanf exactly like readTuples (util.hpp:104-216).
+ * Values stay attached to their entries (the reference's compaction loop forgets
+ * to move them, util.hpp:268-277 — a quirk the driver hides by overwriting all
+ * values with 1).
+ */
+int oracle_read_mtx(const char* fname, int* nrows, int* ncols, int* nvals, int** rows_out, int** cols_out,
+                    float** vals_out) {
+    FILE* f = fopen(fname, "r");
+    if (!f) return 1;
+    char line[1025];
+    char banner[64], mtx[64], crd[64], dtype[64], scheme[64];
+    if (!fgets(line, sizeof line, f) ||
+        sscanf(line, "%63s %63s %63s %63s %63s", banner, mtx, crd, dtype, scheme) != 5) {
+        fclose(f);
+        return 2;
+    }
+    if (strncmp(banner, "%%MatrixMarket", 14) != 0 || !tok_eq_ci(mtx, "matrix")) {
+        fclose(f);
+        return 2;
+    }
+    const int is_coord = tok_eq_ci(crd, "coordinate");
+    if (!is_coord && !tok_eq_ci(crd, "array")) {
+        fclose(f);
+        return 2;
+    }
+    int kind; /* 0 real, 1 integer, 2 pattern, 3 complex */
+    if (tok_eq_ci(dtype, "real")) kind = 0;
+    else if (tok_eq_ci(dtype, "integer")) kind = 1;
+    else if (tok_eq_ci(dtype, "pattern")) kind = 2;
+    else if (tok_eq_ci(dtype, "complex")) kind = 3;
+    else {
+        fclose(f);
+        return 2;
+    }
+    int symmetric = 0;
+    if (tok_eq_ci(scheme, "symmetric")) symmetric = 1;
+    else if (!tok_eq_ci(scheme, "general") && !tok_eq_ci(scheme, "hermitian") &&
+             !tok_eq_ci(scheme, "skew-symmetric")) {
+        fclose(f);
+        return 2;
+    }
+    if (!is_coord || kind == 3) { /* outside what the SpMM driver can consume */
+        fclose(f);
+        return 2;
+    }
+
+    int M = 0, K = 0, NZ = 0;
+    do {
+        if (!fgets(line, sizeof line, f)) {
+            fclose(f);
+            return 3;
+        }
+    } while (line[0] == '%');
+    if (sscanf(line, "%d %d %d", &M, &K, &NZ) != 3) {
+        int got;
+        do {
+            got = fscanf(f, "%d %d %d", &M, &K, &NZ);
+            if (got == EOF) {
+                fclose(f);
+                return 3;
+            }
+        } while (got != 3);
+    }
+
+    size_t cap = (size_t)NZ * (symmetric ? 2 : 1) + 1;
+    oracle_tuple* t = (oracle_tuple*)malloc(cap * sizeof *t);
+    int n = 0;
+    for (int i = 0; i < NZ; i++) {
+        int r, c;
+        if (fscanf(f, "%d", &r) == EOF) {
+            printf("Error: not enough rows in mtx file.\n");
+            break;
+        }
+        if (fscanf(f, "%d", &c) != 1) break;
+        float v = 1.0f;
+        if (kind == 1) {
+            int iv = 0;
+            if (fscanf(f, "%d", &iv) != 1) break;
+            v = (float)iv;
+        } else if (kind == 0) {
+            if (fscanf(f, "%f", &v) != 1) break;
+        }
+        t[n].r = r - 1;
+        t[n].c = c - 1;
+        t[n].v = v;
+        t[n].seq = n;
+        n++;
+    }
+    fclose(f);
+
+    if (symmetric) { /* makeSymmetric, util.hpp:218-284 */
+        const int n0 = n;
+        for (int i = 0; i < n0; i++)
+            if (t[i].c != t[i].r) {
+                t[n].r = t[i].c;
+                t[n].c = t[i].r;
+                t[n].v = t[i].v;
+                t[n].seq = n;
+                n++;
+            }
+        qsort(t, (size_t)n, sizeof *t, cmp_tuple);
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const int self = t[i].r == t[i].c;
+            const int dup = i > 0 && t[i].r == t[i - 1].r && t[i].c == t[i - 1].c;
+            if (self || dup) continue;
+            /* Duplicates are judged against the ORIGINAL sorted predecessor
+               (util.hpp:246-261 reads `curr` before marking). Compacting in place is
+               safe: slot m <= i, and slot i itself is only ever rewritten with itself,
+               so t[i] is still the original entry when iteration i+1 looks back. */
+            t[m] = t[i];
+            m++;
+        }
+        n = m;
+    }
+    for (int i = 0; i < n; i++) t[i].seq = i;
+    qsort(t, (size_t)n, sizeof *t, cmp_tuple); /* customSort, util.hpp:327 */
+
+    int* R = (int*)malloc(((size_t)n + 1) * sizeof(int));
+    int* Cc = (int*)malloc(((size_t)n + 1) * sizeof(int));
+    float* V = (float*)malloc(((size_t)n + 1) * sizeof(float));
+    for (int i = 0; i < n; i++) {
+        R[i] = t[i].r;
+        Cc[i] = t[i].c;
+        V[i] = t[i].v;
+    }
+    free(t);
+    *nrows = M;
+    *ncols = K;
+    *nvals = n;
+    *rows_out = R;
+    *cols_out = Cc;
+    *vals_out = V;
+    return 0;
+}
+
+void oracle_free(void* p) { free(p); }
+
+/* ------------------------------------------------------------------ SDDMM */
+
+/*
+ * out[e] = sum_j D1[row(e), j] * D2[col(e), j]  (sddmm.cu:7-424). The reference
+ * combines per-lane partial sums with a shuffle tree (computeUtil.h:115-124), so
+ * no summation order is canonical; the oracle accumulates in float64 and rounds
+ * once, and reports sum|d1*d2| as the tolerance scale.
+ * CSR form: row(e) by the same search as findRow (computeUtil.h:11-28).
+ */
+static int oracle_find_row(const int* rowptr, int eid, int start, int end) {
+    int low = start, high = end;
+    if (low == high) return low;
+    while (low < high) {
+        int mid = (low + high) >> 1;
+        if (rowptr[mid] <= eid) low = mid + 1;
+        else high = mid;
+    }
+    if (rowptr[high] == eid) return high;
+    return high - 1;
+}
+
+void oracle_sddmm(int is_csr, int M, int nnz, int N, const int* rows, const int* colind, const float* D1,
+                  const float* D2, float* out, double* scale) {
+    for (int e = 0; e < nnz; e++) {
+        int r = is_csr ? oracle_find_row(rows, e, 0, M) : rows[e];
+        /* findRow can land on an empty row whose rowptr equals eid; advance to the
+           row that really contains e (rowptr[r] <= e < rowptr[r+1]). */
+        if (is_csr) {
+            while (r < M - 1 && rows[r + 1] <= e) r++;
+            while (r > 0 && rows[r] > e) r--;
+        }
+        const int c = colind[e];
+        double acc = 0.0, sc = 0.0;
+        for (int j = 0; j < N; j++) {
+            const double p = (double)D1[(size_t)r * N + j] * (double)D2[(size_t)c * N + j];
+            acc += p;
+            sc += fabs(p);
+        }
+        out[e] = (float)acc;
+        if (scale) scale[e] = sc;
+    }
+}
+
+/* ------------------------------------------------------------------ CSR -> CSC */
+
+/* What cusparseCsr2cscEx2 (spmm_kernel.cu:381-423) is asked to produce: the CSC
+ * arrays of the same matrix, rows ascending inside each column. */
+void oracle_csr2csc(int M, int K, const int* rowptr, const int* colind, const float* val, int* colptr, int* rowind,
+                    float* cscval) {
+    for (int c = 0; c <= K; c++) colptr[c] = 0;
+    for (int p = 0; p < rowptr[M]; p++) colptr[colind[p] + 1]++;
+    for (int c = 0; c < K; c++) colptr[c + 1] += colptr[c];
+    int* next = (int*)malloc(((size_t)K + 1) * sizeof(int));
+    memcpy(next, colptr, ((size_t)K + 1) * sizeof(int));
+    for (int r = 0; r < M; r++)
+        for (int p = rowptr[r]; p < rowptr[r + 1]; p++) {
+            const int dst = next[colind[p]]++;
+            rowind[dst] = r;
+            if (val) cscval[dst] = val[p];
+        }
+    free(next);
+}

@@ -1,0 +1,125 @@
+"""The C ABI library: loads, exports everything include/gespmm.h declares, validates
+its arguments on the host, and has no CPU compute path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "gespmm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gespmm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    from gespmm_amd import _lib
+
+    declared = _declared_functions()
+    assert len(declared) >= 14
+    assert sorted(_lib.EXPORTS) == declared, "ctypes binding and header disagree"
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, nm), "%s not exported" % name
+        getattr(_lib.lib, name)
+
+
+def test_no_torch_types_in_header():
+    text = open(os.path.join(ROOT, "include", "gespmm.h")).read()
+    assert "torch" not in text.lower().replace("pytorch", "") and "at::" not in text
+
+
+def test_version_and_error_strings(pkg):
+    from gespmm_amd import _lib
+
+    assert _lib.lib.gespmm_version().decode().startswith("gespmm ")
+    assert _lib.lib.gespmm_error_string(0) == b"success"
+    for code in (-1, -2, -3, -4, -5, -6):
+        assert b"gespmm" in _lib.lib.gespmm_error_string(code)
+    assert _lib.lib.gespmm_error_string(100)  # a hipError_t
+
+
+def test_argument_validation_needs_no_gpu(pkg):
+    from gespmm_amd import _lib
+
+    lib = _lib.lib
+    buf = (ctypes.c_int32 * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    odd = ctypes.c_void_p(p.value + 2)
+    f = lib.gespmm_csr_spmm_f32
+    assert f(p, p, None, p, p, -1, 4, 4, 0, -1, None) == -1          # negative M
+    assert f(None, p, None, p, p, 4, 4, 4, 8, -1, None) == -1        # null rowptr
+    assert f(p, p, None, p, None, 4, 4, 4, 8, -1, None) == -1        # null C
+    assert f(p, None, None, p, p, 4, 4, 4, 8, -1, None) == -1        # null colind with nnz > 0
+    assert f(p, p, None, p, p, 4, 4, 4, 8, 17, None) == -1           # unknown variant
+    assert f(p, p, None, odd, p, 4, 4, 4, 8, -1, None) == -2         # misaligned B
+    assert f(p, p, None, p, p, 1 << 33, 4, 4, 8, -1, None) == -3     # M beyond int32
+    assert f(p, p, None, p, p, 0, 4, 4, 0, -1, None) == 0            # empty problem: no launch
+    assert f(p, p, None, p, p, 4, 4, 0, 0, -1, None) == 0
+    cfg = _lib.LaunchCfg(3, 0, 0, 0)
+    assert lib.gespmm_csr_spmm_f32_cfg(p, p, None, p, p, 4, 4, 4, 8, -1, ctypes.byref(cfg), None) == -1
+    cfg = _lib.LaunchCfg(0, 0, 24, 0)
+    assert lib.gespmm_csr_spmm_f32_cfg(p, p, None, p, p, 4, 4, 4, 8, -1, ctypes.byref(cfg), None) == -1
+    # max reducer exists for unweighted CRC variants only
+    assert lib.gespmm_csr_spmm_max_f32(p, p, p, p, 4, 4, 4, 8, -1e4, 5, None) == -1
+    assert lib.gespmm_sddmm_coo_f32(None, p, p, p, p, 8, 4, None) == -1
+    assert lib.gespmm_sddmm_coo_f32(p, p, p, p, p, 0, 4, None) == 0
+    assert lib.gespmm_sddmm_csr_f32(p, p, p, p, p, -1, 8, 4, None) == -1
+    assert lib.gespmm_csr2csc_f32(None, p, None, p, p, None, 4, 4, 8, p, None) == -1
+    assert lib.gespmm_csr2csc_f32(p, p, p, p, p, None, 4, 4, 8, p, None) == -1  # val in without val out
+    assert lib.gespmm_row_partition(None, 4, 2, p) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback(pkg):
+    """Without a HIP device the compute entry points fail loudly — there is no CPU path."""
+    from gespmm_amd import _lib, spmm
+
+    rowptr = np.array([0, 1, 2], dtype=np.int32)
+    colind = np.array([0, 1], dtype=np.int32)
+    B = np.ones((2, 4), dtype=np.float32)
+    C = np.zeros((2, 4), dtype=np.float32)
+    rc = _lib.lib.gespmm_csr_spmm_f32(rowptr.ctypes.data, colind.ctypes.data, None, B.ctypes.data, C.ctypes.data,
+                                      2, 2, 4, 2, -1, None)
+    assert rc > 0, "expected a hipError_t (no device)"
+    assert np.all(C == 0), "nothing may be computed on the host"
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        spmm.csr_spmm_no_edge_value(torch.from_numpy(rowptr), torch.from_numpy(colind), torch.from_numpy(B))
+    from gespmm_amd import sddmm
+
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sddmm.coo_sddmm(torch.from_numpy(colind), torch.from_numpy(colind), torch.from_numpy(B),
+                        torch.from_numpy(B))
+
+
+def test_product_never_touches_the_oracle():
+    """The product package and its C sources may not reference oracle/ in any way."""
+    pkg_dir = os.path.join(ROOT, "ge-spmm_amd")
+    for base, _, files in os.walk(pkg_dir):
+        if os.sep + "lib" in base:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(base, fn), errors="ignore").read().lower()
+                assert "oracle" not in text, os.path.join(base, fn)
+    ldd = subprocess.run(["ldd", os.path.join(pkg_dir, "lib", "libgespmm.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
+
+
+def test_select_variant(pkg):
+    from gespmm_amd import _lib, spmm
+
+    assert spmm.select_variant(1000, 5000, 128) == _lib.VARIANT_CRC_CWM4
+    assert spmm.select_variant(1000, 5000, 512) == _lib.VARIANT_CRC_CWM4
+    assert spmm.select_variant(1000, 5000, 32) == _lib.VARIANT_CRC_CWM4
+    assert spmm.select_variant(1000, 5000, 6) == _lib.VARIANT_CRC_CWM2
+    assert spmm.select_variant(1000, 5000, 41) == _lib.VARIANT_CRC
+    assert spmm.select_variant(1000, 5000, 3) == _lib.VARIANT_CRC
+    for n in (1, 2, 3, 16, 41, 128, 500, 512):
+        assert 0 <= spmm.select_variant(10, 10, n) <= 4, "auto never picks the tolerance-only variant"

@@ -1,0 +1,86 @@
+"""BASELINE.json's full-size workload (com-Amazon-like, N=128), checked through
+size-independent properties instead of the (slow) oracle:
+  * integer-valued inputs make every fp32 sum exact, so the result must EQUAL an
+    independent int64 computation (torch index_select / index_add on the GPU);
+  * B == 1 gives the row degrees;
+  * linearity in B within fp32 rounding;
+  * a sampled set of rows against the oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amazon(pkg):
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("com-amazon-like", seed=42, device="cuda")
+    assert g["M"] == 334863 and g["nnz"] == 1851744
+    return g
+
+
+def test_generator_contract(amazon):
+    rp, ci = amazon["rowptr"].long(), amazon["colind"].long()
+    M = amazon["M"]
+    rows = torch.repeat_interleave(torch.arange(M, device="cuda"), rp[1:] - rp[:-1])
+    key = rows * M + ci
+    assert torch.all(key[1:] > key[:-1]), "sorted, no duplicates"
+    assert not torch.any(rows == ci), "no self loops"
+    tkey, _ = torch.sort(ci * M + rows)
+    assert torch.equal(tkey, key), "symmetric"
+    deg = (rp[1:] - rp[:-1])
+    assert 100 < int(deg.max()) < 2000
+
+
+@pytest.mark.parametrize("N", (32, 128, 512))
+def test_exact_integer_arithmetic_full_size(pkg, amazon, N):
+    from gespmm_amd import spmm
+
+    M = amazon["M"]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(N)
+    Bi = torch.randint(-8, 9, (M, N), generator=gen, device="cuda", dtype=torch.int32)
+    vi = torch.randint(-4, 5, (amazon["nnz"],), generator=gen, device="cuda", dtype=torch.int32)
+    rp, ci = amazon["rowptr"], amazon["colind"]
+    rows = torch.repeat_interleave(torch.arange(M, device="cuda"), (rp[1:] - rp[:-1]).long())
+    # independent exact reference in int64, chunked over columns to bound memory
+    for variant in (-1, 2, 4):
+        C = spmm.csr_spmm(rp, ci, vi.float(), Bi.float(), variant=variant)
+        for c0 in range(0, N, 64):
+            c1 = min(c0 + 64, N)
+            contrib = Bi[ci.long(), c0:c1].long() * vi.long().unsqueeze(1)
+            ref = torch.zeros((M, c1 - c0), dtype=torch.int64, device="cuda")
+            ref.index_add_(0, rows, contrib)
+            assert torch.equal(C[:, c0:c1].long(), ref), (N, variant, c0)
+    Cu = spmm.csr_spmm_no_edge_value(rp, ci, torch.ones(M, N, device="cuda"))
+    deg = (rp[1:] - rp[:-1]).float().unsqueeze(1).expand(M, N)
+    assert torch.equal(Cu, deg), "A @ 1 = row degree"
+
+
+def test_linearity_and_sampled_oracle_rows(pkg, oracle, amazon):
+    from gespmm_amd import spmm
+
+    M, N = amazon["M"], 128
+    rp, ci = amazon["rowptr"], amazon["colind"]
+    B1 = torch.from_numpy(oracle.hash_B(M, N, seed=1)).cuda()
+    B2 = torch.from_numpy(oracle.hash_B(M, N, seed=2)).cuda()
+    val = torch.from_numpy(oracle.hash_val(amazon["nnz"], seed=7)).cuda()
+    C1 = spmm.csr_spmm(rp, ci, val, B1)
+    C2 = spmm.csr_spmm(rp, ci, val, B2)
+    C12 = spmm.csr_spmm(rp, ci, val, B1 + B2)
+    scale = spmm.csr_spmm(rp, ci, val.abs(), B1.abs() + B2.abs())
+    assert torch.all((C12 - (C1 + C2)).abs() <= 1e-5 * scale + 1e-12)
+    # 2000 sampled rows, bit-exact against the oracle on the extracted sub-matrix
+    rng = np.random.RandomState(0)
+    rows = np.sort(rng.choice(M, 2000, replace=False))
+    rph, cih, vh = rp.cpu().numpy(), ci.cpu().numpy(), val.cpu().numpy()
+    sub_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
+    sub_ptr[1:] = np.cumsum(rph[rows + 1] - rph[rows])
+    sel = np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows])
+    ref = oracle.spmm(sub_ptr, cih[sel], vh[sel], B1.cpu().numpy(), "fma")
+    got = C1[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.array_equal(bits(got), bits(ref))

@@ -1,0 +1,160 @@
+"""SPMMFunction / GCNConv (mirror of pytorch-custom/op.py) against a dense-torch
+restatement on the CPU:  out = D_in^-1/2 · A · (D_out^-1/2 ⊙ (X W)) + b,
+grad_feat = A^T · grad_out  (SURVEY.md §8 c2, A4), with A built exactly as
+gcn_custom.py:29-49 builds it (self-loops added, CSR stored as colptr/rowind, CSC as
+rowptr/colind)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def proc_like_reference(edge_index, n_v, add_self_loop=True):
+    """gcn_custom.py:29-49 with scipy, returning host arrays."""
+    if add_self_loop:
+        loops = np.array([np.arange(n_v).astype(np.int32)] * 2)
+        edge_index = np.concatenate((edge_index, loops), axis=1)
+    n_e = edge_index.shape[1]
+    adj = sp.coo_matrix((np.ones(n_e), (edge_index[0], edge_index[1])), shape=(n_v, n_v))
+    g = {}
+    csr = adj.tocsr()
+    g["colptr"], g["rowind"], g["value_csc"] = csr.indptr, csr.indices, csr.data.astype(np.float32)
+    csc = adj.tocsc()
+    g["rowptr"], g["colind"], g["value_csr"] = csc.indptr, csc.indices, csc.data.astype(np.float32)
+    g["dense"] = adj.toarray().astype(np.float64)
+    return g
+
+
+@pytest.fixture(scope="module")
+def graph():
+    rng = np.random.RandomState(0)
+    n_v, n_e = 300, 2400
+    src = rng.randint(0, n_v, n_e)
+    dst = rng.randint(0, n_v, n_e)
+    keep = src != dst
+    ei = np.unique(np.stack([src[keep], dst[keep]]), axis=1).astype(np.int32)
+    g = proc_like_reference(ei, n_v)
+    for k in ("rowptr", "colind", "colptr", "rowind"):
+        g[k + "_d"] = torch.from_numpy(g[k].astype(np.int32)).cuda()
+    g["value_csr_d"] = torch.from_numpy(g["value_csr"]).cuda()
+    g["value_csc_d"] = torch.from_numpy(g["value_csc"]).cuda()
+    g["n_v"] = n_v
+    return g
+
+
+def test_spmm_function_forward_backward(pkg, graph):
+    from gespmm_amd import SPMMFunction
+
+    g = graph
+    # the op's "rowptr/colind" are the CSC of adj => forward multiplies by adj^T
+    At = torch.from_numpy(g["dense"].T)
+    for weighted in (False, True):
+        x = torch.randn(g["n_v"], 24, dtype=torch.float64)
+        xd = x.float().cuda().requires_grad_(True)
+        args = [g["rowptr_d"], g["colind_d"], g["colptr_d"], g["rowind_d"], xd]
+        if weighted:
+            args += [g["value_csr_d"], g["value_csc_d"]]
+        y = SPMMFunction.apply(*args)
+        assert torch.allclose(y.detach().cpu().double(), At @ x.float().double(), atol=1e-4)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        assert torch.allclose(xd.grad.cpu().double(), At.T @ w.cpu().double(), atol=1e-4)
+    # returns exactly the reference's gradient structure: only `feat` gets a gradient
+    ew = g["value_csr_d"].clone().requires_grad_(True)
+    xd = torch.randn(g["n_v"], 8, device="cuda", requires_grad=True)
+    y = SPMMFunction.apply(g["rowptr_d"], g["colind_d"], g["colptr_d"], g["rowind_d"], xd, ew, g["value_csc_d"])
+    y.sum().backward()
+    assert ew.grad is None and xd.grad is not None
+
+
+def test_spmm_function_error_behaviour(pkg, graph):
+    from gespmm_amd import SPMMFunction
+
+    g = graph
+    xd = torch.randn(g["n_v"], 8, device="cuda", requires_grad=True)
+    y = SPMMFunction.apply(g["rowptr_d"], g["colind_d"], g["colptr_d"], g["rowind_d"], xd, g["value_csr_d"])
+    with pytest.raises(RuntimeError, match="edge values in both"):  # op.py:22-27
+        y.sum().backward()
+
+
+def test_edge_weight_gradient_extension(pkg, graph):
+    """need_edge_grad=True: d/dw[e] = <grad_out[row(e)], feat[col(e)]> via SDDMM."""
+    from gespmm_amd import SPMMFunction
+
+    g = graph
+    n = g["n_v"]
+    w = torch.rand(g["colind_d"].numel(), device="cuda").requires_grad_(True)
+    # CSC-ordered copy of the same weights for the backward SpMM
+    from gespmm_amd import spmm
+
+    colptr = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    rowind = torch.empty_like(g["colind_d"])
+    w_csc = spmm.csr2csc(g["rowptr_d"], g["colind_d"], colptr, rowind, w.detach())
+    x = torch.randn(n, 12, device="cuda", requires_grad=True)
+    y = SPMMFunction.apply(g["rowptr_d"], g["colind_d"], colptr, rowind, x, w, w_csc, True)
+    gout = torch.randn_like(y)
+    (y * gout).sum().backward()
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"),
+                                   (g["rowptr_d"][1:] - g["rowptr_d"][:-1]).long())
+    ref = (gout[rows] * x.detach()[g["colind_d"].long()]).sum(1)
+    assert torch.allclose(w.grad, ref, atol=1e-4)
+    dense = torch.zeros(n, n, device="cuda", dtype=torch.float64)
+    dense[rows, g["colind_d"].long()] = w.detach().double()
+    assert torch.allclose(x.grad.double(), dense.T @ gout.double(), atol=1e-4)
+
+
+@pytest.mark.parametrize("weighted", (False, True))
+def test_gcnconv_matches_dense_restatement(pkg, graph, weighted):
+    from gespmm_amd import GCNConv
+
+    g = graph
+    torch.manual_seed(0)
+    conv = GCNConv(40, 16, cached=True, normalize=True).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(g["n_v"], 40, device="cuda", requires_grad=True)
+    args = (x, g["rowptr_d"], g["colind_d"], g["colptr_d"], g["rowind_d"])
+    if weighted:
+        args += (g["value_csr_d"], g["value_csc_d"])
+    out = conv(*args)
+    A = torch.from_numpy(g["dense"].T).cuda()  # forward operand (see above)
+    in_deg = torch.from_numpy(np.diff(g["rowptr"]).astype(np.float64)).cuda()
+    out_deg = torch.from_numpy(np.diff(g["colptr"]).astype(np.float64)).cuda()
+    W, b = conv.weight.detach().double(), conv.bias.detach().double()
+    ref = (in_deg ** -0.5).unsqueeze(1) * (A @ ((out_deg ** -0.5).unsqueeze(1) * (x.detach().double() @ W))) + b
+    assert torch.allclose(out.double(), ref, atol=2e-4)
+    out.pow(2).sum().backward()
+    xr = x.detach().double().requires_grad_(True)
+    Wr = W.clone().requires_grad_(True)
+    ((in_deg ** -0.5).unsqueeze(1) * (A @ ((out_deg ** -0.5).unsqueeze(1) * (xr @ Wr))) + b).pow(2).sum().backward()
+    assert torch.allclose(x.grad.double(), xr.grad, atol=2e-3)
+    assert torch.allclose(conv.weight.grad.double(), Wr.grad, atol=2e-3)
+    assert conv.cached_result is not None
+    assert repr(conv) == "GCNConv(40, 16)"
+
+
+def test_two_layer_gcn_trains(pkg, graph):
+    """The caller of gcn_custom.py:63-143 in miniature: loss goes down."""
+    import torch.nn.functional as F
+
+    from gespmm_amd import GCNConv
+
+    g = graph
+    torch.manual_seed(1)
+    x = torch.rand(g["n_v"], 50, device="cuda")
+    x = x / x.sum(1, keepdim=True)
+    ylab = torch.randint(0, 3, (g["n_v"],), device="cuda")
+    c1, c2 = GCNConv(50, 32, cached=True).cuda(), GCNConv(32, 3, cached=True).cuda()
+    opt = torch.optim.Adam([dict(params=c1.parameters(), weight_decay=5e-4), dict(params=c2.parameters())], lr=0.01)
+    a = (g["rowptr_d"], g["colind_d"], g["colptr_d"], g["rowind_d"], g["value_csr_d"], g["value_csc_d"])
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        h = F.dropout(F.relu(c1(x, *a)), training=True)
+        loss = F.nll_loss(F.log_softmax(c2(h, *a), dim=1), ylab)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]

@@ -1,0 +1,242 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same inputs. Variants 0-4 must be BIT-EXACT (integer compare of the fp32 bit patterns)
+against the device-arithmetic restatement, and — unweighted — against the reference's
+CPU golden loop; the parallel-reduction variant is held to north_star's 1e-4 relative
+tolerance, scaled by sum|a*b| as SURVEY.md §8(c4) prescribes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, bits, edge_case_csr
+
+pytestmark = pytest.mark.gpu
+
+EXACT_VARIANTS = (-1, 0, 1, 2, 3, 4)
+N_SWEEP = (1, 2, 3, 4, 5, 8, 16, 31, 32, 33, 41, 64, 100, 128, 192, 256, 512)
+
+
+def dev_csr(G, dev="cuda"):
+    return (torch.from_numpy(np.ascontiguousarray(G["rowptr"])).to(dev),
+            torch.from_numpy(np.ascontiguousarray(G["colind"])).to(dev))
+
+
+def run(pkg, G, B, val=None, variant=-1, cfg=None):
+    from gespmm_amd import spmm
+
+    rp, ci = dev_csr(G)
+    Bd = torch.from_numpy(B).cuda()
+    if val is None:
+        C = spmm.csr_spmm_no_edge_value(rp, ci, Bd, variant=variant, cfg=cfg)
+    else:
+        C = spmm.csr_spmm(rp, ci, torch.from_numpy(val).cuda(), Bd, variant=variant, cfg=cfg)
+    torch.cuda.synchronize()
+    return C.cpu().numpy()
+
+
+def assert_bits_equal(a, b, what):
+    if not np.array_equal(bits(a), bits(b)):
+        bad = np.argwhere(bits(a) != bits(b))
+        r, c = bad[0]
+        raise AssertionError("%s: %d/%d elements differ, first at [%d,%d]: %r vs %r" %
+                             (what, len(bad), a.size, r, c, a[r, c], b[r, c]))
+
+
+@pytest.mark.parametrize("g", ("cora", "citeseer", "pubmed"))
+def test_bundled_graphs_bit_exact_all_variants(pkg, oracle, bundled, g):
+    G = bundled[g]
+    val = oracle.hash_val(G["nnz"], seed=7)
+    for N in (3, 16, 32, 41, 64, 128, 512):
+        if g == "pubmed" and N == 512:
+            continue
+        B = oracle.hash_B(G["K"], N, seed=1)
+        ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")  # reference CPU golden
+        ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")      # reference device arithmetic
+        for variant in EXACT_VARIANTS:
+            assert_bits_equal(run(pkg, G, B, None, variant), ref_u, "%s N=%d unweighted v%d" % (g, N, variant))
+            assert_bits_equal(run(pkg, G, B, val, variant), ref_v, "%s N=%d valued v%d" % (g, N, variant))
+
+
+def test_committed_golden_vectors(pkg, oracle, bundled):
+    """HIP output against the vectors committed under tests/golden/ (no oracle call)."""
+    with open(os.path.join(GOLDEN, "spmm_checksums.json")) as f:
+        sums = json.load(f)["graphs"]
+    for g in ("cora", "citeseer", "pubmed"):
+        G = bundled[g]
+        val = oracle.hash_val(G["nnz"], seed=7)
+        for N in (3, 16, 32, 41, 64, 128, 512):
+            B = oracle.hash_B(G["K"], N, seed=1)
+            for mode, v in (("unweighted_golden", None), ("valued_fma", val)):
+                C = run(pkg, G, B, v)
+                exp = sums[g][str(N)][mode]
+                assert int(np.bitwise_xor.reduce(bits(C).ravel())) == exp["xor"], (g, N, mode)
+                assert float(C.astype(np.float64).sum()) == exp["sum"], (g, N, mode)
+                for r, c, b in exp["samples"]:
+                    assert int(bits(C[r, c:c + 1])[0]) == b
+
+
+@pytest.mark.parametrize("seed", (0, 1))
+def test_edge_shapes_every_width(pkg, oracle, seed):
+    """Empty rows, rows of 63/64/65/127/128/129/200 entries, ragged M, K != M, unsorted
+    and repeated column indices — across N that are not multiples of any tile."""
+    G = edge_case_csr(seed)
+    val = oracle.hash_val(G["nnz"], seed=3)
+    for N in N_SWEEP:
+        B = oracle.hash_B(G["K"], N, seed=10 + N)
+        ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
+        ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+        for variant in EXACT_VARIANTS:
+            assert_bits_equal(run(pkg, G, B, None, variant), ref_u, "edge N=%d unweighted v%d" % (N, variant))
+            assert_bits_equal(run(pkg, G, B, val, variant), ref_v, "edge N=%d valued v%d" % (N, variant))
+
+
+def test_explicit_geometries_and_flags(pkg, oracle, bundled):
+    """Every (vec, strips, group) the launcher accepts gives the same bits, with and
+    without the XCD remap, non-temporal stores and 64-bit offsets."""
+    from gespmm_amd import _lib
+
+    G = bundled["cora"]
+    val = oracle.hash_val(G["nnz"], seed=5)
+    for N in (8, 96, 128, 200):
+        B = oracle.hash_B(G["K"], N, seed=N)
+        ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+        ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
+        for vec in (1, 2, 4):
+            for strips in (1, 2):
+                for group in (4, 8, 16, 32, 64):
+                    for flags in (0, _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_NT_STORE, _lib.FLAG_FORCE_IDX64,
+                                  _lib.FLAG_NT_STORE | _lib.FLAG_FORCE_IDX64 | _lib.FLAG_NO_XCD_REMAP):
+                        cfg = {"vec": vec, "strips": strips, "group": group, "flags": flags}
+                        what = "N=%d cfg=%r" % (N, cfg)
+                        assert_bits_equal(run(pkg, G, B, val, 3, cfg), ref_v, what)
+                        assert_bits_equal(run(pkg, G, B, None, 1, cfg), ref_u, what)
+                        assert_bits_equal(run(pkg, G, B, val, 0, cfg), ref_v, what + " naive")
+
+
+def test_parallel_reduction_variant_within_tolerance(pkg, oracle, bundled):
+    for g, Ns in (("cora", (1, 3, 7, 16, 41)), ("pubmed", (3, 8))):
+        G = bundled[g]
+        val = oracle.hash_val(G["nnz"], seed=2)
+        for N in Ns:
+            B = oracle.hash_B(G["K"], N, seed=N)
+            for v in (None, val):
+                ref = oracle.spmm(G["rowptr"], G["colind"], v, B, "fma")
+                scale = oracle.spmm_abs(G["rowptr"], G["colind"], v, B)
+                C = run(pkg, G, B, v, variant=5)
+                tol = 1e-4 * np.maximum(np.abs(ref), scale)  # north_star: 1e-4 relative
+                assert np.all(np.abs(C.astype(np.float64) - ref) <= tol + 1e-30), (g, N)
+    G = edge_case_csr(4)
+    B = oracle.hash_B(G["K"], 5, seed=1)
+    ref = oracle.spmm(G["rowptr"], G["colind"], None, B, "fma")
+    for group in (4, 8, 16, 32, 64):
+        C = run(pkg, G, B, None, variant=5, cfg={"group": group})
+        assert np.abs(C - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_misaligned_and_strided_inputs(pkg, oracle, bundled):
+    """A B/C pointer that is only 4- or 8-byte aligned degrades the vector width, never
+    the result; non-contiguous inputs are rejected like the reference's asserts."""
+    from gespmm_amd import spmm
+
+    G = bundled["citeseer"]
+    rp, ci = dev_csr(G)
+    N = 64
+    B = oracle.hash_B(G["K"], N, seed=8)
+    ref = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
+    for shift in (1, 2, 3):
+        flat = torch.zeros(G["K"] * N + 8, dtype=torch.float32, device="cuda")
+        Bd = flat[shift:shift + G["K"] * N].view(G["K"], N)
+        Bd.copy_(torch.from_numpy(B))
+        assert Bd.data_ptr() % 16 != 0
+        oflat = torch.empty(G["M"] * N + 8, dtype=torch.float32, device="cuda")
+        out = oflat[shift:shift + G["M"] * N].view(G["M"], N)
+        spmm.csr_spmm_no_edge_value(rp, ci, Bd, out=out)
+        assert_bits_equal(out.cpu().numpy(), ref, "shift %d" % shift)
+    with pytest.raises(ValueError):
+        spmm.csr_spmm_no_edge_value(rp, ci, torch.from_numpy(B).cuda().t())
+    with pytest.raises(TypeError):
+        spmm.csr_spmm_no_edge_value(rp.long(), ci, torch.from_numpy(B).cuda())
+    with pytest.raises(RuntimeError):
+        spmm.csr_spmm_no_edge_value(rp.cpu(), ci, torch.from_numpy(B).cuda())
+
+
+def test_degenerate_shapes(pkg, oracle):
+    from gespmm_amd import spmm
+
+    # M = 0, N = 0, nnz = 0, single row, single column
+    rp = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ci = torch.zeros(0, dtype=torch.int32, device="cuda")
+    assert spmm.csr_spmm_no_edge_value(rp, ci, torch.ones(5, 8, device="cuda")).shape == (0, 8)
+    rp = torch.zeros(4, dtype=torch.int32, device="cuda")
+    out = spmm.csr_spmm_no_edge_value(rp, ci, torch.ones(5, 8, device="cuda"))
+    assert out.shape == (3, 8) and torch.all(out == 0), "rows without non-zeros write 0 (no pre-zeroing needed)"
+    assert spmm.csr_spmm_no_edge_value(rp, ci, torch.ones(5, 0, device="cuda")).shape == (3, 0)
+    rp = torch.tensor([0, 3], dtype=torch.int32, device="cuda")
+    ci = torch.tensor([2, 0, 2], dtype=torch.int32, device="cuda")
+    B = torch.arange(3, dtype=torch.float32, device="cuda").view(3, 1) + 1
+    v = torch.tensor([0.5, 2.0, -1.0], device="cuda")
+    assert spmm.csr_spmm(rp, ci, v, B).item() == 0.5 * 3 + 2.0 * 1 - 3.0
+    # output buffer pre-filled with garbage is fully overwritten
+    G = edge_case_csr(5)
+    Bn = oracle.hash_B(G["K"], 33, seed=1)
+    junk = torch.full((G["M"], 33), float("nan"), device="cuda")
+    rpd, cid = dev_csr(G)
+    spmm.csr_spmm_no_edge_value(rpd, cid, torch.from_numpy(Bn).cuda(), out=junk)
+    assert_bits_equal(junk.cpu().numpy(), oracle.spmm(G["rowptr"], G["colind"], None, Bn, "golden"), "overwrite")
+
+
+def test_special_values_propagate_like_the_reference(pkg, oracle):
+    """inf / nan / -0 in B and val: the chain is the same IEEE fma sequence."""
+    G = edge_case_csr(6)
+    N = 16
+    B = oracle.hash_B(G["K"], N, seed=2)
+    B[3, :] = np.inf
+    B[7, 2] = np.nan
+    B[11, :] = -0.0
+    val = oracle.hash_val(G["nnz"], seed=4)
+    val[::17] = 0.0
+    val[5::29] = -0.0
+    ref = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+    for variant in EXACT_VARIANTS:
+        C = run(pkg, G, B, val, variant)
+        nan_ref, nan_c = np.isnan(ref), np.isnan(C)
+        assert np.array_equal(nan_ref, nan_c)
+        assert np.array_equal(bits(C)[~nan_c], bits(ref)[~nan_ref])
+
+
+def test_max_reducer(pkg, oracle, bundled):
+    from gespmm_amd import spmm
+
+    for G in (edge_case_csr(7), bundled["cora"]):
+        rp, ci = dev_csr(G)
+        for N in (1, 5, 32, 100, 128):
+            B = oracle.hash_B(G["K"], N, seed=N)
+            for init in (-10000.0, float("-inf")):
+                ref = oracle.spmm_max(G["rowptr"], G["colind"], B, init)
+                for variant in (-1, 1, 2, 3, 4):
+                    C = spmm.csr_spmm_max(rp, ci, torch.from_numpy(B).cuda(), init, variant).cpu().numpy()
+                    assert_bits_equal(C, ref, "max N=%d init=%r v%d" % (N, init, variant))
+
+
+def test_stream_semantics(pkg, oracle, bundled):
+    """Launches go to the CURRENT torch stream (the reference uses the legacy default
+    stream, spmm_kernel.cu:189,196,203)."""
+    from gespmm_amd import spmm
+
+    G = bundled["cora"]
+    rp, ci = dev_csr(G)
+    B = torch.from_numpy(oracle.hash_B(G["K"], 64, seed=3)).cuda()
+    ref = spmm.csr_spmm_no_edge_value(rp, ci, B)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        big = torch.randn(4096, 4096, device="cuda")
+        for _ in range(4):
+            big = big @ big  # keep the side stream busy ahead of the SpMM
+            big = big / big.abs().max()
+        x = (big[: G["K"], :64] * 0 + B).contiguous()  # depends on the matmuls: only valid in-stream
+        out = spmm.csr_spmm_no_edge_value(rp, ci, x)
+    s.synchronize()
+    assert torch.equal(out, ref)

@@ -1,0 +1,122 @@
+"""Synthetic stand-in generators (host logic) and the multi-GPU row partition +
+B exchange, exercised with 2 gloo processes on CPU tensors. The SpMM of each shard is
+evaluated by the ORACLE here (as the checker): what is under test is the partition,
+the rebasing and the exchange, which contain no device code."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def test_synthetic_contract_small(pkg):
+    from gespmm_amd import graphs
+
+    for name in ("com-amazon-like", "cit-hepth-like", "pubmed-like"):
+        g = graphs.synthetic_graph(name, seed=3, scale=0.02)
+        M, nnz, sym, _ = graphs.SPECS[name]
+        rp, ci = g["rowptr"].long(), g["colind"].long()
+        assert rp[0] == 0 and rp[-1] == g["nnz"] == ci.numel()
+        rows = torch.repeat_interleave(torch.arange(g["M"]), rp[1:] - rp[:-1])
+        key = rows * g["M"] + ci
+        assert torch.all(key[1:] > key[:-1]), "sorted by (row, col), no duplicates"
+        assert int(ci.min()) >= 0 and int(ci.max()) < g["K"]
+        if sym:
+            assert not torch.any(rows == ci)
+            assert torch.equal(torch.sort(ci * g["M"] + rows)[0], key)
+        g2 = graphs.synthetic_graph(name, seed=3, scale=0.02)
+        assert torch.equal(g2["colind"], g["colind"]), "pure function of (name, seed)"
+        g3 = graphs.synthetic_graph(name, seed=4, scale=0.02)
+        assert not torch.equal(g3["colind"], g["colind"])
+
+
+def test_exact_sizes_of_the_headline_graph(pkg):
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("cit-hepth-like", seed=42)
+    assert (g["M"], g["nnz"]) == (27770, 352807)  # matrix_id_info.xlsx row cit-HepTh
+    loc = graphs.synthetic_graph("com-amazon-like", seed=1, scale=0.05, locality=0.9, band=50)
+    rp, ci = loc["rowptr"].long(), loc["colind"].long()
+    rows = torch.repeat_interleave(torch.arange(loc["M"]), rp[1:] - rp[:-1])
+    d = (rows - ci).abs()
+    d = torch.minimum(d, loc["M"] - d)
+    assert float((d < 500).float().mean()) > 0.8, "locality knob produces a banded pattern"
+
+
+def test_self_loops_and_transpose(pkg):
+    from gespmm_amd import graphs
+    import scipy.sparse as sp
+
+    g = graphs.synthetic_graph("pubmed-selfloop-like", seed=0, scale=0.05)
+    M = g["M"]
+    A = sp.csr_matrix((np.ones(g["nnz"]), g["colind"].numpy(), g["rowptr"].numpy()), shape=(M, M))
+    assert np.all(A.diagonal() == 1)
+    colptr, rowind = graphs.transpose_csr(g["rowptr"], g["colind"])
+    T = A.tocsc()
+    assert np.array_equal(colptr.numpy(), T.indptr) and np.array_equal(rowind.numpy(), T.indices)
+    B = graphs.reference_B(7, 5, seed=1)
+    q = torch.round(B * 100)
+    assert q.min() >= -50 and q.max() <= 49
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gespmm_amd  # noqa: F401
+    from gespmm_amd import dist as gdist
+    from gespmm_amd import graphs
+
+    import oracle_py
+
+    G = graphs.load_mtx_as_csr(os.path.join(ROOT, "tests", "golden", "cora.mtx"))
+    N = 24
+    val = oracle_py.hash_val(G["nnz"], seed=1)
+    cut = gdist.partition_rows(G["rowptr"], world)
+    lptr, lcol, lval, (r0, r1) = gdist.shard_csr(G["rowptr"], G["colind"], val, cut, rank)
+    assert lptr[0] == 0 and lptr[-1] == len(lcol) == len(lval)
+
+    # (a) B row-sharded over ranks (ragged shards), all_gather'ed
+    Bfull_ref = oracle_py.hash_B(G["K"], N, seed=2)
+    bcut = np.linspace(0, G["K"], world + 1).astype(int)
+    bcut[1] += 3  # ragged on purpose
+    counts = [int(bcut[i + 1] - bcut[i]) for i in range(world)]
+    mine = torch.from_numpy(Bfull_ref[bcut[rank]:bcut[rank + 1]].copy())
+    Bfull = gdist.exchange_dense(mine, counts)
+    assert np.array_equal(Bfull.numpy(), Bfull_ref)
+    # equal shards take the all_gather_into_tensor path
+    Keq = (G["K"] // world) * world
+    eq = torch.from_numpy(Bfull_ref[rank * (Keq // world):(rank + 1) * (Keq // world)].copy())
+    assert np.array_equal(gdist.exchange_dense(eq).numpy(), Bfull_ref[:Keq])
+    # (b) B owned by rank 1, broadcast
+    Bb = gdist.broadcast_dense(torch.from_numpy(Bfull_ref) if rank == 1 else None, G["K"], N, src=1)
+    assert np.array_equal(Bb.numpy(), Bfull_ref)
+
+    # shard product (oracle as checker) == the same rows of the full product
+    C_loc = oracle_py.spmm(lptr, lcol, lval, Bfull.numpy(), "fma")
+    C_ref = oracle_py.spmm(G["rowptr"], G["colind"], val, Bfull_ref, "fma")
+    assert np.array_equal(C_loc.view(np.uint32), C_ref[r0:r1].view(np.uint32))
+    # gather the row shards back and compare the whole matrix on rank 0
+    pieces = [None] * world
+    dist.all_gather_object(pieces, (r0, r1, C_loc))
+    if rank == 0:
+        whole = np.concatenate([p[2] for p in sorted(pieces, key=lambda t: t[0])])
+        assert np.array_equal(whole.view(np.uint32), C_ref.view(np.uint32))
+        loads = [int(G["rowptr"][p[1]] - G["rowptr"][p[0]]) for p in pieces]
+        assert max(loads) - min(loads) <= 2 * 168 + 2, "nnz-balanced (cora max degree 168)"
+        open(os.path.join(tmpdir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_partition_and_exchange_world2(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()

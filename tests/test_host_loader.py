@@ -1,0 +1,138 @@
+"""Product host code (C ABI loader / COO->CSR / row partition) against the oracle."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+
+def _all_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.mtx")) + glob.glob(os.path.join(GOLDEN, "mtx", "*.mtx")))
+
+
+def test_loader_matches_oracle_on_every_fixture(pkg, oracle):
+    from gespmm_amd import _lib, graphs
+
+    n_ok = 0
+    for path in _all_files():
+        ref = oracle.read_mtx(path)
+        if ref["rc"] != 0:
+            with pytest.raises(_lib.GespmmError) as ei:
+                graphs.read_mtx(path)
+            assert ei.value.code == -5, path  # GESPMM_EFORMAT
+            continue
+        got = graphs.read_mtx(path)
+        assert (got["nrows"], got["ncols"], got["nnz"]) == (ref["nrows"], ref["ncols"], ref["nnz"]), path
+        assert np.array_equal(got["row"], ref["row"]), path
+        assert np.array_equal(got["col"], ref["col"]), path
+        assert np.array_equal(got["val"], ref["val"]), path
+        n_ok += 1
+    assert n_ok >= 10
+
+
+def test_loader_handmade_expectations(pkg):
+    from gespmm_amd import graphs
+
+    with open(os.path.join(GOLDEN, "mtx_expected.json")) as f:
+        expected = json.load(f)
+    for name, exp in expected.items():
+        if exp["rc"] == "format":
+            continue
+        got = graphs.read_mtx(os.path.join(GOLDEN, "mtx", name))
+        assert got["row"].tolist() == exp["row"] and got["col"].tolist() == exp["col"], name
+        assert np.array_equal(got["val"], np.array(exp["val"], dtype=np.float32)), name
+
+
+def test_loader_errors_are_codes_not_exits(pkg, tmp_path):
+    from gespmm_amd import _lib, graphs
+
+    with pytest.raises(_lib.GespmmError) as ei:
+        graphs.read_mtx(tmp_path / "missing.mtx")
+    assert ei.value.code == -4  # GESPMM_EIO (reference: prints and exit(1), util.hpp:300-303)
+    p = tmp_path / "nosize.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n% only comments\n")
+    with pytest.raises(_lib.GespmmError) as ei:
+        graphs.read_mtx(p)
+    assert ei.value.code == -5
+    p = tmp_path / "array.mtx"
+    p.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(_lib.GespmmError):
+        graphs.read_mtx(p)
+    p = tmp_path / "zero_based.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n2 2 1\n0 1\n")
+    with pytest.raises(_lib.GespmmError):
+        graphs.read_mtx(p)
+
+
+def test_loader_large_random_file(pkg, oracle, tmp_path):
+    """Ragged whitespace, many duplicates, symmetric expansion at a few 10^4 entries."""
+    rng = np.random.RandomState(11)
+    M, n = 700, 30000
+    r = rng.randint(1, M + 1, n)
+    c = rng.randint(1, M + 1, n)
+    v = rng.randint(-9, 10, n)
+    p = tmp_path / "rand_sym.mtx"
+    with open(p, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate integer symmetric\n%%c\n%d %d %d\n" % (M, M, n))
+        for i in range(n):
+            f.write("%d\t%d   %d\n" % (r[i], c[i], v[i]) if i % 3 else " %d %d %d \n" % (r[i], c[i], v[i]))
+    from gespmm_amd import graphs
+
+    got, ref = graphs.read_mtx(p), oracle.read_mtx(p)
+    assert got["nnz"] == ref["nnz"] and got["nnz"] > 0
+    assert np.array_equal(got["row"], ref["row"]) and np.array_equal(got["col"], ref["col"])
+    # duplicates with different values: both keep the first in (row, col, file order)
+    assert np.array_equal(got["val"], ref["val"])
+
+
+def test_coo_to_csr_matches_oracle(pkg, oracle):
+    from gespmm_amd import _lib, graphs
+
+    rng = np.random.RandomState(5)
+    nrows, ncols, nnz = 53, 61, 900
+    row = rng.randint(0, nrows, nnz).astype(np.int32)
+    col = rng.randint(0, ncols, nnz).astype(np.int32)
+    val = rng.rand(nnz).astype(np.float32)
+    for v in (None, val):
+        a = graphs.coo_to_csr(nrows, ncols, row, col, v)
+        b = oracle.coo_to_csr(nrows, row, col, v)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    ptr, ind, vv = graphs.coo_to_csr(4, 4, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert ptr.tolist() == [0, 0, 0, 0, 0] and ind.size == 0
+    with pytest.raises(_lib.GespmmError):  # reference only prints "out of bound row" (spmm_test.cu:563)
+        graphs.coo_to_csr(3, 3, np.array([3], np.int32), np.array([0], np.int32))
+    with pytest.raises(_lib.GespmmError):
+        graphs.coo_to_csr(3, 3, np.array([0], np.int32), np.array([3], np.int32))
+
+
+def test_load_mtx_as_csr_forces_ones(pkg, bundled):
+    from gespmm_amd import graphs
+
+    for g in ("cora", "citeseer", "pubmed"):
+        got = graphs.load_mtx_as_csr(os.path.join(GOLDEN, g + ".mtx"))
+        assert np.array_equal(got["rowptr"], bundled[g]["rowptr"])
+        assert np.array_equal(got["colind"], bundled[g]["colind"])
+        assert np.all(got["val"] == 1.0)
+
+
+def test_row_partition_properties(pkg, bundled):
+    from gespmm_amd import graphs
+
+    rowptr = bundled["pubmed"]["rowptr"]
+    M, nnz = len(rowptr) - 1, int(rowptr[-1])
+    for parts in (1, 2, 3, 8, 64):
+        cut = graphs.row_partition(rowptr, parts)
+        assert cut[0] == 0 and cut[-1] == M and np.all(np.diff(cut) >= 0)
+        loads = rowptr[cut[1:]] - rowptr[cut[:-1]]
+        assert loads.sum() == nnz
+        maxdeg = int(np.diff(rowptr).max())
+        assert loads.max() <= nnz / parts + maxdeg + 1, "balanced to within one row"
+    skew = np.array([0, 0, 1000, 1000, 1001, 1002], dtype=np.int32)  # one giant row
+    cut = graphs.row_partition(skew, 4)
+    assert cut[0] == 0 and cut[-1] == 5 and np.all(np.diff(cut) >= 0)
+    empty = np.zeros(6, dtype=np.int32)
+    assert graphs.row_partition(empty, 3)[-1] == 5
