@@ -23,6 +23,8 @@ NUM_VARIANTS = 6
 FLAG_NO_XCD_REMAP = 0x1
 FLAG_NT_STORE = 0x2
 FLAG_FORCE_IDX64 = 0x4
+FLAG_ROW_PER_GROUP = 0x8
+FLAG_SHALLOW_UNROLL = 0x10
 
 # Every symbol include/gespmm.h declares; tests check the library exports all of them.
 EXPORTS = [
@@ -44,7 +46,8 @@ EXPORTS = [
 
 
 class LaunchCfg(Structure):
-    _fields_ = [("vec", c_int32), ("strips", c_int32), ("group", c_int32), ("flags", c_int32)]
+    _fields_ = [("vec", c_int32), ("strips", c_int32), ("group", c_int32), ("rows_per_wave", c_int32),
+                ("flags", c_int32)]
 
 
 class Coo(Structure):

@@ -45,6 +45,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     if (reduce == gespmm::kReduceMax && (val != nullptr || variant == GESPMM_VARIANT_PARREDUCE ||
                                          variant == GESPMM_VARIANT_NAIVE))
         return GESPMM_EINVAL;
+    if (cfg && (cfg->rows_per_wave < 0 || cfg->rows_per_wave > gespmm::kMaxRowsPerWave)) return GESPMM_EINVAL;
 
     // Vector width is limited by what both B and C rows can be addressed with.
     int max_vec = 4;
@@ -55,7 +56,8 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     int flags = 0;
     if (cfg) flags = cfg->flags;
     const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
-                                             cfg ? cfg->strips : 0, cfg ? cfg->group : 0, flags, &sel);
+                                             cfg ? cfg->strips : 0, cfg ? cfg->group : 0,
+                                             cfg ? cfg->rows_per_wave : 0, flags, &sel);
     if (src != 0) return src;
     sel.geo.reduce = reduce;
 
@@ -74,8 +76,11 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
+    a.rpw = sel.geo.rows_per_wave;
     if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);
-    else e = gespmm::launch_spmm_rowgroup(a, sel.geo, st);
+    else if (sel.variant == GESPMM_VARIANT_NAIVE || (flags & gespmm::kFlagRowPerGroup))
+        e = gespmm::launch_spmm_rowgroup(a, sel.geo, st);
+    else e = gespmm::launch_spmm_stream(a, sel.geo, st);
     return (int)e;
 }
 

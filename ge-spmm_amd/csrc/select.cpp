@@ -28,7 +28,7 @@ int auto_variant(int64_t M, int64_t nnz, int64_t N) {
 }
 
 int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, int max_vec,
-                     int cfg_vec, int cfg_strips, int cfg_group, int flags, Selection* out) {
+                     int cfg_vec, int cfg_strips, int cfg_group, int cfg_rows_per_wave, int flags, Selection* out) {
     if (variant == GESPMM_VARIANT_AUTO) variant = auto_variant(M, nnz, N);
     Geometry g;
     g.reduce = kReduceSum;
@@ -68,6 +68,19 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         if (cfg_group < 4 || cfg_group > 64 || (cfg_group & (cfg_group - 1))) return GESPMM_EINVAL;
         g.group = cfg_group;
     }
+    // Rows per wavefront of the streaming kernel: aim at ~2 LDS tiles (128 CSR entries)
+    // per wavefront so row pointers and tiles are fetched in full coalesced loads, but
+    // keep >= ~4 wavefronts per wave slot of the chip (256 CUs x 32 slots) in the grid.
+    const int rows_in_flight = 64 / g.group;
+    {
+        const int64_t avg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
+        int rpw = kMaxRowsPerWave;
+        while (rpw > rows_in_flight && (int64_t)rpw * avg > 128) rpw >>= 1;
+        while (rpw > rows_in_flight && M / rpw < 4 * 8192) rpw >>= 1;
+        if (rpw < rows_in_flight) rpw = rows_in_flight;
+        g.rows_per_wave = rpw;
+    }
+    if (cfg_rows_per_wave) g.rows_per_wave = cfg_rows_per_wave;
     out->variant = variant;
     out->geo = g;
     return 0;

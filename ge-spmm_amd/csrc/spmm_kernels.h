@@ -9,6 +9,7 @@ namespace gespmm {
 constexpr int kThreads = 256;  // workgroup = 4 wavefronts of 64 lanes
 constexpr int kWaves = 4;
 constexpr int kTile = 64;      // CSR entries staged in LDS per wavefront refill
+constexpr int kMaxRowsPerWave = 32;  // streaming kernel: rows owned by one wavefront
 
 constexpr int kReduceSum = 0;
 constexpr int kReduceMax = 1;
@@ -16,6 +17,8 @@ constexpr int kReduceMax = 1;
 constexpr int kFlagNoXcdRemap = 0x1;  // == GESPMM_FLAG_NO_XCD_REMAP
 constexpr int kFlagNtStore = 0x2;     // == GESPMM_FLAG_NT_STORE
 constexpr int kFlagForceIdx64 = 0x4;  // == GESPMM_FLAG_FORCE_IDX64
+constexpr int kFlagShallowUnroll = 0x10; // == GESPMM_FLAG_SHALLOW_UNROLL
+constexpr int kFlagRowPerGroup = 0x8; // == GESPMM_FLAG_ROW_PER_GROUP (first-generation CRC kernel)
 
 struct SpmmArgs {
     const int32_t* rowptr;
@@ -28,6 +31,7 @@ struct SpmmArgs {
     int32_t nblk;   // row blocks (filled in by the launcher)
     int32_t ntile;  // column tiles (filled in by the launcher)
     int32_t flags;
+    int32_t rpw;    // streaming kernel: rows per wavefront (filled in by the launcher)
     float empty;    // max reducer: value of rows without non-zeros / initial accumulator
 };
 
@@ -36,12 +40,14 @@ struct Geometry {
     int vec;      // V: floats per lane per strip (1, 2, 4)
     int strips;   // S: strips per lane (1, 2)
     int group;    // W: lanes per row (4..64)
+    int rows_per_wave;  // streaming kernel: consecutive rows owned by one wavefront
     bool crc;     // LDS-staged CSR tiles (variants 1-4) vs naive (variant 0)
     bool idx64;   // 64-bit byte offsets into B
     int reduce;   // kReduceSum / kReduceMax
 };
 
 hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
 // sddmm_kernels.hip

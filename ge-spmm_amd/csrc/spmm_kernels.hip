@@ -109,7 +109,7 @@ constexpr int unroll_for(int cf) { return cf >= 8 ? 2 : (cf >= 4 ? 4 : 8); }
 
 // ----------------------------------------------------------------------------- CRC (+CWM) kernel
 
-template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC, bool NTS>
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC>
 __global__ __launch_bounds__(kThreads) void spmm_rowgroup_kernel(SpmmArgs a) {
     constexpr int G = 64 / W;  // rows per wavefront
     constexpr int U = unroll_for(V * S);
@@ -249,9 +249,173 @@ __global__ __launch_bounds__(kThreads) void spmm_rowgroup_kernel(SpmmArgs a) {
 
     if (rowok) {
         float* Crow = a.C + (size_t)row * (size_t)a.N + col0;
+        const bool nts = (a.flags & kFlagNtStore) != 0;
 #pragma unroll
         for (int s = 0; s < S; ++s)
-            if (colok[s]) store_vec<V, NTS>(Crow + s * (W * V), acc[s]);
+            if (colok[s]) {
+                if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                else store_vec<V, false>(Crow + s * (W * V), acc[s]);
+            }
+    }
+}
+
+
+// ----------------------------------------------------------------------------- streaming CRC (+CWM) kernel
+//
+// The production kernel for variants 1-4. One wavefront owns `rpw` CONSECUTIVE rows
+// (rpw a multiple of G, <= 32), i.e. one contiguous CSR range:
+//
+//   * row pointers of all its rows: ONE coalesced load, parked in LDS;
+//   * the CSR range streams through the wavefront's 64-entry LDS tile, one coalesced
+//     load per tile, the next tile always prefetched in registers — independent of
+//     where the row boundaries fall;
+//   * rows are walked G at a time ("batch"); a batch consumes the part of its rows
+//     that lies in the current tile, the tile advances when the batch reaches past
+//     it, the batch advances when its rows are finished. Both decisions are
+//     wave-uniform;
+//   * inside a batch the non-zeros are gathered U at a time, and the tail (< U) is
+//     issued as ONE predicated group, so a row of <= U non-zeros costs a single
+//     memory round trip instead of one per leftover entry.
+//
+// Per row this removes two of the three dependent global round trips of a
+// row-per-wave design (rowptr -> colind/val -> B) and keeps the accumulation order
+// (ascending CSR position, one FMA per non-zero) untouched.
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED, int U>
+__global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
+    constexpr int G = 64 / W;
+    using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
+
+    __shared__ off_t s_off[kWaves][kTile];
+    __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? kTile : 1];
+    __shared__ int s_ptr[kWaves][kMaxRowsPerWave + 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / W;
+    const int l = lane % W;
+
+    const int nitems = a.nblk * a.ntile;
+    const int item = (a.flags & kFlagNoXcdRemap) ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, nitems);
+    int tile = 0, rb = item;
+    if (a.ntile > 1) {
+        tile = item % a.ntile;
+        rb = item / a.ntile;
+    }
+    const int rpw = a.rpw;
+    const int row_first = (rb * kWaves + wave) * rpw;
+    if (row_first >= a.M) return;  // whole wavefront leaves together
+    const int nrows = (a.M - row_first < rpw) ? a.M - row_first : rpw;  // wave-uniform
+
+    // Row pointers of this wavefront's rows -> LDS (one coalesced load, rpw <= 32).
+    const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
+    if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
+    const int wb = __builtin_amdgcn_readfirstlane(rp);
+    const int we = __builtin_amdgcn_readlane(rp, nrows);
+
+    const int col0 = tile * (W * V * S) + l * V;
+    bool colok[S];
+    off_t cbytes[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        colok[s] = (col0 + s * W * V) < a.N;
+        // lanes/strips past N gather column 0 (valid, same line as lane 0) and skip the store
+        cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
+    }
+    const char* Bbase = reinterpret_cast<const char*>(a.B);
+    const off_t rowbytes = (off_t)a.N * 4u;
+    const float init = (RED == kReduceMax) ? a.empty : 0.0f;
+
+    // Tile stream state: `t0` = CSR position of the tile resident in LDS.
+    int pc = 0;
+    float pv = 0.0f;
+    auto fetch_tile_regs = [&](int base) {
+        const int p = base + lane;
+        if (p < we) {
+            pc = __builtin_nontemporal_load(a.colind + p);
+            if constexpr (VALUED) pv = __builtin_nontemporal_load(a.val + p);
+        }
+    };
+    auto publish_tile = [&]() {
+        s_off[wave][lane] = (off_t)(uint32_t)pc * rowbytes;
+        if constexpr (VALUED) s_val[wave][lane] = pv;
+    };
+    int t0 = wb;
+    fetch_tile_regs(t0);
+    publish_tile();
+    fetch_tile_regs(t0 + kTile);
+    wave_lds_sync();
+
+    for (int b = 0; b < nrows; b += G) {
+        const int r = b + g;
+        const bool rowok = r < nrows;
+        int lb = 0, hb = 0;
+        if (rowok) {
+            lb = s_ptr[wave][r];
+            hb = s_ptr[wave][r + 1];
+        }
+        const int be = __builtin_amdgcn_readfirstlane(s_ptr[wave][(b + G < nrows) ? b + G : nrows]);
+        if constexpr (G == 1) {
+            lb = __builtin_amdgcn_readfirstlane(lb);
+            hb = __builtin_amdgcn_readfirstlane(hb);
+        }
+
+        float acc[S][V];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[s][i] = init;
+
+        for (;;) {
+            const int tend = t0 + kTile;
+            int k = (lb > t0 ? lb : t0) - t0;
+            const int ke = (hb < tend ? hb : tend) - t0;
+            // U entries per step, every slot under one predicate: full steps and the tail
+            // share ONE register set, and a row of <= U non-zeros is a single round trip.
+            for (; k < ke; k += U) {
+                const int cnt = ke - k;
+                off_t off[U];
+                float v[U];
+                float bv[U][S][V];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    if (j < cnt) {
+                        off[j] = s_off[wave][k + j];
+                        if constexpr (VALUED) v[j] = s_val[wave][k + j];
+                        else v[j] = 1.0f;
+#pragma unroll
+                        for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    if (j < cnt) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int i = 0; i < V; ++i)
+                                acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+                    }
+                }
+            }
+            if (be <= tend) break;  // every row of this batch ends inside the resident tile
+            wave_lds_sync();        // all reads of the old tile are issued before it is overwritten
+            t0 = tend;
+            publish_tile();
+            fetch_tile_regs(t0 + kTile);
+            wave_lds_sync();
+        }
+
+        if (rowok) {
+            float* Crow = a.C + (size_t)(row_first + r) * (size_t)a.N + col0;
+            const bool nts = (a.flags & kFlagNtStore) != 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (colok[s]) {
+                    if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                    else store_vec<V, false>(Crow + s * (W * V), acc[s]);
+                }
+        }
     }
 }
 
@@ -309,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
 // ----------------------------------------------------------------------------- host-side launch table
 
 template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC>
-static hipError_t launch_rowgroup(const SpmmArgs& a, bool nts, hipStream_t st) {
+static hipError_t launch_rowgroup(const SpmmArgs& a, hipStream_t st) {
     constexpr int G = 64 / W;
     SpmmArgs args = a;
     args.nblk = (int)(((int64_t)a.M + kWaves * G - 1) / (kWaves * G));
@@ -318,48 +482,46 @@ static hipError_t launch_rowgroup(const SpmmArgs& a, bool nts, hipStream_t st) {
     if (nitems <= 0) return hipSuccess;
     if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
     dim3 grid((unsigned)nitems), block(kThreads);
-    if (nts) hipLaunchKernelGGL((spmm_rowgroup_kernel<V, S, W, VALUED, IDX64, RED, CRC, true>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((spmm_rowgroup_kernel<V, S, W, VALUED, IDX64, RED, CRC, false>), grid, block, 0, st, args);
+    hipLaunchKernelGGL((spmm_rowgroup_kernel<V, S, W, VALUED, IDX64, RED, CRC>), grid, block, 0, st, args);
     return hipGetLastError();
 }
 
 template <int V, int S, bool VALUED, bool IDX64, int RED, bool CRC>
-static hipError_t dispatch_w(const SpmmArgs& a, int W, bool nts, hipStream_t st) {
+static hipError_t dispatch_w(const SpmmArgs& a, int W, hipStream_t st) {
     switch (W) {
-        case 4: return launch_rowgroup<V, S, 4, VALUED, IDX64, RED, CRC>(a, nts, st);
-        case 8: return launch_rowgroup<V, S, 8, VALUED, IDX64, RED, CRC>(a, nts, st);
-        case 16: return launch_rowgroup<V, S, 16, VALUED, IDX64, RED, CRC>(a, nts, st);
-        case 32: return launch_rowgroup<V, S, 32, VALUED, IDX64, RED, CRC>(a, nts, st);
-        case 64: return launch_rowgroup<V, S, 64, VALUED, IDX64, RED, CRC>(a, nts, st);
+        case 4: return launch_rowgroup<V, S, 4, VALUED, IDX64, RED, CRC>(a, st);
+        case 8: return launch_rowgroup<V, S, 8, VALUED, IDX64, RED, CRC>(a, st);
+        case 16: return launch_rowgroup<V, S, 16, VALUED, IDX64, RED, CRC>(a, st);
+        case 32: return launch_rowgroup<V, S, 32, VALUED, IDX64, RED, CRC>(a, st);
+        case 64: return launch_rowgroup<V, S, 64, VALUED, IDX64, RED, CRC>(a, st);
     }
     return hipErrorInvalidValue;
 }
 
 template <bool VALUED, bool IDX64, int RED, bool CRC>
-static hipError_t dispatch_vs(const SpmmArgs& a, int V, int S, int W, bool nts, hipStream_t st) {
+static hipError_t dispatch_vs(const SpmmArgs& a, int V, int S, int W, hipStream_t st) {
     if (S == 2) {
-        if (V == 4) return dispatch_w<4, 2, VALUED, IDX64, RED, CRC>(a, W, nts, st);
+        if (V == 4) return dispatch_w<4, 2, VALUED, IDX64, RED, CRC>(a, W, st);
         return hipErrorInvalidValue;
     }
     switch (V) {
-        case 1: return dispatch_w<1, 1, VALUED, IDX64, RED, CRC>(a, W, nts, st);
-        case 2: return dispatch_w<2, 1, VALUED, IDX64, RED, CRC>(a, W, nts, st);
-        case 4: return dispatch_w<4, 1, VALUED, IDX64, RED, CRC>(a, W, nts, st);
+        case 1: return dispatch_w<1, 1, VALUED, IDX64, RED, CRC>(a, W, st);
+        case 2: return dispatch_w<2, 1, VALUED, IDX64, RED, CRC>(a, W, st);
+        case 4: return dispatch_w<4, 1, VALUED, IDX64, RED, CRC>(a, W, st);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
     const bool valued = a.val != nullptr;
-    const bool nts = (a.flags & kFlagNtStore) != 0;
     if (geo.reduce == kReduceMax) {
         // max reducer exists for the unweighted CRC path only (binary_reduce_max.cu).
         if (valued || !geo.crc) return hipErrorInvalidValue;
-        if (geo.idx64) return dispatch_vs<false, true, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, nts, st);
-        return dispatch_vs<false, false, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, nts, st);
+        if (geo.idx64) return dispatch_vs<false, true, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, st);
+        return dispatch_vs<false, false, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, st);
     }
 #define GESPMM_DISPATCH(VAL, I64, CRCF) \
-    return dispatch_vs<VAL, I64, kReduceSum, CRCF>(a, geo.vec, geo.strips, geo.group, nts, st)
+    return dispatch_vs<VAL, I64, kReduceSum, CRCF>(a, geo.vec, geo.strips, geo.group, st)
     if (geo.crc) {
         if (valued) { if (geo.idx64) GESPMM_DISPATCH(true, true, true); else GESPMM_DISPATCH(true, false, true); }
         else        { if (geo.idx64) GESPMM_DISPATCH(false, true, true); else GESPMM_DISPATCH(false, false, true); }
@@ -368,6 +530,72 @@ hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStrea
         else        { if (geo.idx64) GESPMM_DISPATCH(false, true, false); else GESPMM_DISPATCH(false, false, false); }
     }
 #undef GESPMM_DISPATCH
+}
+
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
+static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {
+    constexpr int G = 64 / W;
+    SpmmArgs args = a;
+    if (rpw < G) rpw = G;
+    if (rpw > kMaxRowsPerWave) rpw = kMaxRowsPerWave;
+    rpw = rpw / G * G;
+    args.rpw = rpw;
+    args.nblk = (int)(((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw));
+    args.ntile = (a.N + W * V * S - 1) / (W * V * S);
+    const int64_t nitems = (int64_t)args.nblk * args.ntile;
+    if (nitems <= 0) return hipSuccess;
+    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    // Gather depth U: 8 B-row loads in flight per lane group unless the accumulators are
+    // already wide (CF = 8) or the caller asks for the shallow form.
+    if constexpr (V * S >= 8) {
+        hipLaunchKernelGGL((spmm_stream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
+                           dim3(kThreads), 0, st, args);
+    } else {
+        if (a.flags & kFlagShallowUnroll)
+            hipLaunchKernelGGL((spmm_stream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
+                               dim3(kThreads), 0, st, args);
+        else
+            hipLaunchKernelGGL((spmm_stream_kernel<V, S, W, VALUED, IDX64, RED, 8>), dim3((unsigned)nitems),
+                               dim3(kThreads), 0, st, args);
+    }
+    return hipGetLastError();
+}
+
+template <int V, int S, bool VALUED, bool IDX64, int RED>
+static hipError_t stream_w(const SpmmArgs& a, int W, int rpw, hipStream_t st) {
+    switch (W) {
+        case 4: return launch_stream<V, S, 4, VALUED, IDX64, RED>(a, rpw, st);
+        case 8: return launch_stream<V, S, 8, VALUED, IDX64, RED>(a, rpw, st);
+        case 16: return launch_stream<V, S, 16, VALUED, IDX64, RED>(a, rpw, st);
+        case 32: return launch_stream<V, S, 32, VALUED, IDX64, RED>(a, rpw, st);
+        case 64: return launch_stream<V, S, 64, VALUED, IDX64, RED>(a, rpw, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <bool VALUED, bool IDX64, int RED>
+static hipError_t stream_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
+    if (g.strips == 2) {
+        if (g.vec == 4) return stream_w<4, 2, VALUED, IDX64, RED>(a, g.group, g.rows_per_wave, st);
+        return hipErrorInvalidValue;
+    }
+    switch (g.vec) {
+        case 1: return stream_w<1, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_wave, st);
+        case 2: return stream_w<2, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_wave, st);
+        case 4: return stream_w<4, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_wave, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+    const bool valued = a.val != nullptr;
+    if (geo.reduce == kReduceMax) {
+        if (valued) return hipErrorInvalidValue;  // max reducer is unweighted (binary_reduce_max.cu)
+        return geo.idx64 ? stream_vs<false, true, kReduceMax>(a, geo, st) : stream_vs<false, false, kReduceMax>(a, geo, st);
+    }
+    if (valued) return geo.idx64 ? stream_vs<true, true, kReduceSum>(a, geo, st) : stream_vs<true, false, kReduceSum>(a, geo, st);
+    return geo.idx64 ? stream_vs<false, true, kReduceSum>(a, geo, st) : stream_vs<false, false, kReduceSum>(a, geo, st);
 }
 
 template <int W, bool VALUED, bool IDX64>

@@ -109,18 +109,24 @@ int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N);
  *   strips   strips per lane (1 or 2); coarsening factor = vec * strips
  *   group    lanes cooperating on one row (4..64, power of two); a 64-lane
  *            wavefront therefore carries 64/group rows
+ *   rows_per_wave  consecutive rows one wavefront streams through (1..32; rounded to a
+ *            multiple of 64/group)
  *   flags    GESPMM_FLAG_* bits
  */
 typedef struct gespmm_launch_cfg {
     int32_t vec;
     int32_t strips;
     int32_t group;
+    int32_t rows_per_wave;
     int32_t flags;
 } gespmm_launch_cfg;
 
 #define GESPMM_FLAG_NO_XCD_REMAP   0x1  /* plain blockIdx -> row-block mapping */
 #define GESPMM_FLAG_NT_STORE       0x2  /* non-temporal stores of C */
 #define GESPMM_FLAG_FORCE_IDX64    0x4  /* 64-bit B offsets even when K*N*4 < 2^32 */
+#define GESPMM_FLAG_SHALLOW_UNROLL 0x10 /* gather 4 instead of 8 B rows per step (fewer VGPRs) */
+#define GESPMM_FLAG_ROW_PER_GROUP  0x8  /* first-generation CRC kernel (one row batch per wavefront);
+                                           kept for A/B measurements, same results */
 
 int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const float* val,
                             const float* B, float* C,

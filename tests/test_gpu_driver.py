@@ -1,0 +1,68 @@
+"""The spmm_test CLI driver (boundary #1) and the GCN example (the op's caller) on the GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from helpers import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+DRIVER = os.path.join(ROOT, "ge-spmm_amd", "lib", "spmm_test")
+
+
+def test_reference_command_line_and_csv(tmp_path):
+    """./spmm_test file.mtx [dev]: the reference's stdout lines, six '%f,' fields for
+    N=128,256,512 appended without a newline (run_test.sh adds name + newline)."""
+    out = tmp_path / "spmm_test_out.out"
+    r = subprocess.run([DRIVER, os.path.join(GOLDEN, "pubmed.mtx"), "0", "--iters", "20", "--seed", "1"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "reading file ..."
+    assert lines[1] == "read file ok. N=19717 nnz=88648"
+    assert lines[2] == "max_ncols = 512"
+    assert lines[3] == "running tests..."
+    text = out.read_text()
+    assert "\n" not in text
+    fields = text.rstrip(",").split(",")
+    assert len(fields) == 6
+    vals = [float(f) for f in fields]
+    assert vals[0] == vals[2] == vals[4] == 0.0, "vendor column not built"
+    assert all(v > 1.0 for v in vals[1::2]), "GE-SpMM GFLOP/s"
+    # appending: a second run adds six more fields to the same line
+    subprocess.run([DRIVER, os.path.join(GOLDEN, "cora.mtx"), "--iters", "5"], cwd=tmp_path, check=True,
+                   capture_output=True, timeout=300)
+    assert len(out.read_text().rstrip(",").split(",")) == 12
+
+
+def test_validate_all_variants_and_flags(tmp_path):
+    r = subprocess.run([DRIVER, os.path.join(GOLDEN, "citeseer.mtx"), "--validate", "--cpu-baseline", "--ncols",
+                        "32,100", "--method", "-1", "--iters", "5", "--seed", "7", "--use-values", "--out",
+                        str(tmp_path / "o.csv")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "WA" not in r.stdout, r.stdout
+    assert "validate done (6 variants, N=512)" in r.stdout
+    assert re.search(r"cpu golden loop: [0-9.]+ GFLOP/s", r.stdout)
+    assert re.search(r"N=32 method=-1", r.stdout) and re.search(r"N=100 method=-1", r.stdout)
+    assert len((tmp_path / "o.csv").read_text().rstrip(",").split(",")) == 4
+
+
+def test_error_exits(tmp_path):
+    r = subprocess.run([DRIVER, str(tmp_path / "missing.mtx")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "not found" in r.stdout  # util.hpp:300-303
+    r = subprocess.run([DRIVER, os.path.join(GOLDEN, "mtx", "bad_banner.mtx")], cwd=tmp_path, capture_output=True,
+                       text=True)
+    assert r.returncode == 1 and "Could not process Matrix Market banner." in r.stdout  # util.hpp:306-309
+    r = subprocess.run([DRIVER, os.path.join(GOLDEN, "cora.mtx"), "99"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0  # no such device: EXIT_FAILURE, never a CPU result
+
+
+def test_gcn_example_runs(tmp_path):
+    for extra in ([], ["--convs", "3"], ["--graph-capture"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "gcn_custom.py"), "--dataset", "cora",
+                            "--n-hidden", "32", "--epochs", "20"] + extra, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert re.search(r"gpu [0-9.]+ ms/epoch", r.stdout), r.stdout

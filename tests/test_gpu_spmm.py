@@ -90,6 +90,10 @@ def test_edge_shapes_every_width(pkg, oracle, seed):
         for variant in EXACT_VARIANTS:
             assert_bits_equal(run(pkg, G, B, None, variant), ref_u, "edge N=%d unweighted v%d" % (N, variant))
             assert_bits_equal(run(pkg, G, B, val, variant), ref_v, "edge N=%d valued v%d" % (N, variant))
+        for rpw in (1, 2, 3, 8, 21, 32):  # rows per wavefront of the streaming kernel, incl. > M
+            for variant in (1, 3, 4):
+                cfg = {"rows_per_wave": rpw}
+                assert_bits_equal(run(pkg, G, B, val, variant, cfg), ref_v, "edge N=%d rpw=%d v%d" % (N, rpw, variant))
 
 
 def test_explicit_geometries_and_flags(pkg, oracle, bundled):
@@ -103,12 +107,15 @@ def test_explicit_geometries_and_flags(pkg, oracle, bundled):
         B = oracle.hash_B(G["K"], N, seed=N)
         ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
         ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
+        all_flags = (0, _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_NT_STORE, _lib.FLAG_FORCE_IDX64, _lib.FLAG_ROW_PER_GROUP,
+                     _lib.FLAG_SHALLOW_UNROLL,
+                     _lib.FLAG_NT_STORE | _lib.FLAG_FORCE_IDX64 | _lib.FLAG_NO_XCD_REMAP | _lib.FLAG_SHALLOW_UNROLL)
         for vec in (1, 2, 4):
             for strips in (1, 2):
                 for group in (4, 8, 16, 32, 64):
-                    for flags in (0, _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_NT_STORE, _lib.FLAG_FORCE_IDX64,
-                                  _lib.FLAG_NT_STORE | _lib.FLAG_FORCE_IDX64 | _lib.FLAG_NO_XCD_REMAP):
-                        cfg = {"vec": vec, "strips": strips, "group": group, "flags": flags}
+                    for i, flags in enumerate(all_flags):
+                        rpw = (0, 1, 2, 4, 7, 16, 32)[(i + group + vec) % 7]
+                        cfg = {"vec": vec, "strips": strips, "group": group, "rows_per_wave": rpw, "flags": flags}
                         what = "N=%d cfg=%r" % (N, cfg)
                         assert_bits_equal(run(pkg, G, B, val, 3, cfg), ref_v, what)
                         assert_bits_equal(run(pkg, G, B, None, 1, cfg), ref_u, what)
