@@ -18,6 +18,11 @@ as exchange_ms; it is the path's only exchange step, there is no reduction). The
 region is K SpMM launches per rank on the resident operands; value = total FLOP of all
 ranks / max-over-ranks time.
 
+`--graph rmat --rmat-scale S --ncols 256` is the north_star's strong-scaling case: ONE
+RMAT graph (Graph500 parameters, S = 26 for the billion-edge run), nnz-balanced
+contiguous row shards generated rank-locally from a shared counter-based stream, full
+B on every rank; reported as "scaling": "strong".
+
 The JSON line also carries
   roofline      algorithmic bytes / average kernel duration measured
                 with HIP events on the launch stream, against 8 TB/s HBM;
@@ -48,7 +53,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ncols", type=int, default=128, help="feature width N of the headline measurement")
-    ap.add_argument("--graph", default="com-amazon-like")
+    ap.add_argument("--graph", default="com-amazon-like",
+                    help="named stand-in (weak scaling: one per rank) or 'rmat' (one fixed graph, strong scaling)")
+    ap.add_argument("--rmat-scale", type=int, default=22, help="log2(vertices) of the RMAT graph (north_star: 26)")
+    ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--locality", type=float, default=0.0, help="fraction of id-local edges in the stand-in")
     ap.add_argument("--no-extra", action="store_true", help="skip the N=32/512 and unweighted side measurements")
@@ -71,11 +79,18 @@ def main():
         raise SystemExit("bench.py needs a HIP device: there is no CPU path to measure")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # torchrun with 1 process still exercises RCCL
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     # ------------------------------------------------------------------ workload
-    g = graphs.synthetic_graph(args.graph, seed=42 + rank, device=dev, locality=args.locality)
+    strong = args.graph == "rmat"
+    if strong:
+        # ONE fixed graph, nnz-balanced contiguous row shards: the north_star's
+        # "row-partitioned billion-edge synthetic graph" (scale 26) at a selectable scale.
+        g = graphs.rmat_shard(args.rmat_scale, args.edge_factor, rank, world, seed=42, device=dev)
+    else:
+        g = graphs.synthetic_graph(args.graph, seed=42 + rank, device=dev, locality=args.locality)
     M, K, nnz = g["M"], g["K"], g["nnz"]
     rowptr, colind = g["rowptr"], g["colind"]
     gen = torch.Generator(device=dev)
@@ -95,7 +110,7 @@ def main():
 
     def get_B(N):
         nonlocal exchange_ms
-        if world == 1:
+        if not use_dist:
             return make_B(N)
         from gespmm_amd import dist as gdist
 
@@ -103,7 +118,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        B = gdist.broadcast_dense(B0, K, N, src=0, device=dev)
+        B = gdist.broadcast_dense(B0, K, N, src=0, device=dev)  # RCCL over xGMI: the path's only exchange
         torch.cuda.synchronize()
         dist.barrier()
         exchange_ms = (time.perf_counter() - t0) * 1e3
@@ -111,7 +126,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -139,7 +154,7 @@ def main():
         sync_all()
         wall = time.perf_counter() - t0
         kern_ms = e0.elapsed_time(e1) / steps
-        if world > 1:
+        if use_dist:
             t = torch.tensor([wall], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
@@ -153,20 +168,29 @@ def main():
         import oracle_py
 
         rng = np.random.RandomState(0)
-        rows = np.sort(rng.choice(M, 512, replace=False))
+        rows = np.sort(rng.choice(M, min(512, M), replace=False))
         rph, cih = rowptr.cpu().numpy(), colind.cpu().numpy()
         sub_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
         sub_ptr[1:] = np.cumsum(rph[rows + 1] - rph[rows])
         sel = np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows]).astype(np.int64)
         vh = val.cpu().numpy()[sel] if valued else None
-        ref = oracle_py.spmm(sub_ptr, cih[sel], vh, B.cpu().numpy(), "fma")
+        # only the B rows these CSR rows touch travel to the host (B can be tens of GB)
+        cols_u, inv = np.unique(cih[sel], return_inverse=True)
+        Bsub = B[torch.from_numpy(cols_u.astype(np.int64)).to(dev)].cpu().numpy()
+        ref = oracle_py.spmm(sub_ptr, inv.astype(np.int32), vh, Bsub, "fma")
         got = C[torch.from_numpy(rows).to(dev)].cpu().numpy()
         return bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
 
     # ------------------------------------------------------------------ headline
     N = args.ncols
     res = measure(N, True, args.steps, args.warmup, args.variant)
-    flop_per_step = 2.0 * nnz * N * world
+    if use_dist:  # total non-zeros over all ranks (shards differ in nnz for the RMAT graph)
+        tn = torch.tensor([nnz], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn)
+        nnz_total = int(tn.item())
+    else:
+        nnz_total = nnz
+    flop_per_step = 2.0 * nnz_total * N
     value = flop_per_step * args.steps / res["wall_s"] / 1e9
     ms_per_step = res["wall_s"] / args.steps * 1e3
     abytes = algorithmic_bytes(M, K, N, nnz, True)
@@ -181,7 +205,7 @@ def main():
         with open(pmc_path) as f:
             pm = json.load(f)
         key = "%s/N%d/valued" % (args.graph, N)
-        if key in pm and args.locality == 0.0:
+        if key in pm and args.locality == 0.0 and world == 1:
             traffic = pm[key]["bytes_per_launch"]
             traffic_note = pm[key].get("source")
 
@@ -237,17 +261,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s (M=K=%d, nnz=%d per GPU, symmetric, seed 42+rank, locality %.2f) x N=%d, valued CSR, "
-                            "variant %d" % (args.graph, M, nnz, args.locality, N, args.variant),
+                "workload": ("RMAT scale %d edge-factor %d (a,b,c,d = .57,.19,.19,.05), %d global nnz, nnz-balanced "
+                             "row shards x N=%d, valued CSR, variant %d" %
+                             (args.rmat_scale, args.edge_factor, nnz_total, N, args.variant)) if strong else
+                            ("%s (M=K=%d, nnz=%d per GPU, symmetric, seed 42+rank, locality %.2f) x N=%d, valued CSR, "
+                             "variant %d" % (args.graph, M, nnz, args.locality, N, args.variant)),
                 "rows_per_gpu": M,
                 "nnz_per_gpu": nnz,
                 "ncols": N,
-                "partition": "1-D rows, B replicated by one RCCL broadcast" if world > 1 else "single GPU",
+                "partition": ("1-D rows (%s), B replicated by one RCCL broadcast" %
+                              ("nnz-balanced shards of one graph" if strong else "one shard per rank"))
+                             if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -268,7 +297,7 @@ def main():
             "extra": extra,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -127,10 +127,13 @@ def main():
                                   dict(params=model.non_reg_params, weight_decay=0)], lr=0.01,
                                  capturable=args.graph_capture)
 
+    train_idx = masks["train"].nonzero().squeeze(1)  # index tensor: boolean masks sync (not capturable)
+    y_train = y[train_idx]
+
     def train_step():
         optimizer.zero_grad(set_to_none=False)
         out = model(x, g)
-        loss = F.nll_loss(out[masks["train"]], y[masks["train"]])
+        loss = F.nll_loss(out.index_select(0, train_idx), y_train)
         loss.backward()
         optimizer.step()
         return loss

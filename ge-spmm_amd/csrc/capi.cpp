@@ -73,14 +73,26 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.ntile = 0;
     a.flags = flags;
     a.empty = empty;
+    a.long_row = 0;
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
-    a.rpw = sel.geo.rows_per_wave;
+    a.rpw = sel.geo.rows_per_group;
     if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);
     else if (sel.variant == GESPMM_VARIANT_NAIVE || (flags & gespmm::kFlagRowPerGroup))
         e = gespmm::launch_spmm_rowgroup(a, sel.geo, st);
-    else e = gespmm::launch_spmm_stream(a, sel.geo, st);
+    else {
+        bool seg = sel.geo.segmented;
+        if (flags & gespmm::kFlagBatchStream) seg = false;
+        if ((flags & gespmm::kFlagSegStream) && !sel.geo.split_long_rows) seg = true;
+        if (seg) e = gespmm::launch_spmm_segstream(a, sel.geo, st);
+        else {
+            a.rpw = sel.geo.rows_per_wave;
+            a.long_row = sel.geo.split_long_rows ? sel.geo.long_row_threshold : 0;
+            e = gespmm::launch_spmm_stream(a, sel.geo, st);
+            if (e == hipSuccess && sel.geo.split_long_rows) e = gespmm::launch_spmm_longrows(a, sel.geo, st);
+        }
+    }
     return (int)e;
 }
 

@@ -80,7 +80,38 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         if (rpw < rows_in_flight) rpw = rows_in_flight;
         g.rows_per_wave = rpw;
     }
-    if (cfg_rows_per_wave) g.rows_per_wave = cfg_rows_per_wave;
+    // Rows per lane group of the segmented-stream kernel: ~64 CSR entries per group task
+    // (two 32-entry tiles), again keeping the grid several waves deep.
+    {
+        const int64_t avg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
+        int rpg = kMaxRowsPerWave;
+        while (rpg > 1 && (int64_t)rpg * avg > 64) rpg >>= 1;
+        while (rpg > 1 && M / ((int64_t)rpg * rows_in_flight) < 4 * 8192) rpg >>= 1;
+        g.rows_per_group = rpg;
+    }
+    if (cfg_rows_per_wave) {
+        g.rows_per_wave = cfg_rows_per_wave;
+        g.rows_per_group = cfg_rows_per_wave;
+    }
+    // Kernel generation. Wide groups (W >= 32: one or two rows per wavefront) run the
+    // segmented-stream kernel; with many narrow groups per wavefront its per-entry row
+    // flushes diverge between groups and the batch kernel (rows in lock-step, one store
+    // phase per batch) is faster — measured in profiles/r01/kernel_generations.log.
+    const int64_t avg_deg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
+    g.split_long_rows = ((flags & kFlagSplitLongRows) != 0 || nnz >= kLongRowMinNnz) && (flags & kFlagStrictOrder) == 0 &&
+                        variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
+    // A row is "long" when it dwarfs the average wavefront's work: 32x the mean degree,
+    // at least kLongRowThreshold entries (reddit-like graphs, mean degree ~500, keep
+    // their many 2k..15k-entry rows on the main kernel, which is faster on them).
+    {
+        int64_t thr = 32 * avg_deg;
+        if (thr < kLongRowThreshold) thr = kLongRowThreshold;
+        if (thr > 0x3fffffff) thr = 0x3fffffff;
+        g.long_row_threshold = (int)thr;
+    }
+    // The segmented kernel pays off for short rows only; long rows (and the long-row
+    // split, which the batch kernel implements) go to the batch kernel.
+    g.segmented = g.group >= 32 && avg_deg <= 12 && !g.split_long_rows;
     out->variant = variant;
     out->geo = g;
     return 0;

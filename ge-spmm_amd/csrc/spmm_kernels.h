@@ -18,6 +18,13 @@ constexpr int kFlagNoXcdRemap = 0x1;  // == GESPMM_FLAG_NO_XCD_REMAP
 constexpr int kFlagNtStore = 0x2;     // == GESPMM_FLAG_NT_STORE
 constexpr int kFlagForceIdx64 = 0x4;  // == GESPMM_FLAG_FORCE_IDX64
 constexpr int kFlagShallowUnroll = 0x10; // == GESPMM_FLAG_SHALLOW_UNROLL
+constexpr int kFlagCachedCsr = 0x40;     // == GESPMM_FLAG_CACHED_CSR
+constexpr int kFlagBatchStream = 0x20;   // == GESPMM_FLAG_BATCH_STREAM (force the batch-stream kernel)
+constexpr int kFlagStrictOrder = 0x100;  // == GESPMM_FLAG_STRICT_ORDER (never split long rows)
+constexpr int kFlagSplitLongRows = 0x200; // == GESPMM_FLAG_SPLIT_LONG_ROWS (always run the long-row pass)
+constexpr int kLongRowThreshold = 2048;  // entries; lower bound of the long-row threshold (32 x mean degree)
+constexpr int64_t kLongRowMinNnz = 1 << 23;  // auto: only matrices this large get the long-row pass
+constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
 constexpr int kFlagRowPerGroup = 0x8; // == GESPMM_FLAG_ROW_PER_GROUP (first-generation CRC kernel)
 
 struct SpmmArgs {
@@ -32,6 +39,7 @@ struct SpmmArgs {
     int32_t ntile;  // column tiles (filled in by the launcher)
     int32_t flags;
     int32_t rpw;    // streaming kernel: rows per wavefront (filled in by the launcher)
+    int32_t long_row;  // > 0: rows with more entries are skipped by the main kernel (long-row kernel does them)
     float empty;    // max reducer: value of rows without non-zeros / initial accumulator
 };
 
@@ -40,14 +48,20 @@ struct Geometry {
     int vec;      // V: floats per lane per strip (1, 2, 4)
     int strips;   // S: strips per lane (1, 2)
     int group;    // W: lanes per row (4..64)
-    int rows_per_wave;  // streaming kernel: consecutive rows owned by one wavefront
+    int rows_per_wave;  // batch-stream kernel: consecutive rows owned by one wavefront
+    int rows_per_group; // segmented-stream kernel: consecutive rows owned by one lane group
     bool crc;     // LDS-staged CSR tiles (variants 1-4) vs naive (variant 0)
     bool idx64;   // 64-bit byte offsets into B
+    bool segmented;  // segmented-stream kernel (else batch-stream)
+    bool split_long_rows;  // run the long-row pass
+    int long_row_threshold;  // rows with more entries than this go to the long-row pass
     int reduce;   // kReduceSum / kReduceMax
 };
 
 hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
 // sddmm_kernels.hip

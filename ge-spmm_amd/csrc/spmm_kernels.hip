@@ -94,6 +94,14 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// CSR stream loads. Non-temporal by default (each entry is used once per launch); the
+// plain form keeps them in L2 / Infinity Cache across launches (GESPMM_FLAG_CACHED_CSR).
+template <typename T>
+__device__ __forceinline__ T load_csr(const T* p, bool cached) {
+    return cached ? *p : __builtin_nontemporal_load(p);
+}
+
 template <int RED, bool VALUED>
 __device__ __forceinline__ float combine(float acc, float a, float b) {
     if constexpr (RED == kReduceMax) {
@@ -329,11 +337,12 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
     // Tile stream state: `t0` = CSR position of the tile resident in LDS.
     int pc = 0;
     float pv = 0.0f;
+    const bool cached_csr = (a.flags & kFlagCachedCsr) != 0;
     auto fetch_tile_regs = [&](int base) {
         const int p = base + lane;
         if (p < we) {
-            pc = __builtin_nontemporal_load(a.colind + p);
-            if constexpr (VALUED) pv = __builtin_nontemporal_load(a.val + p);
+            pc = load_csr(a.colind + p, cached_csr);
+            if constexpr (VALUED) pv = load_csr(a.val + p, cached_csr);
         }
     };
     auto publish_tile = [&]() {
@@ -350,9 +359,14 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         const int r = b + g;
         const bool rowok = r < nrows;
         int lb = 0, hb = 0;
+        bool rowok2 = rowok;
         if (rowok) {
             lb = s_ptr[wave][r];
             hb = s_ptr[wave][r + 1];
+            if (a.long_row > 0 && hb - lb > a.long_row) {  // left to spmm_longrow_kernel
+                hb = lb;
+                rowok2 = false;
+            }
         }
         const int be = __builtin_amdgcn_readfirstlane(s_ptr[wave][(b + G < nrows) ? b + G : nrows]);
         if constexpr (G == 1) {
@@ -370,16 +384,39 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
             const int tend = t0 + kTile;
             int k = (lb > t0 ? lb : t0) - t0;
             const int ke = (hb < tend ? hb : tend) - t0;
-            // U entries per step, every slot under one predicate: full steps and the tail
-            // share ONE register set, and a row of <= U non-zeros is a single round trip.
-            for (; k < ke; k += U) {
-                const int cnt = ke - k;
+            // Full steps: U gathers issued back to back, no predicates.
+            for (; k + U <= ke; k += U) {
                 off_t off[U];
                 float v[U];
                 float bv[U][S][V];
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
-                    if (j < cnt) {
+                    off[j] = s_off[wave][k + j];
+                    if constexpr (VALUED) v[j] = s_val[wave][k + j];
+                    else v[j] = 1.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+#pragma unroll
+                for (int j = 0; j < U; ++j)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+            }
+            // Tail (1..U-1 entries): ONE predicated group, so a short row is a single round
+            // trip. It is not inside a loop, so there is no loop-carried register hazard and
+            // the compiler keeps the predicated loads in flight together.
+            const int rem = ke - k;
+            if (rem > 0) {
+                off_t off[U - 1];
+                float v[U - 1];
+                float bv[U - 1][S][V];
+#pragma unroll
+                for (int j = 0; j < U - 1; ++j) {
+                    if (j < rem) {
                         off[j] = s_off[wave][k + j];
                         if constexpr (VALUED) v[j] = s_val[wave][k + j];
                         else v[j] = 1.0f;
@@ -388,8 +425,8 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    if (j < cnt) {
+                for (int j = 0; j < U - 1; ++j) {
+                    if (j < rem) {
 #pragma unroll
                         for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -406,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
             wave_lds_sync();
         }
 
-        if (rowok) {
+        if (rowok2) {
             float* Crow = a.C + (size_t)(row_first + r) * (size_t)a.N + col0;
             const bool nts = (a.flags & kFlagNtStore) != 0;
 #pragma unroll
@@ -416,6 +453,351 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
                     else store_vec<V, false>(Crow + s * (W * V), acc[s]);
                 }
         }
+    }
+}
+
+
+// ----------------------------------------------------------------------------- segmented-stream kernel
+//
+// Every W-lane group owns `rpg` CONSECUTIVE rows, i.e. one contiguous CSR range
+// [gb, ge), and treats it as ONE stream: U entries per step are gathered back to
+// back no matter where the row boundaries fall, then consumed in CSR order; whenever
+// the position passes the end of the current row the accumulator is flushed to C
+// (also for empty rows) and restarted. The per-element sum is still one fp32 chain
+// in ascending CSR position, so results are bit-identical to the other variants —
+// but a graph of 5-nnz rows keeps 8 B-row loads in flight per group continuously
+// instead of draining the memory pipeline at every row batch.
+//
+// CRC staging is per group: the group's lanes load T = max(W, 32) entries per refill
+// (E = T/W consecutive entries per lane), next tile prefetched in registers.
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED, int U>
+__global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
+    constexpr int G = 64 / W;
+    constexpr int T = (W > 32) ? W : 32;  // entries per group tile
+    constexpr int E = T / W;              // entries each lane stages per refill
+    static_assert(T % U == 0, "tile must hold whole steps");
+    using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
+
+    __shared__ off_t s_off[kWaves][G][T];
+    __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? G : 1][VALUED ? T : 1];
+    __shared__ int s_ptr[kWaves][G][kMaxRowsPerWave + 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / W;
+    const int l = lane % W;
+
+    const int nitems = a.nblk * a.ntile;
+    const int item = (a.flags & kFlagNoXcdRemap) ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, nitems);
+    int tile = 0, rb = item;
+    if (a.ntile > 1) {
+        tile = item % a.ntile;
+        rb = item / a.ntile;
+    }
+    const int rpg = a.rpw;  // rows per GROUP in this kernel
+    const int task_first = ((rb * kWaves + wave) * G + g) * rpg;
+    if (((rb * kWaves + wave) * G) * rpg >= a.M) return;  // whole wavefront past the end
+    int nrows = a.M - task_first;                          // rows of this group's task
+    nrows = nrows < 0 ? 0 : (nrows > rpg ? rpg : nrows);
+
+    // Row pointers of the task -> LDS (rpg <= 32; lanes of a group cover 0..rpg by striding W).
+    int gb = 0, ge = 0;
+    if (nrows > 0) {
+        for (int i = l; i <= nrows; i += W) s_ptr[wave][g][i] = a.rowptr[task_first + i];
+    }
+    wave_lds_sync();
+    if (nrows > 0) {
+        gb = s_ptr[wave][g][0];
+        ge = s_ptr[wave][g][nrows];
+    }
+
+    const int col0 = tile * (W * V * S) + l * V;
+    bool colok[S];
+    off_t cbytes[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        colok[s] = (col0 + s * W * V) < a.N;
+        cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
+    }
+    const char* Bbase = reinterpret_cast<const char*>(a.B);
+    const off_t rowbytes = (off_t)a.N * 4u;
+    const float init = (RED == kReduceMax) ? a.empty : 0.0f;
+    const bool nts = (a.flags & kFlagNtStore) != 0;
+
+    const bool cached_csr = (a.flags & kFlagCachedCsr) != 0;
+    // Per-group tile stream.
+    int pc[E];
+    float pv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        pc[e] = 0;
+        pv[e] = 0.0f;
+    }
+    auto fetch_tile_regs = [&](int base) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int p = base + l * E + e;
+            if (p < ge) {
+                pc[e] = load_csr(a.colind + p, cached_csr);
+                if constexpr (VALUED) pv[e] = load_csr(a.val + p, cached_csr);
+            }
+        }
+    };
+    auto publish_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            s_off[wave][g][l * E + e] = (off_t)(uint32_t)pc[e] * rowbytes;
+            if constexpr (VALUED) s_val[wave][g][l * E + e] = pv[e];
+        }
+    };
+
+    int tbase = gb;  // CSR position of the group's resident tile
+    fetch_tile_regs(tbase);
+    publish_tile();
+    fetch_tile_regs(tbase + T);
+    wave_lds_sync();
+
+    float acc[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[s][i] = init;
+    int cur = 0;                                       // current row of the task
+    int rend = (nrows > 0) ? s_ptr[wave][g][1] : 0;    // CSR end of the current row
+    float* Crow = a.C + (size_t)task_first * (size_t)a.N + col0;
+
+    auto flush_row = [&]() {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (colok[s]) {
+                if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                else store_vec<V, false>(Crow + s * (W * V), acc[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[s][i] = init;
+        }
+        Crow += a.N;
+        ++cur;
+        rend = s_ptr[wave][g][(cur + 1 <= nrows) ? cur + 1 : nrows];
+    };
+
+    for (int k = gb; k < ge; k += U) {
+        if (k >= tbase + T) {  // group-uniform: the step crosses into the next tile
+            tbase += T;
+            publish_tile();
+            fetch_tile_regs(tbase + T);
+            wave_lds_sync();
+        }
+        const int cnt = ge - k;
+        const int t = k - tbase;
+        off_t off[U];
+        float v[U];
+        float bv[U][S][V];
+        // Straight-line issue of all U gathers: slots past the end of the stream re-read the
+        // last valid entry (same cache line, no extra memory traffic) instead of being
+        // branched around — control flow around the loads makes the compiler serialise
+        // them with s_waitcnt vmcnt(0). Predicates apply only when the values are consumed.
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int tj = t + ((j < cnt) ? j : cnt - 1);
+            off[j] = s_off[wave][g][tj];
+            if constexpr (VALUED) v[j] = s_val[wave][g][tj];
+            else v[j] = 1.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+        }
+        if (cnt >= U && k + U <= rend) {
+            // every entry of the step belongs to the current row (rend = its CSR end and the
+            // previous entry already did): long rows run without boundary checks
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (j < cnt) {
+                    while (k + j >= rend) flush_row();  // rows ending before this entry (incl. empty ones)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+                }
+            }
+        }
+        wave_lds_sync();  // reads of this step precede a possible tile publish of the next step
+    }
+    while (cur < nrows) flush_row();  // last row and any trailing empty rows
+}
+
+
+// ----------------------------------------------------------------------------- long-row kernel
+//
+// Load balance for skewed graphs (RMAT hubs, reddit): a row of 10^5..10^6 non-zeros
+// walked by ONE lane group is a serial chain that outlasts the rest of the launch.
+// Rows longer than `long_row` entries are therefore skipped by the main kernel and
+// done here by a whole workgroup: the NG = 4*G lane groups of the workgroup take the
+// row's 64-entry tiles round-robin (group q: tiles q, q+NG, ...), each keeps ONE
+// accumulator chain over its tiles in ascending order, and the NG partial rows are
+// added in fixed order q = 0..NG-1 through LDS. The result does not depend on
+// scheduling (bit-reproducible run to run) but is a re-association of the strict
+// CSR-order sum, so these rows are checked to north_star's 1e-4 tolerance instead
+// of bit-for-bit. GESPMM_FLAG_STRICT_ORDER turns the split off.
+//
+// No list of long rows is built: every workgroup scans its own slice of rowptr
+// (coalesced, 256 rows per pass) and serves the long rows it finds.
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
+__global__ __launch_bounds__(kThreads) void spmm_longrow_kernel(SpmmArgs a) {
+    constexpr int G = 64 / W;
+    constexpr int NG = kWaves * G;
+    constexpr int T = 64;               // entries per tile (all 64 lanes of the wavefront load one tile per group round)
+    constexpr int U = (V * S >= 8) ? 4 : 8;
+    using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
+
+    __shared__ off_t s_off[kWaves][G][T];
+    __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? G : 1][VALUED ? T : 1];
+    __shared__ float s_part[NG][W * V * S];
+    __shared__ int s_rows[kThreads];
+    __shared__ int s_nrows;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane / W;
+    const int l = lane % W;
+    const int q = wave * G + g;  // group id inside the workgroup
+
+    const int rows_per_block = (a.M + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int slice_begin = (int)blockIdx.x * rows_per_block;
+    const int slice_end = (slice_begin + rows_per_block < a.M) ? slice_begin + rows_per_block : a.M;
+    const char* Bbase = reinterpret_cast<const char*>(a.B);
+    const off_t rowbytes = (off_t)a.N * 4u;
+    const float init = (RED == kReduceMax) ? a.empty : 0.0f;
+    const int ntile = (a.N + W * V * S - 1) / (W * V * S);
+
+    for (int base = slice_begin; base < slice_end; base += kThreads) {
+        // ---- find the long rows among rows [base, base+256): ascending row order
+        if (tid == 0) s_nrows = 0;
+        __syncthreads();
+        const int row = base + tid;
+        bool is_long = false;
+        if (row < slice_end) is_long = (a.rowptr[row + 1] - a.rowptr[row]) > a.long_row;
+        const unsigned long long m = __ballot(is_long);
+        __shared__ int s_wcount[kWaves];
+        if (lane == 0) s_wcount[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_wcount[w];
+        if (is_long) s_rows[woff + __popcll(m & ((1ull << lane) - 1ull))] = row;
+        if (tid == 0) s_nrows = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        __syncthreads();
+        const int nlong = s_nrows;
+
+        for (int i = 0; i < nlong; ++i) {
+            const int r = s_rows[i];
+            const int lb = a.rowptr[r];
+            const int hb = a.rowptr[r + 1];
+            const int ntiles_row = (hb - lb + T - 1) / T;
+            for (int ct = 0; ct < ntile; ++ct) {
+                const int col0 = ct * (W * V * S) + l * V;
+                bool colok[S];
+                off_t cbytes[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    colok[s] = (col0 + s * W * V) < a.N;
+                    cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
+                }
+                float acc[S][V];
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int k2 = 0; k2 < V; ++k2) acc[s][k2] = init;
+
+                // group q walks tiles q, q+NG, ... ; the W lanes of the group stage T/W entries each
+                constexpr int E = T / W;
+                int pc[E];
+                float pv[E];
+                auto fetch = [&](int t) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int p = lb + t * T + l * E + e;
+                        pc[e] = 0;
+                        pv[e] = 0.0f;
+                        if (t < ntiles_row && p < hb) {
+                            pc[e] = a.colind[p];
+                            if constexpr (VALUED) pv[e] = a.val[p];
+                        }
+                    }
+                };
+                fetch(q);
+                for (int t = q; t < ntiles_row; t += NG) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        s_off[wave][g][l * E + e] = (off_t)(uint32_t)pc[e] * rowbytes;
+                        if constexpr (VALUED) s_val[wave][g][l * E + e] = pv[e];
+                    }
+                    fetch(t + NG);
+                    wave_lds_sync();
+                    const int cnt_tile = (hb - (lb + t * T) < T) ? hb - (lb + t * T) : T;
+                    for (int k = 0; k < cnt_tile; k += U) {
+                        const int cnt = cnt_tile - k;
+                        off_t off[U];
+                        float v[U];
+                        float bv[U][S][V];
+#pragma unroll
+                        for (int j = 0; j < U; ++j) {
+                            const int kj = k + ((j < cnt) ? j : cnt - 1);
+                            off[j] = s_off[wave][g][kj];
+                            if constexpr (VALUED) v[j] = s_val[wave][g][kj];
+                            else v[j] = 1.0f;
+#pragma unroll
+                            for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+                        }
+#pragma unroll
+                        for (int j = 0; j < U; ++j) {
+                            if (j < cnt) {
+#pragma unroll
+                                for (int s = 0; s < S; ++s)
+#pragma unroll
+                                    for (int k2 = 0; k2 < V; ++k2)
+                                        acc[s][k2] = combine<RED, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                }
+                // ---- fixed-order combine of the NG partial rows
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int k2 = 0; k2 < V; ++k2) s_part[q][(s * W + l) * V + k2] = acc[s][k2];
+                __syncthreads();
+                if (q == 0) {
+                    float* Crow = a.C + (size_t)r * (size_t)a.N + col0;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        float outv[V];
+#pragma unroll
+                        for (int k2 = 0; k2 < V; ++k2) {
+                            float t2 = s_part[0][(s * W + l) * V + k2];
+                            for (int qq = 1; qq < NG; ++qq) {
+                                const float pq = s_part[qq][(s * W + l) * V + k2];
+                                if constexpr (RED == kReduceMax) t2 = fmaxf(t2, pq);
+                                else t2 = t2 + pq;
+                            }
+                            outv[k2] = t2;
+                        }
+                        if (colok[s]) store_vec<V, false>(Crow + s * (W * V), outv);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -596,6 +978,123 @@ hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_
     }
     if (valued) return geo.idx64 ? stream_vs<true, true, kReduceSum>(a, geo, st) : stream_vs<true, false, kReduceSum>(a, geo, st);
     return geo.idx64 ? stream_vs<false, true, kReduceSum>(a, geo, st) : stream_vs<false, false, kReduceSum>(a, geo, st);
+}
+
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
+static hipError_t launch_segstream(const SpmmArgs& a, int rpg, hipStream_t st) {
+    constexpr int G = 64 / W;
+    SpmmArgs args = a;
+    if (rpg < 1) rpg = 1;
+    if (rpg > kMaxRowsPerWave) rpg = kMaxRowsPerWave;
+    args.rpw = rpg;
+    args.nblk = (int)(((int64_t)a.M + (int64_t)kWaves * G * rpg - 1) / ((int64_t)kWaves * G * rpg));
+    args.ntile = (a.N + W * V * S - 1) / (W * V * S);
+    const int64_t nitems = (int64_t)args.nblk * args.ntile;
+    if (nitems <= 0) return hipSuccess;
+    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    if constexpr (V * S >= 8) {
+        hipLaunchKernelGGL((spmm_segstream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
+                           dim3(kThreads), 0, st, args);
+    } else {
+        if (a.flags & kFlagShallowUnroll)
+            hipLaunchKernelGGL((spmm_segstream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
+                               dim3(kThreads), 0, st, args);
+        else
+            hipLaunchKernelGGL((spmm_segstream_kernel<V, S, W, VALUED, IDX64, RED, 8>), dim3((unsigned)nitems),
+                               dim3(kThreads), 0, st, args);
+    }
+    return hipGetLastError();
+}
+
+template <int V, int S, bool VALUED, bool IDX64, int RED>
+static hipError_t segstream_w(const SpmmArgs& a, int W, int rpg, hipStream_t st) {
+    switch (W) {
+        case 4: return launch_segstream<V, S, 4, VALUED, IDX64, RED>(a, rpg, st);
+        case 8: return launch_segstream<V, S, 8, VALUED, IDX64, RED>(a, rpg, st);
+        case 16: return launch_segstream<V, S, 16, VALUED, IDX64, RED>(a, rpg, st);
+        case 32: return launch_segstream<V, S, 32, VALUED, IDX64, RED>(a, rpg, st);
+        case 64: return launch_segstream<V, S, 64, VALUED, IDX64, RED>(a, rpg, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <bool VALUED, bool IDX64, int RED>
+static hipError_t segstream_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
+    if (g.strips == 2) {
+        if (g.vec == 4) return segstream_w<4, 2, VALUED, IDX64, RED>(a, g.group, g.rows_per_group, st);
+        return hipErrorInvalidValue;
+    }
+    switch (g.vec) {
+        case 1: return segstream_w<1, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_group, st);
+        case 2: return segstream_w<2, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_group, st);
+        case 4: return segstream_w<4, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_group, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+    const bool valued = a.val != nullptr;
+    if (geo.reduce == kReduceMax) {
+        if (valued) return hipErrorInvalidValue;
+        return geo.idx64 ? segstream_vs<false, true, kReduceMax>(a, geo, st)
+                         : segstream_vs<false, false, kReduceMax>(a, geo, st);
+    }
+    if (valued)
+        return geo.idx64 ? segstream_vs<true, true, kReduceSum>(a, geo, st)
+                         : segstream_vs<true, false, kReduceSum>(a, geo, st);
+    return geo.idx64 ? segstream_vs<false, true, kReduceSum>(a, geo, st)
+                     : segstream_vs<false, false, kReduceSum>(a, geo, st);
+}
+
+
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
+static hipError_t launch_longrow(const SpmmArgs& a, hipStream_t st) {
+    SpmmArgs args = a;
+    // One workgroup per 4096-row slice, capped at 4 workgroups per CU: the scan is a
+    // few MB of rowptr and the long rows are spread by whatever id order the graph has.
+    int64_t blocks = ((int64_t)a.M + 4095) / 4096;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((spmm_longrow_kernel<V, S, W, VALUED, IDX64, RED>), dim3((unsigned)blocks), dim3(kThreads), 0,
+                       st, args);
+    return hipGetLastError();
+}
+
+template <int V, int S, bool VALUED, bool IDX64, int RED>
+static hipError_t longrow_w(const SpmmArgs& a, int W, hipStream_t st) {
+    switch (W) {
+        case 4: return launch_longrow<V, S, 4, VALUED, IDX64, RED>(a, st);
+        case 8: return launch_longrow<V, S, 8, VALUED, IDX64, RED>(a, st);
+        case 16: return launch_longrow<V, S, 16, VALUED, IDX64, RED>(a, st);
+        case 32: return launch_longrow<V, S, 32, VALUED, IDX64, RED>(a, st);
+        case 64: return launch_longrow<V, S, 64, VALUED, IDX64, RED>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <bool VALUED, bool IDX64, int RED>
+static hipError_t longrow_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
+    if (g.strips == 2) {
+        if (g.vec == 4) return longrow_w<4, 2, VALUED, IDX64, RED>(a, g.group, st);
+        return hipErrorInvalidValue;
+    }
+    switch (g.vec) {
+        case 1: return longrow_w<1, 1, VALUED, IDX64, RED>(a, g.group, st);
+        case 2: return longrow_w<2, 1, VALUED, IDX64, RED>(a, g.group, st);
+        case 4: return longrow_w<4, 1, VALUED, IDX64, RED>(a, g.group, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+    const bool valued = a.val != nullptr;
+    if (geo.reduce == kReduceMax) {
+        if (valued) return hipErrorInvalidValue;
+        return geo.idx64 ? longrow_vs<false, true, kReduceMax>(a, geo, st) : longrow_vs<false, false, kReduceMax>(a, geo, st);
+    }
+    if (valued) return geo.idx64 ? longrow_vs<true, true, kReduceSum>(a, geo, st) : longrow_vs<true, false, kReduceSum>(a, geo, st);
+    return geo.idx64 ? longrow_vs<false, true, kReduceSum>(a, geo, st) : longrow_vs<false, false, kReduceSum>(a, geo, st);
 }
 
 template <int W, bool VALUED, bool IDX64>

@@ -245,3 +245,89 @@ def reference_B(K, N, seed=1, device="cpu"):
     gen.manual_seed(int(seed))
     r = torch.randint(0, 100, (K, N), generator=gen, dtype=torch.int32)
     return ((r - 50).to(torch.float32) / 100).to(device)
+
+
+# ----------------------------------------------------------------------------- RMAT (Graph500 Kronecker)
+
+def _vertex_scramble(v, scale, seed):
+    """Bijection on [0, 2^scale): odd multiplier, xor-shift, odd multiplier (all mod 2^scale).
+    Spreads the RMAT hubs over the id range so contiguous row shards carry equal work."""
+    mask = (1 << scale) - 1
+    m1 = (0x9E3779B97F4A7C15 * (2 * seed + 1)) & mask | 1
+    m2 = (0xBF58476D1CE4E5B9 * (2 * seed + 3)) & mask | 1
+    sh = max(scale // 2, 1)
+    v = (v * m1) & mask
+    v = v ^ (v >> sh)
+    v = (v * m2) & mask
+    return v
+
+
+def _rmat_chunk(scale, n, a, b, c, seed, chunk, device):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed) * 1000003 + chunk)
+    rows = torch.zeros(n, dtype=torch.int64, device=device)
+    cols = torch.zeros(n, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        u = torch.rand(n, generator=gen, device=device)
+        rbit = (u >= a + b).to(torch.int64)
+        cbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)
+        rows = rows * 2 + rbit
+        cols = cols * 2 + cbit
+    return _vertex_scramble(rows, scale, seed), _vertex_scramble(cols, scale, seed)
+
+
+def rmat_shard(scale, edge_factor=16, rank=0, world=1, seed=42, device="cpu", probs=(0.57, 0.19, 0.19, 0.05),
+               chunk_edges=1 << 25, balanced=True):
+    """One contiguous row range of an RMAT graph with M = 2^scale vertices and
+    edge_factor*M directed edges (Graph500 parameters by default), as a CSR shard whose
+    column indices address the full M columns.
+
+    Every rank generates the same global edge stream chunk by chunk from a seeded
+    counter (chunk index -> generator seed) and keeps its own rows, so the shards are
+    consistent without any communication. With ``balanced`` a first pass over the
+    stream histograms the row degrees and the row ranges are the nnz-balanced cuts
+    (same rule as gespmm_row_partition); otherwise rows are split evenly. Duplicate
+    edges are kept (a general CSR may repeat a column), so the global nnz is exactly
+    edge_factor * 2^scale.
+    Returns dict(M, K, nnz, rowptr, colind, row_begin, row_end, global_nnz)."""
+    device = torch.device(device)
+    M = 1 << scale
+    total = edge_factor * M
+    a, b, c, _ = probs
+    nchunks = (total + chunk_edges - 1) // chunk_edges
+    sizes = [min(chunk_edges, total - i * chunk_edges) for i in range(nchunks)]
+    if balanced and world > 1:
+        deg = torch.zeros(M, dtype=torch.int64, device=device)
+        for ch, n in enumerate(sizes):
+            rows, _ = _rmat_chunk(scale, n, a, b, c, seed, ch, device)
+            deg += torch.bincount(rows, minlength=M)
+        cum = torch.cumsum(deg, 0)  # cum[r] = rowptr[r+1]
+        del deg
+        targets = torch.tensor([(total * p) // world for p in range(1, world)], dtype=torch.int64, device=device)
+        # first row r with rowptr[r] >= target  <=>  first r with cum[r-1] >= target
+        inner = (torch.searchsorted(cum, targets, right=False) + 1).clamp(max=M).tolist()
+        cuts = [0] + inner + [M]
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+        del cum
+    else:
+        cuts = [(M * p) // world for p in range(world + 1)]
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    keep_r, keep_c = [], []
+    for ch, n in enumerate(sizes):
+        rows, cols = _rmat_chunk(scale, n, a, b, c, seed, ch, device)
+        sel = (rows >= r0) & (rows < r1)
+        keep_r.append(rows[sel] - r0)
+        keep_c.append(cols[sel])
+    r = torch.cat(keep_r)
+    cc = torch.cat(keep_c)
+    del keep_r, keep_c
+    order = torch.argsort(r * M + cc)
+    r = r[order]
+    cc = cc[order].to(torch.int32)
+    nloc = r1 - r0
+    rowptr = torch.zeros(nloc + 1, dtype=torch.int64, device=device)
+    if nloc > 0:
+        rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=nloc), 0)
+    return {"M": nloc, "K": M, "nnz": int(cc.numel()), "rowptr": rowptr.to(torch.int32), "colind": cc,
+            "row_begin": r0, "row_end": r1, "global_nnz": total, "cuts": cuts}

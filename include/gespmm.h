@@ -65,6 +65,13 @@ extern "C" {
  * CSR position with one fused multiply-add per non-zero (the arithmetic the
  * reference's device kernels perform); they are bit-identical to each other.
  * Variant 5 changes the summation order and is tolerance-checked.
+ *
+ * Load balance: in matrices with >= 2^23 non-zeros, rows longer than
+ * max(2048, 32 x mean degree) entries (RMAT hubs) are computed by a whole workgroup as 64-entry tiles dealt
+ * round-robin to its lane groups, with the partial rows added in a fixed order —
+ * bit-reproducible from run to run, but a re-association of the strict chain
+ * (within the 1e-4 tolerance, not bit-for-bit). GESPMM_FLAG_STRICT_ORDER (through
+ * gespmm_csr_spmm_f32_cfg) keeps every row a strict chain.
  */
 #define GESPMM_VARIANT_AUTO       (-1)
 #define GESPMM_VARIANT_NAIVE        0
@@ -109,8 +116,8 @@ int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N);
  *   strips   strips per lane (1 or 2); coarsening factor = vec * strips
  *   group    lanes cooperating on one row (4..64, power of two); a 64-lane
  *            wavefront therefore carries 64/group rows
- *   rows_per_wave  consecutive rows one wavefront streams through (1..32; rounded to a
- *            multiple of 64/group)
+ *   rows_per_wave  consecutive rows one lane group streams through (1..32). With
+ *            GESPMM_FLAG_BATCH_STREAM: rows per wavefront (rounded to a multiple of 64/group)
  *   flags    GESPMM_FLAG_* bits
  */
 typedef struct gespmm_launch_cfg {
@@ -125,6 +132,11 @@ typedef struct gespmm_launch_cfg {
 #define GESPMM_FLAG_NT_STORE       0x2  /* non-temporal stores of C */
 #define GESPMM_FLAG_FORCE_IDX64    0x4  /* 64-bit B offsets even when K*N*4 < 2^32 */
 #define GESPMM_FLAG_SHALLOW_UNROLL 0x10 /* gather 4 instead of 8 B rows per step (fewer VGPRs) */
+#define GESPMM_FLAG_CACHED_CSR     0x40 /* plain (cacheable) loads of colind/val instead of non-temporal */
+#define GESPMM_FLAG_BATCH_STREAM   0x20 /* force the batch-stream kernel (rows walked 64/group at a time) */
+#define GESPMM_FLAG_STRICT_ORDER   0x100 /* never split long rows: every row is one strict CSR-order chain */
+#define GESPMM_FLAG_SPLIT_LONG_ROWS 0x200 /* run the long-row pass regardless of matrix size */
+#define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (default for group >= 32) */
 #define GESPMM_FLAG_ROW_PER_GROUP  0x8  /* first-generation CRC kernel (one row batch per wavefront);
                                            kept for A/B measurements, same results */
 

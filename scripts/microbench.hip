@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void k_row_gather(const float* __restrict__ B,
             acc = (f4){0, 0, 0, 0};
         }
     }
+    for (; k < ke; ++k) acc += *(const f4*)(B + (size_t)idx[k] * rowfloats + lane * 4);  // leftover rows
     if (acc.x == 12345.678f) C[0] = acc.x;
 }
 

@@ -86,18 +86,21 @@ def main():
                     base = {"vec": vec, "strips": strips, "group": grp}
                     cands.append(("V%d S%d W%d old" % (vec, strips, grp), 1,
                                   dict(base, flags=_lib.FLAG_ROW_PER_GROUP)))
-                    for rpw in sorted({G, 2 * G, 4, 8, 16, 32}):
+                    for rpw in sorted({G, 8, 16}):  # batch-stream kernel (rows per wavefront)
                         if rpw < G or rpw > 32:
                             continue
+                        cands.append(("V%d S%d W%d bs r%d" % (vec, strips, grp, rpw), 1,
+                                      dict(base, rows_per_wave=rpw, flags=_lib.FLAG_BATCH_STREAM)))
+                    for rpg in (1, 2, 4, 8, 16, 32):  # segmented-stream kernel (rows per lane group)
                         for fl, tag in ((0, ""), (_lib.FLAG_SHALLOW_UNROLL, " u4")):
                             if strips == 2 and fl:
                                 continue
-                            cands.append(("V%d S%d W%d r%d%s" % (vec, strips, grp, rpw, tag), 1,
-                                          dict(base, rows_per_wave=rpw, flags=fl)))
+                            cands.append(("V%d S%d W%d seg g%d%s" % (vec, strips, grp, rpg, tag), 1,
+                                          dict(base, rows_per_wave=rpg, flags=fl)))
                     if not args.quick:
                         for fl, tag in ((_lib.FLAG_NT_STORE, " nt"), (_lib.FLAG_NO_XCD_REMAP, " noxcd"),
                                         (_lib.FLAG_FORCE_IDX64, " i64")):
-                            cands.append(("V%d S%d W%d r8%s" % (vec, strips, grp, tag), 1,
+                            cands.append(("V%d S%d W%d seg g8%s" % (vec, strips, grp, tag), 1,
                                           dict(base, rows_per_wave=8, flags=fl)))
                 best = {}
                 for _ in range(args.rounds):

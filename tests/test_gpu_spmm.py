@@ -90,10 +90,14 @@ def test_edge_shapes_every_width(pkg, oracle, seed):
         for variant in EXACT_VARIANTS:
             assert_bits_equal(run(pkg, G, B, None, variant), ref_u, "edge N=%d unweighted v%d" % (N, variant))
             assert_bits_equal(run(pkg, G, B, val, variant), ref_v, "edge N=%d valued v%d" % (N, variant))
-        for rpw in (1, 2, 3, 8, 21, 32):  # rows per wavefront of the streaming kernel, incl. > M
+        from gespmm_amd import _lib
+
+        for rpw in (1, 2, 3, 8, 21, 32):  # rows per lane group / per wavefront, incl. > M
             for variant in (1, 3, 4):
-                cfg = {"rows_per_wave": rpw}
-                assert_bits_equal(run(pkg, G, B, val, variant, cfg), ref_v, "edge N=%d rpw=%d v%d" % (N, rpw, variant))
+                for flags in (0, _lib.FLAG_BATCH_STREAM):
+                    cfg = {"rows_per_wave": rpw, "flags": flags}
+                    assert_bits_equal(run(pkg, G, B, val, variant, cfg), ref_v,
+                                      "edge N=%d rpw=%d v%d f%d" % (N, rpw, variant, flags))
 
 
 def test_explicit_geometries_and_flags(pkg, oracle, bundled):
@@ -108,13 +112,14 @@ def test_explicit_geometries_and_flags(pkg, oracle, bundled):
         ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
         ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
         all_flags = (0, _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_NT_STORE, _lib.FLAG_FORCE_IDX64, _lib.FLAG_ROW_PER_GROUP,
-                     _lib.FLAG_SHALLOW_UNROLL,
+                     _lib.FLAG_SHALLOW_UNROLL, _lib.FLAG_BATCH_STREAM,
+                     _lib.FLAG_BATCH_STREAM | _lib.FLAG_SHALLOW_UNROLL | _lib.FLAG_FORCE_IDX64,
                      _lib.FLAG_NT_STORE | _lib.FLAG_FORCE_IDX64 | _lib.FLAG_NO_XCD_REMAP | _lib.FLAG_SHALLOW_UNROLL)
         for vec in (1, 2, 4):
             for strips in (1, 2):
                 for group in (4, 8, 16, 32, 64):
                     for i, flags in enumerate(all_flags):
-                        rpw = (0, 1, 2, 4, 7, 16, 32)[(i + group + vec) % 7]
+                        rpw = (0, 1, 2, 4, 7, 16, 32)[(i + group + vec + strips) % 7]
                         cfg = {"vec": vec, "strips": strips, "group": group, "rows_per_wave": rpw, "flags": flags}
                         what = "N=%d cfg=%r" % (N, cfg)
                         assert_bits_equal(run(pkg, G, B, val, 3, cfg), ref_v, what)
@@ -247,3 +252,51 @@ def test_stream_semantics(pkg, oracle, bundled):
         out = spmm.csr_spmm_no_edge_value(rp, ci, x)
     s.synchronize()
     assert torch.equal(out, ref)
+
+
+def _skewed_csr(seed=0):
+    """A few hub rows (2049 .. 70 000 entries, around the 2048-entry split threshold)
+    among short and empty rows."""
+    rng = np.random.RandomState(seed)
+    K = 5000
+    degs = rng.randint(0, 12, size=300)
+    for r, d in ((0, 2048), (5, 2049), (17, 5000), (18, 70000), (150, 2047), (299, 9999)):
+        degs[r] = d
+    rowptr = np.zeros(len(degs) + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)
+    long_rows = np.nonzero(degs > 2048)[0]
+    return {"M": len(degs), "K": K, "nnz": int(rowptr[-1]), "rowptr": rowptr, "colind": colind}, long_rows
+
+
+def test_long_row_split_is_deterministic_and_within_tolerance(pkg, oracle):
+    """Rows above 2048 entries are re-associated (fixed order) when the long-row pass
+    runs; every other row stays bit-exact; STRICT_ORDER restores the strict chain."""
+    from gespmm_amd import _lib
+
+    G, long_rows = _skewed_csr()
+    short = np.setdiff1d(np.arange(G["M"]), long_rows)
+    val = oracle.hash_val(G["nnz"], seed=11)
+    for N in (3, 32, 128, 200, 512):
+        B = oracle.hash_B(G["K"], N, seed=N)
+        for v in (val, None):
+            ref = oracle.spmm(G["rowptr"], G["colind"], v, B, "fma")
+            scale = oracle.spmm_abs(G["rowptr"], G["colind"], v, B)
+            split = {"flags": _lib.FLAG_SPLIT_LONG_ROWS}
+            for variant in (-1, 1, 2, 3, 4):
+                C1 = run(pkg, G, B, v, variant, split)
+                C2 = run(pkg, G, B, v, variant, split)
+                assert np.array_equal(bits(C1), bits(C2)), "split rows must be reproducible run to run"
+                assert np.array_equal(bits(C1[short]), bits(ref[short])), "rows <= 2048 entries stay bit-exact"
+                tol = 1e-4 * np.maximum(np.abs(ref[long_rows]), scale[long_rows])  # north_star: 1e-4 relative
+                assert np.all(np.abs(C1[long_rows].astype(np.float64) - ref[long_rows]) <= tol + 1e-30), (N, variant)
+            strict = {"flags": _lib.FLAG_SPLIT_LONG_ROWS | _lib.FLAG_STRICT_ORDER}
+            assert_bits_equal(run(pkg, G, B, v, -1, strict), ref, "STRICT_ORDER N=%d" % N)
+            assert_bits_equal(run(pkg, G, B, v, -1, None), ref, "small matrices never split, N=%d" % N)
+    # max reducer: exact under any association
+    from gespmm_amd import spmm
+
+    rp, ci = dev_csr(G)
+    Bm = oracle.hash_B(G["K"], 64, seed=3)
+    assert_bits_equal(spmm.csr_spmm_max(rp, ci, torch.from_numpy(Bm).cuda()).cpu().numpy(),
+                      oracle.spmm_max(G["rowptr"], G["colind"], Bm), "max")

@@ -120,3 +120,26 @@ def test_row_partition_and_exchange_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def test_rmat_shards_tile_the_global_graph(pkg):
+    from gespmm_amd import graphs
+
+    full = graphs.rmat_shard(11, 8, 0, 1, seed=5, chunk_edges=3000)
+    assert full["M"] == full["K"] == 2048 and full["nnz"] == full["global_nnz"] == 8 * 2048
+    for balanced in (False, True):
+        parts = [graphs.rmat_shard(11, 8, r, 3, seed=5, chunk_edges=3000, balanced=balanced) for r in range(3)]
+        assert parts[0]["row_begin"] == 0 and parts[-1]["row_end"] == 2048
+        assert all(parts[i]["row_end"] == parts[i + 1]["row_begin"] for i in range(2))
+        assert torch.equal(torch.cat([p["colind"] for p in parts]), full["colind"])
+        offs = 0
+        for p in parts:
+            seg = full["rowptr"][p["row_begin"]:p["row_end"] + 1] - full["rowptr"][p["row_begin"]]
+            assert torch.equal(seg, p["rowptr"])
+            offs += p["nnz"]
+        assert offs == full["nnz"]
+        if balanced:  # same cuts as the C ABI partitioner on the global rowptr
+            cut = graphs.row_partition(full["rowptr"].numpy(), 3)
+            assert list(cut) == parts[0]["cuts"]
+    deg = (full["rowptr"][1:] - full["rowptr"][:-1])
+    assert int(deg.max()) > 20 * float(deg.float().mean()), "RMAT is heavy-tailed"
