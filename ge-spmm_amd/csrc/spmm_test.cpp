@@ -10,8 +10,9 @@
 //            "running tests..."
 //   appends to ./spmm_test_out.out, for N in {128,256,512} (<= max_ncols), the pair
 //            "<vendor GFLOP/s>,<GE-SpMM GFLOP/s>," with no newline (run_test.sh adds
-//            the matrix name and the newline). The vendor column is rocSPARSE-less
-//            in this build and prints 0.000000 (a "next" row).
+//            the matrix name and the newline). The vendor column is rocSPARSE's generic
+//            SpMM (rocsparse_spmm, CSR, row-major B and C) where the reference times
+//            cusparseScsrmm2 (spmm_test.cu:660,730-738); --no-vendor prints 0.000000.
 //   exit 1 on a missing file / bad banner (util.hpp:300-313), EXIT_FAILURE on a
 //   device error, 0 otherwise. Device allocation failure halves max_ncols and
 //   retries, like spmm_test.cu:619-634.
@@ -30,10 +31,12 @@
 //                   loop only CHECKS device output; it never produces results.
 //   --cpu-baseline  time that CPU loop (1 thread) and print its GFLOP/s
 //   --out path      CSV side file                     (default spmm_test_out.out)
+//   --no-vendor     skip the rocSPARSE comparison column
 //
 // There is no CPU fallback: without a HIP device the driver fails with EXIT_FAILURE.
 
 #include <hip/hip_runtime.h>
+#include <rocsparse/rocsparse.h>
 
 #include <chrono>
 #include <cmath>
@@ -123,6 +126,61 @@ void cpu_check_loop(int M, int N, const int32_t* indptr, const int32_t* indices,
         }
 }
 
+// Vendor baseline: rocSPARSE generic SpMM on the same device buffers (comparison
+// column only — the role cuSPARSE csrmm2 plays in the reference driver).
+struct VendorSpmm {
+    rocsparse_handle handle = nullptr;
+    rocsparse_spmat_descr A = nullptr;
+    rocsparse_dnmat_descr B = nullptr, C = nullptr;
+    void* buffer = nullptr;
+    size_t buffer_size = 0;
+    float alpha = 1.0f, beta = 0.0f;
+    bool ok = false;
+
+    bool setup(int M, int K, int N, int nnz, int32_t* indptr, int32_t* indices, float* data, float* Bd, float* Cd) {
+        teardown();
+        if (rocsparse_create_handle(&handle) != rocsparse_status_success) return false;
+        if (rocsparse_create_csr_descr(&A, M, K, nnz, indptr, indices, data, rocsparse_indextype_i32,
+                                       rocsparse_indextype_i32, rocsparse_index_base_zero,
+                                       rocsparse_datatype_f32_r) != rocsparse_status_success)
+            return false;
+        if (rocsparse_create_dnmat_descr(&B, K, N, N, Bd, rocsparse_datatype_f32_r, rocsparse_order_row) !=
+            rocsparse_status_success)
+            return false;
+        if (rocsparse_create_dnmat_descr(&C, M, N, N, Cd, rocsparse_datatype_f32_r, rocsparse_order_row) !=
+            rocsparse_status_success)
+            return false;
+        if (rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C,
+                           rocsparse_datatype_f32_r, rocsparse_spmm_alg_default, rocsparse_spmm_stage_buffer_size,
+                           &buffer_size, nullptr) != rocsparse_status_success)
+            return false;
+        if (hipMalloc(&buffer, buffer_size ? buffer_size : 4) != hipSuccess) return false;
+        if (rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C,
+                           rocsparse_datatype_f32_r, rocsparse_spmm_alg_default, rocsparse_spmm_stage_preprocess,
+                           &buffer_size, buffer) != rocsparse_status_success)
+            return false;
+        ok = true;
+        return true;
+    }
+    bool run() {
+        return rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C,
+                              rocsparse_datatype_f32_r, rocsparse_spmm_alg_default, rocsparse_spmm_stage_compute,
+                              &buffer_size, buffer) == rocsparse_status_success;
+    }
+    void teardown() {
+        if (buffer) (void)hipFree(buffer);
+        if (C) rocsparse_destroy_dnmat_descr(C);
+        if (B) rocsparse_destroy_dnmat_descr(B);
+        if (A) rocsparse_destroy_spmat_descr(A);
+        if (handle) rocsparse_destroy_handle(handle);
+        buffer = nullptr;
+        A = nullptr;
+        B = C = nullptr;
+        handle = nullptr;
+        ok = false;
+    }
+};
+
 std::vector<int> parse_list(const char* s) {
     std::vector<int> v;
     while (*s) {
@@ -142,7 +200,7 @@ int main(int argc, char** argv) {
     int dev_id = 0;
     int method = GESPMM_VARIANT_CRC_CWM2;
     int iters = 200;
-    bool validate = false, cpu_baseline = false, use_values = false, seed_given = false;
+    bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true;
     unsigned seed = 0;
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
@@ -165,12 +223,13 @@ int main(int argc, char** argv) {
         else if (a == "--validate") validate = true;
         else if (a == "--cpu-baseline") cpu_baseline = true;
         else if (a == "--use-values") use_values = true;
+        else if (a == "--no-vendor") vendor = false;
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
     if (!mtx_path) {
         fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
-                        "[--use-values] [--validate] [--cpu-baseline] [--out path]\n", argv[0]);
+                        "[--use-values] [--validate] [--cpu-baseline] [--no-vendor] [--out path]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (iters < 1) iters = 1;
@@ -287,6 +346,22 @@ int main(int argc, char** argv) {
                         break;
                     }
         }
+        if (vendor) {  // reference: csrmm2 checked against golden too (spmm_test.cu:671-679)
+            VendorSpmm vs;
+            if (vs.setup(M, K, N, nnz, g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev) && vs.run()) {
+                CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
+                for (int i = 0; i < M; i++)
+                    for (int j = 0; j < N; j++)
+                        if (fabs(g.C[(size_t)i * N + j] - g.golden[(size_t)i * N + j]) > 1e-2) {
+                            printf("rocsparse WA: C[%d, %d] = %f, golden = %f\n", i, j, g.C[(size_t)i * N + j],
+                                   g.golden[(size_t)i * N + j]);
+                            break;
+                        }
+            } else {
+                printf("rocsparse spmm unavailable\n");
+            }
+            vs.teardown();
+        }
         printf("validate done (%d variants, N=%d)\n", GESPMM_NUM_VARIANTS, N);
     }
     if (cpu_baseline) printf("cpu golden loop: %f GFLOP/s (1 thread, N=%d)\n", cpu_gflops, max_ncols);
@@ -302,8 +377,21 @@ int main(int argc, char** argv) {
         if (N > max_ncols || N < 1) continue;
         const double gflop = (double)nnz * 2 / 1000000 * N;
         float rt = 0.0f;
-        // vendor column (reference: cusparseScsrmm2, spmm_test.cu:730-738): not built in
-        if (g.fpo) fprintf(g.fpo, "%f,", 0.0);
+        // vendor column (reference: cusparseScsrmm2, spmm_test.cu:730-738)
+        double vendor_gflops = 0.0;
+        if (vendor) {
+            VendorSpmm vs;
+            if (vs.setup(M, K, N, nnz, g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev) && vs.run()) {
+                CHECK_HIP(hipEventRecord(g.start, 0));
+                for (int i = 0; i < iters; i++) vs.run();
+                CHECK_HIP(hipEventRecord(g.stop, 0));
+                CHECK_HIP(hipEventSynchronize(g.stop));
+                CHECK_HIP(hipEventElapsedTime(&rt, g.start, g.stop));
+                vendor_gflops = gflop / (rt / iters);
+            }
+            vs.teardown();
+        }
+        if (g.fpo) fprintf(g.fpo, "%f,", vendor_gflops);
 
         CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, method,
                                      nullptr));
@@ -315,7 +403,8 @@ int main(int argc, char** argv) {
         CHECK_HIP(hipEventSynchronize(g.stop));
         CHECK_HIP(hipEventElapsedTime(&rt, g.start, g.stop));
         if (g.fpo) fprintf(g.fpo, "%f,", gflop / (rt / iters));
-        printf("N=%d method=%d: %f ms/iter, %f GFLOP/s\n", N, method, rt / iters, gflop / (rt / iters));
+        printf("N=%d method=%d: %f ms/iter, %f GFLOP/s (rocsparse %f GFLOP/s)\n", N, method, rt / iters,
+               gflop / (rt / iters), vendor_gflops);
     }
 
     g.release();

@@ -331,3 +331,19 @@ def rmat_shard(scale, edge_factor=16, rank=0, world=1, seed=42, device="cpu", pr
         rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=nloc), 0)
     return {"M": nloc, "K": M, "nnz": int(cc.numel()), "rowptr": rowptr.to(torch.int32), "colind": cc,
             "row_begin": r0, "row_end": r1, "global_nnz": total, "cuts": cuts}
+
+
+def write_mtx(path, rowptr, colind, K=None):
+    """Write a CSR pattern as a MatrixMarket `pattern general` file (1-based), e.g. to
+    feed a synthetic stand-in to the spmm_test driver the way run_test.sh feeds it the
+    SNAP files."""
+    rp = rowptr.cpu().numpy() if hasattr(rowptr, "cpu") else np.asarray(rowptr)
+    ci = colind.cpu().numpy() if hasattr(colind, "cpu") else np.asarray(colind)
+    M = rp.shape[0] - 1
+    K = M if K is None else K
+    rows = np.repeat(np.arange(M, dtype=np.int64), np.diff(rp.astype(np.int64)))
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern general\n")
+        f.write("%% synthetic stand-in written by gespmm_amd.graphs.write_mtx\n")
+        f.write("%d %d %d\n" % (M, K, ci.shape[0]))
+        np.savetxt(f, np.stack([rows + 1, ci.astype(np.int64) + 1], axis=1), fmt="%d %d")
