@@ -43,33 +43,87 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
                                                           const float* __restrict__ D2, float* __restrict__ out,
                                                           int M, int nnz, int N) {
     constexpr int G = 64 / W;
+    constexpr int EPW = 64;  // edges per wavefront (CSR form): G edges at a time, EPW/G rounds
     using T = typename SdVec<V>::type;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane / W;
     const int l = lane % W;
-    const int e = (blockIdx.x * kWaves + wave) * G + g;
-    const bool ok = e < nnz;
-    float part = 0.0f;
-    if (ok) {
-        const int r = CSR ? row_of_edge(rows, M, e) : rows[e];
-        const int c = colind[e];
-        const float* p1 = D1 + (size_t)r * (size_t)N;
-        const float* p2 = D2 + (size_t)c * (size_t)N;
-        for (int j = l * V; j < N; j += W * V) {
-            const T x = *reinterpret_cast<const T*>(p1 + j);
-            const T y = *reinterpret_cast<const T*>(p2 + j);
-            if constexpr (V == 1) {
-                part = __builtin_fmaf(x, y, part);
-            } else {
+
+    if constexpr (!CSR) {
+        const int e = (blockIdx.x * kWaves + wave) * G + g;
+        const bool ok = e < nnz;
+        float part = 0.0f;
+        if (ok) {
+            const int r = rows[e];
+            const int c = colind[e];
+            const float* p1 = D1 + (size_t)r * (size_t)N;
+            const float* p2 = D2 + (size_t)c * (size_t)N;
+            for (int j = l * V; j < N; j += W * V) {
+                const T x = *reinterpret_cast<const T*>(p1 + j);
+                const T y = *reinterpret_cast<const T*>(p2 + j);
+                if constexpr (V == 1) {
+                    part = __builtin_fmaf(x, y, part);
+                } else {
 #pragma unroll
-                for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+                    for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
-    if (ok && l == 0) out[e] = part;
+        for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+        if (ok && l == 0) out[e] = part;
+    } else {
+        // CSR form: the wavefront owns EPW consecutive edges. ONE global binary search
+        // (wave-uniform) finds the row of its first edge; the rows of all its edges then
+        // lie in a window of at most EPW+1 row pointers, staged in LDS, and every group
+        // finds its edge's row there (the reference searches rowptr in global memory once
+        // per edge, computeUtil.h:11-28).
+        __shared__ int s_rp[kWaves][EPW + 2];
+        __shared__ int s_col[kWaves][EPW];
+        const int e0 = (blockIdx.x * kWaves + wave) * EPW;
+        if (e0 >= nnz) return;
+        const int e1 = (e0 + EPW < nnz) ? e0 + EPW : nnz;
+        const int r0 = row_of_edge(rows, M, e0);  // same address in every lane: broadcast loads
+        // rows r0 .. r0+EPW cover [e0, e1) unless empty rows intervene; rows past the window
+        // are found by continuing the search from the window's end
+        for (int i = lane; i < EPW + 2; i += 64) s_rp[wave][i] = (r0 + i <= M) ? rows[r0 + i] : 0x7fffffff;
+        if (e0 + lane < e1) s_col[wave][lane] = colind[e0 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = e0 + g; e < e1; e += G) {
+            // largest i in [0, EPW+1] with s_rp[i] <= e   (s_rp[0] = rowptr[r0] <= e0 <= e)
+            int lo = 0, hi = EPW + 1;
+            if (s_rp[wave][hi] <= e) {  // more than EPW empty rows in the window: fall back
+                lo = row_of_edge(rows, M, e) - r0;
+                hi = lo + 1;
+            }
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_rp[wave][mid] <= e) lo = mid;
+                else hi = mid;
+            }
+            const int r = r0 + lo;
+            const int c = s_col[wave][e - e0];
+            const float* p1 = D1 + (size_t)r * (size_t)N;
+            const float* p2 = D2 + (size_t)c * (size_t)N;
+            float part = 0.0f;
+            for (int j = l * V; j < N; j += W * V) {
+                const T x = *reinterpret_cast<const T*>(p1 + j);
+                const T y = *reinterpret_cast<const T*>(p2 + j);
+                if constexpr (V == 1) {
+                    part = __builtin_fmaf(x, y, part);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+                }
+            }
+#pragma unroll
+            for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+            if (l == 0) out[e] = part;
+        }
+    }
 }
 
 template <int V, bool CSR>
@@ -78,7 +132,8 @@ static hipError_t sddmm_w(int W, const int32_t* rows, const int32_t* colind, con
 #define GESPMM_SD(WW)                                                                                         \
     case WW: {                                                                                                 \
         constexpr int G = 64 / WW;                                                                             \
-        const int nblk = (int)(((int64_t)nnz + kWaves * G - 1) / (kWaves * G));                                \
+        constexpr int per_wave = CSR ? 64 : G; /* edges per wavefront */                                       \
+        const int nblk = (int)(((int64_t)nnz + kWaves * per_wave - 1) / (kWaves * per_wave));                  \
         hipLaunchKernelGGL((sddmm_kernel<V, WW, CSR>), dim3(nblk), dim3(kThreads), 0, st, rows, colind, D1, D2, \
                            out, M, nnz, N);                                                                    \
         return hipGetLastError();                                                                              \

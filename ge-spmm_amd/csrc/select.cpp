@@ -22,6 +22,12 @@ static int pow2_ceil(int64_t x) {
 int auto_variant(int64_t M, int64_t nnz, int64_t N) {
     (void)M;
     (void)nnz;
+    // Up to 64 columns one lane per column already spans a whole wavefront-wide group;
+    // coarsening would only shrink the group and put more rows on one wavefront, and a
+    // 64-entry CSR tile of a long row feeds ONE group at a time. Measured (profiles/r01/
+    // narrow_n_kernel_choice.log): V=1 is equal or faster for every graph at N <= 64,
+    // by 30-58 % on the denser ones (products-like N=32, reddit-like N<=32).
+    if (N <= 64) return GESPMM_VARIANT_CRC;
     if (N % 4 == 0) return GESPMM_VARIANT_CRC_CWM4;
     if (N % 2 == 0) return GESPMM_VARIANT_CRC_CWM2;
     return GESPMM_VARIANT_CRC;

@@ -87,18 +87,22 @@ def zeros(tensor):
 
 
 class GCNConv(torch.nn.Module):
+    """Graph convolution  out = D_in^-1/2 · A · (D_out^-1/2 ⊙ (x W)) + b  on the custom op.
+
+    Constructor and ``forward`` signatures are the reference's (op.py:77-152). Degrees
+    come from the pointer differences of the two index orders (``rowptr`` -> in-degree
+    of the aggregating side, ``colptr`` -> out-degree of the source side); with
+    ``cached=True`` the two scaling vectors are computed once and reused.
+    """
+
     def __init__(self, in_channels, out_channels, improved=False, cached=False, bias=True, normalize=True,
                  **kwargs):
         super().__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.improved = improved
-        self.cached = cached
-        self.normalize = normalize
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached, self.normalize = improved, cached, normalize
         self.weight = Parameter(torch.empty(in_channels, out_channels))
-        if bias:
-            self.bias = Parameter(torch.empty(out_channels))
-        else:
+        self.bias = Parameter(torch.empty(out_channels)) if bias else None
+        if not bias:
             self.register_parameter("bias", None)
         self.reset_parameters()
 
@@ -109,32 +113,34 @@ class GCNConv(torch.nn.Module):
         self.cached_num_edges = None
 
     @staticmethod
-    def in_deg_sqrt(indptr):
-        return (1 / torch.sqrt((indptr[1:] - indptr[:-1]).float())).unsqueeze(dim=1)
+    def _inv_sqrt_degree(indptr):
+        degree = torch.diff(indptr).to(torch.float32)
+        return (1 / torch.sqrt(degree)).unsqueeze(1)  # zero-degree rows give inf, as in the reference
 
-    @staticmethod
-    def out_deg_sqrt(indptr):
-        return (1 / torch.sqrt((indptr[1:] - indptr[:-1]).float())).unsqueeze(dim=1)
+    # names kept from the reference (op.py:103-109); both are the same pointer-difference rule
+    in_deg_sqrt = _inv_sqrt_degree
+    out_deg_sqrt = _inv_sqrt_degree
+
+    def _scalings(self, x, rowptr, colptr):
+        if self.cached and self.cached_result is not None:
+            return self.cached_result
+        if self.normalize:
+            scal = (self._inv_sqrt_degree(rowptr), self._inv_sqrt_degree(colptr))
+        else:  # the reference's branch here raises TypeError (rowptr.shape(0)); intent: no scaling
+            scal = (torch.ones(rowptr.numel() - 1, 1, dtype=x.dtype, device=x.device),
+                    torch.ones(colptr.numel() - 1, 1, dtype=x.dtype, device=x.device))
+        self.cached_result = scal
+        return scal
 
     def forward(self, x, rowptr, colind, colptr, rowind, edge_weight_csr=None, edge_weight_csc=None):
-        x = torch.matmul(x, self.weight)
-        if not self.cached or self.cached_result is None:
-            if self.normalize:
-                in_deg_norm = self.in_deg_sqrt(rowptr)
-                out_deg_norm = self.out_deg_sqrt(colptr)
-            else:
-                in_deg_norm = torch.ones(rowptr.shape[0] - 1, 1, dtype=x.dtype, device=x.device)
-                out_deg_norm = torch.ones(colptr.shape[0] - 1, 1, dtype=x.dtype, device=x.device)
-            self.cached_result = in_deg_norm, out_deg_norm
-        in_deg_norm, out_deg_norm = self.cached_result
+        h = x @ self.weight
+        in_scale, out_scale = self._scalings(h, rowptr, colptr)
         if self.normalize:
-            x = x * out_deg_norm
-        aggr_out = SPMMFunction.apply(rowptr, colind, colptr, rowind, x, edge_weight_csr, edge_weight_csc)
+            h = h * out_scale
+        h = SPMMFunction.apply(rowptr, colind, colptr, rowind, h, edge_weight_csr, edge_weight_csc)
         if self.normalize:
-            aggr_out = aggr_out * in_deg_norm
-        if self.bias is not None:
-            aggr_out = aggr_out + self.bias
-        return aggr_out
+            h = h * in_scale
+        return h if self.bias is None else h + self.bias
 
     def __repr__(self):
-        return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
+        return "%s(%d, %d)" % (type(self).__name__, self.in_channels, self.out_channels)

@@ -117,8 +117,12 @@ def test_select_variant(pkg):
 
     assert spmm.select_variant(1000, 5000, 128) == _lib.VARIANT_CRC_CWM4
     assert spmm.select_variant(1000, 5000, 512) == _lib.VARIANT_CRC_CWM4
-    assert spmm.select_variant(1000, 5000, 32) == _lib.VARIANT_CRC_CWM4
-    assert spmm.select_variant(1000, 5000, 6) == _lib.VARIANT_CRC_CWM2
+    assert spmm.select_variant(1000, 5000, 256) == _lib.VARIANT_CRC_CWM4
+    assert spmm.select_variant(1000, 5000, 130) == _lib.VARIANT_CRC_CWM2
+    assert spmm.select_variant(1000, 5000, 129) == _lib.VARIANT_CRC
+    assert spmm.select_variant(1000, 5000, 64) == _lib.VARIANT_CRC
+    assert spmm.select_variant(1000, 5000, 32) == _lib.VARIANT_CRC
+    assert spmm.select_variant(1000, 5000, 6) == _lib.VARIANT_CRC
     assert spmm.select_variant(1000, 5000, 41) == _lib.VARIANT_CRC
     assert spmm.select_variant(1000, 5000, 3) == _lib.VARIANT_CRC
     for n in (1, 2, 3, 16, 41, 128, 500, 512):
