@@ -84,3 +84,59 @@ def test_linearity_and_sampled_oracle_rows(pkg, oracle, amazon):
     ref = oracle.spmm(sub_ptr, cih[sel], vh[sel], B1.cpu().numpy(), "fma")
     got = C1[torch.from_numpy(rows).cuda()].cpu().numpy()
     assert np.array_equal(bits(got), bits(ref))
+
+
+def test_offsets_beyond_4GB_of_B(pkg):
+    """K*N*4 >= 2^32 switches the kernels to 64-bit byte offsets (RMAT-26 x N=256 needs
+    2^34 elements; reference: 32-bit `col*N`, spmm_test.cu:124, overflows). Rows that
+    reach past the 4 GiB mark must gather the right B rows — checked with exact integer
+    arithmetic against torch index ops."""
+    from gespmm_amd import spmm
+
+    N, K, M = 512, (1 << 21) + 37, 3000  # B = 4.3 GB
+    assert K * N * 4 >= (1 << 32)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    B = torch.randint(-8, 9, (K, N), generator=gen, device="cuda", dtype=torch.int32).float()
+    deg = torch.randint(0, 40, (M,), generator=gen, device="cuda")
+    deg[7] = 3000  # one long row
+    rowptr = torch.zeros(M + 1, dtype=torch.int64, device="cuda")
+    rowptr[1:] = torch.cumsum(deg, 0)
+    nnz = int(rowptr[-1])
+    # half the entries point into the last 5 % of B (beyond 4 GiB), including the very last row
+    hi = torch.randint(int(K * 0.95), K, (nnz,), generator=gen, device="cuda")
+    lo = torch.randint(0, K, (nnz,), generator=gen, device="cuda")
+    col = torch.where(torch.rand(nnz, generator=gen, device="cuda") < 0.5, hi, lo)
+    col[0] = K - 1
+    val = torch.randint(-3, 4, (nnz,), generator=gen, device="cuda").float()
+    rp32, ci32 = rowptr.to(torch.int32), col.to(torch.int32)
+    rows = torch.repeat_interleave(torch.arange(M, device="cuda"), deg)
+    ref = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    ref.index_add_(0, rows, B[col] * val.unsqueeze(1))  # small integers: exact in fp32
+    for variant in (-1, 0, 1, 2, 4, 5):
+        C = spmm.csr_spmm(rp32, ci32, val, B, variant=variant)
+        assert torch.equal(C, ref), "variant %d" % variant
+    Cu = spmm.csr_spmm_no_edge_value(rp32, ci32, B)
+    refu = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    refu.index_add_(0, rows, B[col])
+    assert torch.equal(Cu, refu)
+    del B, ref, refu
+    torch.cuda.empty_cache()
+
+
+def test_wide_and_odd_feature_widths_full_rows(pkg, oracle):
+    """N far beyond one column tile (N = 2048, 1000, 1023): many column tiles per row."""
+    from gespmm_amd import graphs, spmm
+
+    g = graphs.synthetic_graph("cit-hepth-like", seed=3, device="cuda")
+    rp, ci = g["rowptr"], g["colind"]
+    M = g["M"]
+    rows = torch.repeat_interleave(torch.arange(M, device="cuda"), (rp[1:] - rp[:-1]).long())
+    for N in (1000, 1023, 2048):
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(N)
+        B = torch.randint(-8, 9, (M, N), generator=gen, device="cuda", dtype=torch.int32).float()
+        ref = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+        ref.index_add_(0, rows, B[ci.long()])
+        for variant in (-1, 1, 3, 4):
+            assert torch.equal(spmm.csr_spmm_no_edge_value(rp, ci, B, variant=variant), ref), (N, variant)
