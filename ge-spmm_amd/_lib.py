@@ -29,6 +29,8 @@ FLAG_CACHED_CSR = 0x40
 FLAG_SEG_STREAM = 0x80
 FLAG_STRICT_ORDER = 0x100
 FLAG_SPLIT_LONG_ROWS = 0x200
+FLAG_SLAB_BLOCKED = 0x400
+FLAG_NO_SLAB_BLOCKED = 0x800
 FLAG_SHALLOW_UNROLL = 0x10
 
 # Every symbol include/gespmm.h declares; tests check the library exports all of them.
@@ -52,7 +54,7 @@ EXPORTS = [
 
 class LaunchCfg(Structure):
     _fields_ = [("vec", c_int32), ("strips", c_int32), ("group", c_int32), ("rows_per_wave", c_int32),
-                ("flags", c_int32)]
+                ("slab_rows", c_int32), ("flags", c_int32)]
 
 
 class Coo(Structure):

@@ -45,7 +45,8 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     if (reduce == gespmm::kReduceMax && (val != nullptr || variant == GESPMM_VARIANT_PARREDUCE ||
                                          variant == GESPMM_VARIANT_NAIVE))
         return GESPMM_EINVAL;
-    if (cfg && (cfg->rows_per_wave < 0 || cfg->rows_per_wave > gespmm::kMaxRowsPerWave)) return GESPMM_EINVAL;
+    if (cfg && (cfg->rows_per_wave < 0 || cfg->rows_per_wave > gespmm::kMaxRowsPerWave || cfg->slab_rows < 0))
+        return GESPMM_EINVAL;
 
     // Vector width is limited by what both B and C rows can be addressed with.
     int max_vec = 4;
@@ -57,7 +58,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     if (cfg) flags = cfg->flags;
     const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
                                              cfg ? cfg->strips : 0, cfg ? cfg->group : 0,
-                                             cfg ? cfg->rows_per_wave : 0, flags, &sel);
+                                             cfg ? cfg->rows_per_wave : 0, cfg ? cfg->slab_rows : 0, flags, &sel);
     if (src != 0) return src;
     sel.geo.reduce = reduce;
 
@@ -74,6 +75,9 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.flags = flags;
     a.empty = empty;
     a.long_row = 0;
+    a.row_begin = nullptr;
+    a.row_end = nullptr;
+    a.accumulate = 0;
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
@@ -81,7 +85,9 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);
     else if (sel.variant == GESPMM_VARIANT_NAIVE || (flags & gespmm::kFlagRowPerGroup))
         e = gespmm::launch_spmm_rowgroup(a, sel.geo, st);
-    else {
+    else if (sel.geo.slab_blocked && reduce == gespmm::kReduceSum) {
+        e = gespmm::launch_spmm_slabblocked(a, sel.geo, st);
+    } else {
         bool seg = sel.geo.segmented;
         if (flags & gespmm::kFlagBatchStream) seg = false;
         if ((flags & gespmm::kFlagSegStream) && !sel.geo.split_long_rows) seg = true;

@@ -34,7 +34,8 @@ int auto_variant(int64_t M, int64_t nnz, int64_t N) {
 }
 
 int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, int max_vec,
-                     int cfg_vec, int cfg_strips, int cfg_group, int cfg_rows_per_wave, int flags, Selection* out) {
+                     int cfg_vec, int cfg_strips, int cfg_group, int cfg_rows_per_wave, int cfg_slab_rows, int flags,
+                     Selection* out) {
     if (variant == GESPMM_VARIANT_AUTO) variant = auto_variant(M, nnz, N);
     Geometry g;
     g.reduce = kReduceSum;
@@ -104,6 +105,24 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // flushes diverge between groups and the batch kernel (rows in lock-step, one store
     // phase per batch) is faster — measured in profiles/r01/kernel_generations.log.
     const int64_t avg_deg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
+    // Cache blocking for dense graphs (one launch per ~6 MB column slab of B, see
+    // spmm_kernels.hip): worth it when B per column tile is much larger than an L2 and a
+    // row still finds several of its entries in every slab.
+    {
+        const int64_t row_bytes = (int64_t)g.group * g.vec * g.strips * 4;
+        int64_t slab_rows = cfg_slab_rows > 0 ? cfg_slab_rows : (6 << 20) / row_bytes;
+        if (slab_rows < 64 && cfg_slab_rows <= 0) slab_rows = 64;
+        if (slab_rows > 0x3fffffff) slab_rows = 0x3fffffff;
+        g.slab_rows = (int)slab_rows;
+        g.K = K;
+        const int64_t nslab = (K + slab_rows - 1) / slab_rows;
+        // measured on reddit-like (profiles/r01/slab_blocking.log): 1.5-1.7x for N >= 64 with 4-6 MB
+        // slabs, a loss at N = 32 (128-byte row slices)
+        const bool dense = nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 &&
+                           avg_deg >= 4 * nslab && avg_deg >= 64;
+        g.slab_blocked = ((flags & kFlagSlabBlocked) != 0 || dense) && (flags & kFlagNoSlabBlocked) == 0 &&
+                         nslab <= 65536 && variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
+    }
     g.split_long_rows = ((flags & kFlagSplitLongRows) != 0 || nnz >= kLongRowMinNnz) && (flags & kFlagStrictOrder) == 0 &&
                         variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
     // A row is "long" when it dwarfs the average wavefront's work: 32x the mean degree,

@@ -9,6 +9,7 @@ namespace gespmm {
 constexpr int kThreads = 256;  // workgroup = 4 wavefronts of 64 lanes
 constexpr int kWaves = 4;
 constexpr int kTile = 64;      // CSR entries staged in LDS per wavefront refill
+constexpr int kSlabRowsPerGroup = 8; // slab-blocked path: rows a lane group walks per launch
 constexpr int kMaxRowsPerWave = 32;  // streaming kernel: rows owned by one wavefront
 
 constexpr int kReduceSum = 0;
@@ -24,6 +25,8 @@ constexpr int kFlagStrictOrder = 0x100;  // == GESPMM_FLAG_STRICT_ORDER (never s
 constexpr int kFlagSplitLongRows = 0x200; // == GESPMM_FLAG_SPLIT_LONG_ROWS (always run the long-row pass)
 constexpr int kLongRowThreshold = 2048;  // entries; lower bound of the long-row threshold (32 x mean degree)
 constexpr int64_t kLongRowMinNnz = 1 << 23;  // auto: only matrices this large get the long-row pass
+constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force the cache-blocked path)
+constexpr int kFlagNoSlabBlocked = 0x800; // == GESPMM_FLAG_NO_SLAB_BLOCKED
 constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
 constexpr int kFlagRowPerGroup = 0x8; // == GESPMM_FLAG_ROW_PER_GROUP (first-generation CRC kernel)
 
@@ -39,6 +42,9 @@ struct SpmmArgs {
     int32_t ntile;  // column tiles (filled in by the launcher)
     int32_t flags;
     int32_t rpw;    // streaming kernel: rows per wavefront (filled in by the launcher)
+    const int32_t* row_begin;  // slab-blocked path: per-row CSR range of the current slab
+    const int32_t* row_end;
+    int32_t accumulate;        // slab-blocked path: 0 = first slab (C = ...), 1 = C += ...
     int32_t long_row;  // > 0: rows with more entries are skipped by the main kernel (long-row kernel does them)
     float empty;    // max reducer: value of rows without non-zeros / initial accumulator
 };
@@ -53,6 +59,9 @@ struct Geometry {
     bool crc;     // LDS-staged CSR tiles (variants 1-4) vs naive (variant 0)
     bool idx64;   // 64-bit byte offsets into B
     bool segmented;  // segmented-stream kernel (else batch-stream)
+    bool slab_blocked;     // dense graph: one launch per column slab (cache blocking)
+    int slab_rows;         // B rows per slab
+    int64_t K;             // columns of A (for the slab count)
     bool split_long_rows;  // run the long-row pass
     int long_row_threshold;  // rows with more entries than this go to the long-row pass
     int reduce;   // kReduceSum / kReduceMax
@@ -62,6 +71,7 @@ hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStrea
 hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
 // sddmm_kernels.hip

@@ -54,7 +54,7 @@ def _make_cfg(cfg):
     if isinstance(cfg, LaunchCfg):
         return cfg
     return LaunchCfg(int(cfg.get("vec", 0)), int(cfg.get("strips", 0)), int(cfg.get("group", 0)),
-                     int(cfg.get("rows_per_wave", 0)), int(cfg.get("flags", 0)))
+                     int(cfg.get("rows_per_wave", 0)), int(cfg.get("slab_rows", 0)), int(cfg.get("flags", 0)))
 
 
 def _spmm(rowptr, colind, values, dense, variant, cfg, out):

@@ -125,6 +125,7 @@ typedef struct gespmm_launch_cfg {
     int32_t strips;
     int32_t group;
     int32_t rows_per_wave;
+    int32_t slab_rows;   /* cache-blocked path: B rows per column slab (0 = ~6 MB worth) */
     int32_t flags;
 } gespmm_launch_cfg;
 
@@ -136,6 +137,8 @@ typedef struct gespmm_launch_cfg {
 #define GESPMM_FLAG_BATCH_STREAM   0x20 /* force the batch-stream kernel (rows walked 64/group at a time) */
 #define GESPMM_FLAG_STRICT_ORDER   0x100 /* never split long rows: every row is one strict CSR-order chain */
 #define GESPMM_FLAG_SPLIT_LONG_ROWS 0x200 /* run the long-row pass regardless of matrix size */
+#define GESPMM_FLAG_SLAB_BLOCKED   0x400 /* force the cache-blocked path (one launch per column slab of B) */
+#define GESPMM_FLAG_NO_SLAB_BLOCKED 0x800 /* never use it */
 #define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (default for group >= 32) */
 #define GESPMM_FLAG_ROW_PER_GROUP  0x8  /* first-generation CRC kernel (one row batch per wavefront);
                                            kept for A/B measurements, same results */

@@ -62,9 +62,9 @@ def test_argument_validation_needs_no_gpu(pkg):
     assert f(p, p, None, p, p, 1 << 33, 4, 4, 8, -1, None) == -3     # M beyond int32
     assert f(p, p, None, p, p, 0, 4, 4, 0, -1, None) == 0            # empty problem: no launch
     assert f(p, p, None, p, p, 4, 4, 0, 0, -1, None) == 0
-    cfg = _lib.LaunchCfg(3, 0, 0, 0, 0)
+    cfg = _lib.LaunchCfg(3, 0, 0, 0, 0, 0)
     assert lib.gespmm_csr_spmm_f32_cfg(p, p, None, p, p, 4, 4, 4, 8, -1, ctypes.byref(cfg), None) == -1
-    cfg = _lib.LaunchCfg(0, 0, 24, 0, 0)
+    cfg = _lib.LaunchCfg(0, 0, 24, 0, 0, 0)
     assert lib.gespmm_csr_spmm_f32_cfg(p, p, None, p, p, 4, 4, 4, 8, -1, ctypes.byref(cfg), None) == -1
     # max reducer exists for unweighted CRC variants only
     assert lib.gespmm_csr_spmm_max_f32(p, p, p, p, 4, 4, 4, 8, -1e4, 5, None) == -1

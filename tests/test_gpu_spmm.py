@@ -300,3 +300,31 @@ def test_long_row_split_is_deterministic_and_within_tolerance(pkg, oracle):
     Bm = oracle.hash_B(G["K"], 64, seed=3)
     assert_bits_equal(spmm.csr_spmm_max(rp, ci, torch.from_numpy(Bm).cuda()).cpu().numpy(),
                       oracle.spmm_max(G["rowptr"], G["colind"], Bm), "max")
+
+
+def test_slab_blocked_path_is_bit_exact(pkg, oracle, bundled):
+    """The cache-blocked kernel for dense graphs consumes every row's entries in CSR
+    order whatever the slab size — sorted, unsorted and repeated columns alike."""
+    from gespmm_amd import _lib
+
+    cases = [edge_case_csr(8), _skewed_csr(1)[0], bundled["cora"]]
+    for G in cases:
+        val = oracle.hash_val(G["nnz"], seed=13)
+        for N in (1, 3, 32, 64, 100, 128, 512):
+            B = oracle.hash_B(G["K"], N, seed=N + 1)
+            ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+            ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
+            for slab_rows, R in ((1, 1), (7, 3), (64, 8), (1000, 16), (0, 0), (1 << 20, 32)):
+                cfg = {"slab_rows": slab_rows, "rows_per_wave": R, "flags": _lib.FLAG_SLAB_BLOCKED}
+                for variant in (-1, 1, 3, 4):
+                    what = "slab blocked N=%d slab_rows=%d R=%d v%d" % (N, slab_rows, R, variant)
+                    assert_bits_equal(run(pkg, G, B, val, variant, cfg), ref_v, what)
+                assert_bits_equal(run(pkg, G, B, None, -1, cfg), ref_u, "slab blocked unweighted N=%d" % N)
+    # forced 64-bit offsets and explicit geometry
+    G = cases[0]
+    B = oracle.hash_B(G["K"], 96, seed=2)
+    ref = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
+    for vec, group in ((1, 64), (2, 16), (4, 8), (4, 32)):
+        cfg = {"vec": vec, "group": group, "slab_rows": 50,
+               "flags": _lib.FLAG_SLAB_BLOCKED | _lib.FLAG_FORCE_IDX64}
+        assert_bits_equal(run(pkg, G, B, None, 3, cfg), ref, "slab blocked cfg %r" % cfg)
