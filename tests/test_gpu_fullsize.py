@@ -140,3 +140,66 @@ def test_wide_and_odd_feature_widths_full_rows(pkg, oracle):
         ref.index_add_(0, rows, B[ci.long()])
         for variant in (-1, 1, 3, 4):
             assert torch.equal(spmm.csr_spmm_no_edge_value(rp, ci, B, variant=variant), ref), (N, variant)
+
+
+def _exact_reference(rp, ci, vi, Bi, chunk=8):
+    """Independent exact result for integer-valued inputs: int64 index_add, column chunks."""
+    M = rp.numel() - 1
+    N = Bi.shape[1]
+    rows = torch.repeat_interleave(torch.arange(M, device=rp.device), (rp[1:] - rp[:-1]).long())
+    out = torch.empty((M, N), dtype=torch.float32, device=rp.device)
+    cil = ci.long()
+    for c0 in range(0, N, chunk):
+        c1 = min(c0 + chunk, N)
+        contrib = Bi[cil, c0:c1].long()
+        if vi is not None:
+            contrib = contrib * vi.long().unsqueeze(1)
+        ref = torch.zeros((M, c1 - c0), dtype=torch.int64, device=rp.device)
+        ref.index_add_(0, rows, contrib)
+        out[:, c0:c1] = ref.float()
+        del contrib, ref
+    return out
+
+
+def test_dense_graph_auto_path_full_size(pkg):
+    """reddit-like (115 M nnz): AUTO takes the cache-blocked (slab) path at N=64 and the
+    streaming + long-row path at N=16; both must reproduce exact integer arithmetic, and
+    the max reducer (long rows split across a workgroup) must equal torch's segment max."""
+    from gespmm_amd import _lib, graphs, spmm
+
+    g = graphs.synthetic_graph("reddit-like", seed=42, device="cuda")
+    rp, ci, M = g["rowptr"], g["colind"], g["M"]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    vi = torch.randint(-2, 3, (g["nnz"],), generator=gen, device="cuda", dtype=torch.int32)
+    for N in (64, 16):
+        Bi = torch.randint(-4, 5, (M, N), generator=gen, device="cuda", dtype=torch.int32)
+        ref = _exact_reference(rp, ci, vi, Bi)
+        C = spmm.csr_spmm(rp, ci, vi.float(), Bi.float())
+        assert torch.equal(C, ref), "auto path N=%d" % N
+        Cs = spmm.csr_spmm(rp, ci, vi.float(), Bi.float(),
+                           cfg={"flags": _lib.FLAG_NO_SLAB_BLOCKED | _lib.FLAG_STRICT_ORDER})
+        assert torch.equal(Cs, ref), "streaming strict N=%d" % N
+        del ref, C, Cs
+    B = torch.rand(M, 16, generator=gen, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(M, device="cuda"), (rp[1:] - rp[:-1]).long())
+    refm = torch.full((M, 16), -10000.0, device="cuda")
+    refm.scatter_reduce_(0, rows.unsqueeze(1).expand(-1, 16), B[ci.long()], reduce="amax", include_self=True)
+    assert torch.equal(spmm.csr_spmm_max(rp, ci, B), refm)
+
+
+def test_rmat_long_rows_full_size(pkg):
+    """RMAT scale 20 (16.8 M nnz, hub rows of ~10^5 entries): the long-row pass is on
+    (nnz >= 2^23); integer-valued inputs make every association exact."""
+    from gespmm_amd import graphs, spmm
+
+    g = graphs.rmat_shard(20, 16, 0, 1, seed=42, device="cuda")
+    rp, ci, M = g["rowptr"], g["colind"], g["M"]
+    deg = rp[1:] - rp[:-1]
+    assert int(deg.max()) > 20000
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    for N in (128, 32):
+        Bi = torch.randint(-4, 5, (g["K"], N), generator=gen, device="cuda", dtype=torch.int32)
+        ref = _exact_reference(rp, ci, None, Bi, chunk=16)
+        assert torch.equal(spmm.csr_spmm_no_edge_value(rp, ci, Bi.float()), ref), N
