@@ -46,6 +46,7 @@ EXPORTS = [
     "gespmm_csr2csc_workspace_bytes",
     "gespmm_csr2csc_f32",
     "gespmm_mtx_read",
+    "gespmm_mtx_read_cached",
     "gespmm_mtx_free",
     "gespmm_coo_to_csr",
     "gespmm_row_partition",
@@ -98,6 +99,8 @@ def _load():
     lib.gespmm_csr2csc_f32.argtypes = [p, p, p, p, p, p, c_int64, c_int64, c_int64, p, p]
     lib.gespmm_mtx_read.restype = c_int
     lib.gespmm_mtx_read.argtypes = [c_char_p, POINTER(Coo)]
+    lib.gespmm_mtx_read_cached.restype = c_int
+    lib.gespmm_mtx_read_cached.argtypes = [c_char_p, c_char_p, POINTER(Coo)]
     lib.gespmm_mtx_free.restype = None
     lib.gespmm_mtx_free.argtypes = [POINTER(Coo)]
     lib.gespmm_coo_to_csr.restype = c_int

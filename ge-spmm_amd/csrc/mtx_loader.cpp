@@ -20,6 +20,9 @@
 // block, tokens are parsed in place, and ordering is an LSD radix sort on a
 // packed 64-bit (row, col) key — O(nnz), stable, no per-entry allocation.
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cctype>
 #include <cstdint>
 #include <cstdio>
@@ -257,6 +260,61 @@ int gespmm_mtx_read(const char* path, gespmm_coo* out) {
     out->row = orow;
     out->col = ocol;
     out->val = oval;
+    return 0;
+}
+
+int gespmm_mtx_read_cached(const char* path, const char* cache_dir, gespmm_coo* out) {
+    if (!path || !out) return GESPMM_EINVAL;
+    if (!cache_dir) return gespmm_mtx_read(path, out);
+    struct stat st;
+    if (stat(path, &st) != 0) return GESPMM_EIO;
+    const char* base = strrchr(path, '/');
+    base = base ? base + 1 : path;
+    char name[4096];
+    snprintf(name, sizeof name, "%s/%s.%lld.%lld.gespmm-coo", cache_dir, base, (long long)st.st_size,
+             (long long)st.st_mtime);
+    struct Header {
+        char magic[8];
+        int32_t nrows, ncols;
+        int64_t nnz;
+    } h;
+    if (FILE* f = fopen(name, "rb")) {
+        memset(out, 0, sizeof *out);
+        bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "GESPMM01", 8) == 0 && h.nnz >= 0;
+        if (ok) {
+            const size_t n = (size_t)h.nnz, cap = n ? n : 1;
+            out->row = (int32_t*)malloc(cap * 4);
+            out->col = (int32_t*)malloc(cap * 4);
+            out->val = (float*)malloc(cap * 4);
+            ok = out->row && out->col && out->val && fread(out->row, 4, n, f) == n && fread(out->col, 4, n, f) == n &&
+                 fread(out->val, 4, n, f) == n;
+            if (ok) {
+                out->nrows = h.nrows;
+                out->ncols = h.ncols;
+                out->nnz = h.nnz;
+            } else {
+                gespmm_mtx_free(out);
+            }
+        }
+        fclose(f);
+        if (ok) return 0;  // a damaged cache file falls through to a fresh parse
+    }
+    const int rc = gespmm_mtx_read(path, out);
+    if (rc != 0) return rc;
+    char tmp[4200];
+    snprintf(tmp, sizeof tmp, "%s.tmp%ld", name, (long)getpid());
+    if (FILE* f = fopen(tmp, "wb")) {  // best effort: an unwritable cache directory is not an error
+        memcpy(h.magic, "GESPMM01", 8);
+        h.nrows = out->nrows;
+        h.ncols = out->ncols;
+        h.nnz = out->nnz;
+        const size_t n = (size_t)out->nnz;
+        const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(out->row, 4, n, f) == n &&
+                        fwrite(out->col, 4, n, f) == n && fwrite(out->val, 4, n, f) == n;
+        fclose(f);
+        if (ok) rename(tmp, name);
+        else remove(tmp);
+    }
     return 0;
 }
 

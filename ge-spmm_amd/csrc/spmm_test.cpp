@@ -32,6 +32,7 @@
 //   --cpu-baseline  time that CPU loop (1 thread) and print its GFLOP/s
 //   --out path      CSV side file                     (default spmm_test_out.out)
 //   --no-vendor     skip the rocSPARSE comparison column
+//   --cache dir     keep the parsed matrix as a binary file in `dir` and reuse it next time
 //
 // There is no CPU fallback: without a HIP device the driver fails with EXIT_FAILURE.
 
@@ -205,6 +206,7 @@ int main(int argc, char** argv) {
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
     const char* mtx_path = nullptr;
+    const char* cache_dir = nullptr;
     int positional = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -224,6 +226,7 @@ int main(int argc, char** argv) {
         else if (a == "--cpu-baseline") cpu_baseline = true;
         else if (a == "--use-values") use_values = true;
         else if (a == "--no-vendor") vendor = false;
+        else if (a == "--cache") cache_dir = next("--cache");
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
@@ -236,7 +239,7 @@ int main(int argc, char** argv) {
 
     g.fpo = fopen(out_path, "a");
     printf("reading file ...\n");
-    int rc = gespmm_mtx_read(mtx_path, &g.coo);
+    int rc = gespmm_mtx_read_cached(mtx_path, cache_dir, &g.coo);
     if (rc == GESPMM_EIO) {
         printf("File %s not found", mtx_path);
         g.release();

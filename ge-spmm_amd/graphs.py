@@ -37,11 +37,16 @@ SPECS = {
 
 # ----------------------------------------------------------------------------- MatrixMarket via the C ABI
 
-def read_mtx(path):
+def read_mtx(path, cache_dir=None):
     """Returns dict(nrows, ncols, nnz, row, col, val) with numpy arrays (0-based,
-    sorted by (row, col); symmetric files expanded, self-loops/duplicates dropped)."""
+    sorted by (row, col); symmetric files expanded, self-loops/duplicates dropped).
+    With ``cache_dir`` the parsed result is kept there as a binary file and reused."""
     coo = Coo()
-    check(lib.gespmm_mtx_read(str(path).encode(), ctypes.byref(coo)), "gespmm_mtx_read(%s)" % path)
+    if cache_dir is None:
+        check(lib.gespmm_mtx_read(str(path).encode(), ctypes.byref(coo)), "gespmm_mtx_read(%s)" % path)
+    else:
+        check(lib.gespmm_mtx_read_cached(str(path).encode(), str(cache_dir).encode(), ctypes.byref(coo)),
+              "gespmm_mtx_read_cached(%s)" % path)
     try:
         n = int(coo.nnz)
         if n:

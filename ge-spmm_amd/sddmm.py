@@ -9,7 +9,7 @@ reference the feature width is D1.size(1) and, for the CSR form, M = D1.size(0).
 import torch
 
 from ._lib import check, lib
-from .spmm import _need, _ptr, _same_device, _stream
+from .spmm import _need, _on_device, _ptr, _same_device, _stream
 
 
 def _checked(idx0, name0, colind, D1, D2):
@@ -28,7 +28,7 @@ def coo_sddmm(rowind, colind, D1, D2):
     if colind.numel() != nnz:
         raise ValueError("rowind and colind must have the same length")
     out = torch.empty((nnz,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.gespmm_sddmm_coo_f32(_ptr(rowind), _ptr(colind), _ptr(D1), _ptr(D2), _ptr(out), nnz,
                                       D1.shape[1], _stream(dev))
     check(rc, "gespmm_sddmm_coo_f32")
@@ -42,7 +42,7 @@ def csr_sddmm(rowptr, colind, D1, D2):
         raise ValueError("rowptr must have D1.size(0)+1 entries")
     nnz = colind.numel()
     out = torch.empty((nnz,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.gespmm_sddmm_csr_f32(_ptr(rowptr), _ptr(colind), _ptr(D1), _ptr(D2), _ptr(out), M, nnz,
                                       D1.shape[1], _stream(dev))
     check(rc, "gespmm_sddmm_csr_f32")

@@ -48,6 +48,25 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context
+    manager costs ~3 us per op call; the common case needs nothing)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def _make_cfg(cfg):
     if cfg is None:
         return None
@@ -80,7 +99,7 @@ def _spmm(rowptr, colind, values, dense, variant, cfg, out):
         if tuple(out.shape) != (M, N) or out.device != dev:
             raise ValueError("out must be f32[M, N] on the same device")
     c = _make_cfg(cfg)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.gespmm_csr_spmm_f32_cfg(_ptr(rowptr), _ptr(colind), _ptr(values) if values is not None else None,
                                          _ptr(dense), _ptr(out), M, K, N, nnz, int(variant),
                                          ctypes.byref(c) if c is not None else None, _stream(dev))
@@ -111,7 +130,7 @@ def csr_spmm_max(rowptr, colind, dense, empty_value=-10000.0, variant=_lib.VARIA
     M = rowptr.numel() - 1
     K, N = dense.shape
     out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.gespmm_csr_spmm_max_f32(_ptr(rowptr), _ptr(colind), _ptr(dense), _ptr(out), M, K, N,
                                          colind.numel(), float(empty_value), int(variant), _stream(dev))
     check(rc, "gespmm_csr_spmm_max_f32")
@@ -135,7 +154,7 @@ def csr2csc(rowptr, colind, colptr, rowind, csr_data):
     if rowind.numel() != nnz or csr_data.numel() != nnz:
         raise ValueError("rowind and csr_data must have nnz entries")
     out = torch.empty((nnz,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws_bytes = lib.gespmm_csr2csc_workspace_bytes(M, K, nnz)
         if ws_bytes < 0:
             check(int(ws_bytes), "gespmm_csr2csc_workspace_bytes")

@@ -17,7 +17,7 @@
  *   gespmm_sddmm_coo_f32     <- sddmm_cuda_coo()              pytorch-custom/sddmm.cu:427-457
  *   gespmm_sddmm_csr_f32     <- sddmm_cuda_csr()              pytorch-custom/sddmm.cu:459-484
  *   gespmm_csr2csc_f32       <- csr2csc_cuda()/csr2cscKernel  pytorch-custom/spmm_kernel.cu:381-476
- *   gespmm_mtx_read / _free  <- readMtx<float>()              util/util.hpp:286-333 (+ mmio.hpp:215,308)
+ *   gespmm_mtx_read[_cached] / _free  <- readMtx<float>()     util/util.hpp:286-333 (+ mmio.hpp:215,308)
  *   gespmm_coo_to_csr        <- inline COO->CSR               spmm_test.cu:557-581
  *   gespmm_row_partition     <- (new; north_star multi-GPU)   no reference counterpart
  *
@@ -193,6 +193,15 @@ typedef struct gespmm_coo {
 
 int  gespmm_mtx_read(const char* path, gespmm_coo* out);
 void gespmm_mtx_free(gespmm_coo* coo);
+
+/*
+ * Same result through a binary cache: the parsed, expanded and sorted COO of `path`
+ * is stored as `<cache_dir>/<basename>.<bytes>.<mtime>.gespmm-coo` on the first read
+ * and read back (one fread per array) afterwards; a changed file gets a new cache
+ * name. cache_dir == NULL behaves like gespmm_mtx_read. (The reference re-parses the
+ * text with fscanf on every run, util.hpp:104-216 — seconds for 10^7-entry files.)
+ */
+int  gespmm_mtx_read_cached(const char* path, const char* cache_dir, gespmm_coo* out);
 
 /*
  * COO (any order) -> CSR by counting sort on the row, keeping the input order

@@ -136,3 +136,40 @@ def test_row_partition_properties(pkg, bundled):
     assert cut[0] == 0 and cut[-1] == 5 and np.all(np.diff(cut) >= 0)
     empty = np.zeros(6, dtype=np.int32)
     assert graphs.row_partition(empty, 3)[-1] == 5
+
+
+def test_binary_cache_round_trip(pkg, tmp_path):
+    import shutil
+    import time
+
+    from gespmm_amd import _lib, graphs
+
+    src = tmp_path / "pubmed.mtx"
+    shutil.copy(os.path.join(GOLDEN, "pubmed.mtx"), src)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    t0 = time.perf_counter()
+    a = graphs.read_mtx(src, cache_dir=cache)
+    t_parse = time.perf_counter() - t0
+    files = list(cache.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("pubmed.mtx.") and files[0].name.endswith(".gespmm-coo")
+    t0 = time.perf_counter()
+    b = graphs.read_mtx(src, cache_dir=cache)
+    t_cached = time.perf_counter() - t0
+    ref = graphs.read_mtx(src)
+    for k in ("nrows", "ncols", "nnz"):
+        assert a[k] == b[k] == ref[k]
+    for k in ("row", "col", "val"):
+        assert np.array_equal(a[k], ref[k]) and np.array_equal(b[k], ref[k])
+    assert t_cached < t_parse
+    # a changed file must not be served from the old cache
+    with open(src, "a") as f:
+        f.write("\n")
+    os.utime(src, (time.time() + 5, time.time() + 5))
+    graphs.read_mtx(src, cache_dir=cache)
+    assert len(list(cache.iterdir())) == 2
+    # a damaged cache file is ignored (fresh parse), an unwritable directory is not an error
+    files[0].write_bytes(b"garbage")
+    assert graphs.read_mtx(os.path.join(GOLDEN, "cora.mtx"), cache_dir=tmp_path / "does_not_exist")["nnz"] == 10556
+    with pytest.raises(_lib.GespmmError):
+        graphs.read_mtx(tmp_path / "missing.mtx", cache_dir=cache)
