@@ -23,9 +23,7 @@ NUM_VARIANTS = 6
 FLAG_NO_XCD_REMAP = 0x1
 FLAG_NT_STORE = 0x2
 FLAG_FORCE_IDX64 = 0x4
-FLAG_ROW_PER_GROUP = 0x8
 FLAG_BATCH_STREAM = 0x20
-FLAG_CACHED_CSR = 0x40
 FLAG_SEG_STREAM = 0x80
 FLAG_STRICT_ORDER = 0x100
 FLAG_SPLIT_LONG_ROWS = 0x200

@@ -83,8 +83,8 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     hipError_t e;
     a.rpw = sel.geo.rows_per_group;
     if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);
-    else if (sel.variant == GESPMM_VARIANT_NAIVE || (flags & gespmm::kFlagRowPerGroup))
-        e = gespmm::launch_spmm_rowgroup(a, sel.geo, st);
+    else if (sel.variant == GESPMM_VARIANT_NAIVE)
+        e = gespmm::launch_spmm_naive(a, sel.geo, st);
     else if (sel.geo.slab_blocked && reduce == gespmm::kReduceSum) {
         e = gespmm::launch_spmm_slabblocked(a, sel.geo, st);
     } else {

@@ -39,7 +39,6 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     if (variant == GESPMM_VARIANT_AUTO) variant = auto_variant(M, nnz, N);
     Geometry g;
     g.reduce = kReduceSum;
-    g.crc = variant != GESPMM_VARIANT_NAIVE;
     g.idx64 = ((flags & kFlagForceIdx64) != 0) || ((uint64_t)K * (uint64_t)N * 4ull >= (1ull << 32));
     g.strips = 1;
     switch (variant) {

@@ -19,7 +19,6 @@ constexpr int kFlagNoXcdRemap = 0x1;  // == GESPMM_FLAG_NO_XCD_REMAP
 constexpr int kFlagNtStore = 0x2;     // == GESPMM_FLAG_NT_STORE
 constexpr int kFlagForceIdx64 = 0x4;  // == GESPMM_FLAG_FORCE_IDX64
 constexpr int kFlagShallowUnroll = 0x10; // == GESPMM_FLAG_SHALLOW_UNROLL
-constexpr int kFlagCachedCsr = 0x40;     // == GESPMM_FLAG_CACHED_CSR
 constexpr int kFlagBatchStream = 0x20;   // == GESPMM_FLAG_BATCH_STREAM (force the batch-stream kernel)
 constexpr int kFlagStrictOrder = 0x100;  // == GESPMM_FLAG_STRICT_ORDER (never split long rows)
 constexpr int kFlagSplitLongRows = 0x200; // == GESPMM_FLAG_SPLIT_LONG_ROWS (always run the long-row pass)
@@ -28,7 +27,6 @@ constexpr int64_t kLongRowMinNnz = 1 << 23;  // auto: only matrices this large g
 constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force the cache-blocked path)
 constexpr int kFlagNoSlabBlocked = 0x800; // == GESPMM_FLAG_NO_SLAB_BLOCKED
 constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
-constexpr int kFlagRowPerGroup = 0x8; // == GESPMM_FLAG_ROW_PER_GROUP (first-generation CRC kernel)
 
 struct SpmmArgs {
     const int32_t* rowptr;
@@ -56,7 +54,6 @@ struct Geometry {
     int group;    // W: lanes per row (4..64)
     int rows_per_wave;  // batch-stream kernel: consecutive rows owned by one wavefront
     int rows_per_group; // segmented-stream kernel: consecutive rows owned by one lane group
-    bool crc;     // LDS-staged CSR tiles (variants 1-4) vs naive (variant 0)
     bool idx64;   // 64-bit byte offsets into B
     bool segmented;  // segmented-stream kernel (else batch-stream)
     bool slab_blocked;     // dense graph: one launch per column slab (cache blocking)
@@ -67,7 +64,7 @@ struct Geometry {
     int reduce;   // kReduceSum / kReduceMax
 };
 
-hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_naive(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, hipStream_t st);

@@ -95,11 +95,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 
-// CSR stream loads. Non-temporal by default (each entry is used once per launch); the
-// plain form keeps them in L2 / Infinity Cache across launches (GESPMM_FLAG_CACHED_CSR).
+// CSR stream loads are non-temporal: each entry is used once per launch. (Plain loads
+// were measured too — no gain, profiles/r01/kernel_generations_cache_regimes.log.)
 template <typename T>
-__device__ __forceinline__ T load_csr(const T* p, bool cached) {
-    return cached ? *p : __builtin_nontemporal_load(p);
+__device__ __forceinline__ T load_csr(const T* p) {
+    return __builtin_nontemporal_load(p);
 }
 
 template <int RED, bool VALUED>
@@ -113,160 +113,90 @@ __device__ __forceinline__ float combine(float acc, float a, float b) {
     }
 }
 
-constexpr int unroll_for(int cf) { return cf >= 8 ? 2 : (cf >= 4 ? 4 : 8); }
+// ----------------------------------------------------------------------------- naive kernel (variant 0)
+//
+// The reference's method 0 (spmm_test.cu:64-95) on the wave64 geometry: one row per lane
+// group, every lane reads colind/val of its row itself (lanes of a group hit the same
+// address, one broadcast transaction), no LDS staging. Kept as the baseline variant.
 
-// ----------------------------------------------------------------------------- CRC (+CWM) kernel
-
-template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC>
-__global__ __launch_bounds__(kThreads) void spmm_rowgroup_kernel(SpmmArgs a) {
-    constexpr int G = 64 / W;  // rows per wavefront
-    constexpr int U = unroll_for(V * S);
+template <int V, int S, int W, bool VALUED, bool IDX64>
+__global__ __launch_bounds__(kThreads) void spmm_naive_kernel(SpmmArgs a) {
+    constexpr int G = 64 / W;
+    constexpr int U = (V * S >= 8) ? 2 : ((V * S >= 4) ? 4 : 8);
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
-
-    __shared__ off_t s_off[CRC ? kWaves : 1][CRC ? kTile : 1];
-    __shared__ float s_val[(CRC && VALUED) ? kWaves : 1][(CRC && VALUED) ? kTile : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane / W;
     const int l = lane % W;
-
     const int nitems = a.nblk * a.ntile;
     const int item = (a.flags & kFlagNoXcdRemap) ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, nitems);
     const int tile = item % a.ntile;
     const int rb = item / a.ntile;
-
-    const int row0 = (rb * kWaves + wave) * G;  // first row of this wavefront
-    if (row0 >= a.M) return;                    // whole wavefront leaves together
+    const int row0 = (rb * kWaves + wave) * G;
+    if (row0 >= a.M) return;
     const int row = row0 + g;
     const int col0 = tile * (W * V * S) + l * V;
-
-    bool colok[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) colok[s] = (col0 + s * W * V) < a.N;
     const bool rowok = row < a.M;
-
     int lb = 0, hb = 0;
     if (rowok) {
         lb = a.rowptr[row];
         hb = a.rowptr[row + 1];
     }
-    // CSR range covered by the whole wavefront (its G rows are consecutive).
-    const int lastg = (a.M - row0 < G ? a.M - row0 : G) - 1;
-    const int wb = __builtin_amdgcn_readfirstlane(lb);
-    const int we = __builtin_amdgcn_readlane(hb, lastg * W);
-    if constexpr (G == 1) {  // one row per wavefront: bounds are wave-uniform, keep them scalar
-        lb = wb;
-        hb = we;
+    bool colok[S];
+    off_t cbytes[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        colok[s] = (col0 + s * W * V) < a.N;
+        cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
     }
-    const float init = (RED == kReduceMax) ? a.empty : 0.0f;
+    const char* Bbase = reinterpret_cast<const char*>(a.B);
+    const off_t rowbytes = (off_t)a.N * 4u;
     float acc[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc[s][i] = init;
+        for (int i = 0; i < V; ++i) acc[s][i] = 0.0f;
 
-    // Lanes/strips that fall outside N in the last column tile gather from column 0
-    // instead (always valid, same cache line as lane 0) and simply skip the store:
-    // the inner loop carries no per-lane predicate and stays wave-uniform for G == 1.
-    // Addresses are formed as (uniform base) + (off_t byte offset): with 32-bit
-    // offsets that is the SGPR-base + 32-bit-VGPR-offset form of global_load.
-    const char* Bbase = reinterpret_cast<const char*>(a.B);
-    off_t cbytes[S];
+    int k = lb;
+    for (; k + U <= hb; k += U) {
+        off_t off[U];
+        float v[U];
+        float b[U][S][V];
 #pragma unroll
-    for (int s = 0; s < S; ++s) cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
-    const off_t rowbytes = (off_t)a.N * 4u;
-
-    auto gather_steps = [&](auto fetch, int kb, int ke) {
-        // fetch(k, off, v): entry k -> byte offset of its B row, its value
-        int k = kb;
-        for (; k + U <= ke; k += U) {
-            off_t off[U];
-            float v[U];
-            float b[U][S][V];
-#pragma unroll
-            for (int j = 0; j < U; ++j) fetch(k + j, off[j], v[j]);
-#pragma unroll
-            for (int j = 0; j < U; ++j)
-#pragma unroll
-                for (int s = 0; s < S; ++s) load_vec<V>(b[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
-#pragma unroll
-            for (int j = 0; j < U; ++j)
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], b[j][s][i]);
+        for (int j = 0; j < U; ++j) {
+            off[j] = (off_t)(uint32_t)a.colind[k + j] * rowbytes;
+            v[j] = VALUED ? a.val[k + j] : 1.0f;
         }
-        for (; k < ke; ++k) {
-            off_t off;
-            float v;
-            float b[S][V];
-            fetch(k, off, v);
 #pragma unroll
-            for (int s = 0; s < S; ++s) load_vec<V>(b[s], Bbase + (off_t)(off + cbytes[s]));
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int s = 0; s < S; ++s) load_vec<V>(b[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+#pragma unroll
+        for (int j = 0; j < U; ++j)
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v, b[s][i]);
-        }
-    };
-
-    if constexpr (CRC) {
-        // Register prefetch of the first tile.
-        int pc = 0;
-        float pv = 0.0f;
-        {
-            const int p = wb + lane;
-            if (p < we) {
-                pc = __builtin_nontemporal_load(a.colind + p);
-                if constexpr (VALUED) pv = __builtin_nontemporal_load(a.val + p);
-            }
-        }
-        for (int cb = wb; cb < we; cb += kTile) {
-            s_off[wave][lane] = (off_t)(uint32_t)pc * rowbytes;
-            if constexpr (VALUED) s_val[wave][lane] = pv;
-            {  // prefetch the next tile while this one is consumed
-                const int p = cb + kTile + lane;
-                if (p < we) {
-                    pc = __builtin_nontemporal_load(a.colind + p);
-                    if constexpr (VALUED) pv = __builtin_nontemporal_load(a.val + p);
-                }
-            }
-            wave_lds_sync();
-            const int kb = (lb > cb ? lb : cb) - cb;
-            const int ke = (hb < cb + kTile ? hb : cb + kTile) - cb;
-            gather_steps(
-                [&](int k, off_t& off, float& v) {
-                    off = s_off[wave][k];
-                    if constexpr (VALUED) v = s_val[wave][k];
-                    else v = 1.0f;
-                },
-                kb, ke);
-            wave_lds_sync();
-        }
-    } else {
-        // Naive variant (reference method 0): every lane reads colind/val itself.
-        gather_steps(
-            [&](int k, off_t& off, float& v) {
-                off = (off_t)(uint32_t)a.colind[k] * rowbytes;
-                if constexpr (VALUED) v = a.val[k];
-                else v = 1.0f;
-            },
-            lb, hb);
+                for (int i = 0; i < V; ++i) acc[s][i] = combine<kReduceSum, VALUED>(acc[s][i], v[j], b[j][s][i]);
     }
-
-    if (rowok) {
-        float* Crow = a.C + (size_t)row * (size_t)a.N + col0;
-        const bool nts = (a.flags & kFlagNtStore) != 0;
+    for (; k < hb; ++k) {
+        const off_t off = (off_t)(uint32_t)a.colind[k] * rowbytes;
+        const float v = VALUED ? a.val[k] : 1.0f;
+        float b[S][V];
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_vec<V>(b[s], Bbase + (off_t)(off + cbytes[s]));
 #pragma unroll
         for (int s = 0; s < S; ++s)
-            if (colok[s]) {
-                if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
-                else store_vec<V, false>(Crow + s * (W * V), acc[s]);
-            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[s][i] = combine<kReduceSum, VALUED>(acc[s][i], v, b[s][i]);
+    }
+    if (rowok) {
+        float* Crow = a.C + (size_t)row * (size_t)a.N + col0;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (colok[s]) store_vec<V, false>(Crow + s * (W * V), acc[s]);
     }
 }
-
 
 // ----------------------------------------------------------------------------- streaming CRC (+CWM) kernel
 //
@@ -337,12 +267,11 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
     // Tile stream state: `t0` = CSR position of the tile resident in LDS.
     int pc = 0;
     float pv = 0.0f;
-    const bool cached_csr = (a.flags & kFlagCachedCsr) != 0;
     auto fetch_tile_regs = [&](int base) {
         const int p = base + lane;
         if (p < we) {
-            pc = load_csr(a.colind + p, cached_csr);
-            if constexpr (VALUED) pv = load_csr(a.val + p, cached_csr);
+            pc = load_csr(a.colind + p);
+            if constexpr (VALUED) pv = load_csr(a.val + p);
         }
     };
     auto publish_tile = [&]() {
@@ -525,7 +454,6 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
     const float init = (RED == kReduceMax) ? a.empty : 0.0f;
     const bool nts = (a.flags & kFlagNtStore) != 0;
 
-    const bool cached_csr = (a.flags & kFlagCachedCsr) != 0;
     // Per-group tile stream.
     int pc[E];
     float pv[E];
@@ -539,8 +467,8 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
         for (int e = 0; e < E; ++e) {
             const int p = base + l * E + e;
             if (p < ge) {
-                pc[e] = load_csr(a.colind + p, cached_csr);
-                if constexpr (VALUED) pv[e] = load_csr(a.val + p, cached_csr);
+                pc[e] = load_csr(a.colind + p);
+                if constexpr (VALUED) pv[e] = load_csr(a.val + p);
             }
         }
     };
@@ -1073,8 +1001,8 @@ __global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
 
 // ----------------------------------------------------------------------------- host-side launch table
 
-template <int V, int S, int W, bool VALUED, bool IDX64, int RED, bool CRC>
-static hipError_t launch_rowgroup(const SpmmArgs& a, hipStream_t st) {
+template <int V, int S, int W, bool VALUED, bool IDX64>
+static hipError_t launch_naive(const SpmmArgs& a, hipStream_t st) {
     constexpr int G = 64 / W;
     SpmmArgs args = a;
     args.nblk = (int)(((int64_t)a.M + kWaves * G - 1) / (kWaves * G));
@@ -1082,57 +1010,43 @@ static hipError_t launch_rowgroup(const SpmmArgs& a, hipStream_t st) {
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
     if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
-    dim3 grid((unsigned)nitems), block(kThreads);
-    hipLaunchKernelGGL((spmm_rowgroup_kernel<V, S, W, VALUED, IDX64, RED, CRC>), grid, block, 0, st, args);
+    hipLaunchKernelGGL((spmm_naive_kernel<V, S, W, VALUED, IDX64>), dim3((unsigned)nitems), dim3(kThreads), 0, st,
+                       args);
     return hipGetLastError();
 }
 
-template <int V, int S, bool VALUED, bool IDX64, int RED, bool CRC>
-static hipError_t dispatch_w(const SpmmArgs& a, int W, hipStream_t st) {
+template <int V, int S, bool VALUED, bool IDX64>
+static hipError_t naive_w(const SpmmArgs& a, int W, hipStream_t st) {
     switch (W) {
-        case 4: return launch_rowgroup<V, S, 4, VALUED, IDX64, RED, CRC>(a, st);
-        case 8: return launch_rowgroup<V, S, 8, VALUED, IDX64, RED, CRC>(a, st);
-        case 16: return launch_rowgroup<V, S, 16, VALUED, IDX64, RED, CRC>(a, st);
-        case 32: return launch_rowgroup<V, S, 32, VALUED, IDX64, RED, CRC>(a, st);
-        case 64: return launch_rowgroup<V, S, 64, VALUED, IDX64, RED, CRC>(a, st);
+        case 4: return launch_naive<V, S, 4, VALUED, IDX64>(a, st);
+        case 8: return launch_naive<V, S, 8, VALUED, IDX64>(a, st);
+        case 16: return launch_naive<V, S, 16, VALUED, IDX64>(a, st);
+        case 32: return launch_naive<V, S, 32, VALUED, IDX64>(a, st);
+        case 64: return launch_naive<V, S, 64, VALUED, IDX64>(a, st);
     }
     return hipErrorInvalidValue;
 }
 
-template <bool VALUED, bool IDX64, int RED, bool CRC>
-static hipError_t dispatch_vs(const SpmmArgs& a, int V, int S, int W, hipStream_t st) {
-    if (S == 2) {
-        if (V == 4) return dispatch_w<4, 2, VALUED, IDX64, RED, CRC>(a, W, st);
+template <bool VALUED, bool IDX64>
+static hipError_t naive_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
+    if (g.strips == 2) {
+        if (g.vec == 4) return naive_w<4, 2, VALUED, IDX64>(a, g.group, st);
         return hipErrorInvalidValue;
     }
-    switch (V) {
-        case 1: return dispatch_w<1, 1, VALUED, IDX64, RED, CRC>(a, W, st);
-        case 2: return dispatch_w<2, 1, VALUED, IDX64, RED, CRC>(a, W, st);
-        case 4: return dispatch_w<4, 1, VALUED, IDX64, RED, CRC>(a, W, st);
+    switch (g.vec) {
+        case 1: return naive_w<1, 1, VALUED, IDX64>(a, g.group, st);
+        case 2: return naive_w<2, 1, VALUED, IDX64>(a, g.group, st);
+        case 4: return naive_w<4, 1, VALUED, IDX64>(a, g.group, st);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_spmm_rowgroup(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+hipError_t launch_spmm_naive(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+    if (geo.reduce != kReduceSum) return hipErrorInvalidValue;
     const bool valued = a.val != nullptr;
-    if (geo.reduce == kReduceMax) {
-        // max reducer exists for the unweighted CRC path only (binary_reduce_max.cu).
-        if (valued || !geo.crc) return hipErrorInvalidValue;
-        if (geo.idx64) return dispatch_vs<false, true, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, st);
-        return dispatch_vs<false, false, kReduceMax, true>(a, geo.vec, geo.strips, geo.group, st);
-    }
-#define GESPMM_DISPATCH(VAL, I64, CRCF) \
-    return dispatch_vs<VAL, I64, kReduceSum, CRCF>(a, geo.vec, geo.strips, geo.group, st)
-    if (geo.crc) {
-        if (valued) { if (geo.idx64) GESPMM_DISPATCH(true, true, true); else GESPMM_DISPATCH(true, false, true); }
-        else        { if (geo.idx64) GESPMM_DISPATCH(false, true, true); else GESPMM_DISPATCH(false, false, true); }
-    } else {
-        if (valued) { if (geo.idx64) GESPMM_DISPATCH(true, true, false); else GESPMM_DISPATCH(true, false, false); }
-        else        { if (geo.idx64) GESPMM_DISPATCH(false, true, false); else GESPMM_DISPATCH(false, false, false); }
-    }
-#undef GESPMM_DISPATCH
+    if (valued) return geo.idx64 ? naive_vs<true, true>(a, geo, st) : naive_vs<true, false>(a, geo, st);
+    return geo.idx64 ? naive_vs<false, true>(a, geo, st) : naive_vs<false, false>(a, geo, st);
 }
-
 
 template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
 static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {

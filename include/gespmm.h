@@ -133,15 +133,12 @@ typedef struct gespmm_launch_cfg {
 #define GESPMM_FLAG_NT_STORE       0x2  /* non-temporal stores of C */
 #define GESPMM_FLAG_FORCE_IDX64    0x4  /* 64-bit B offsets even when K*N*4 < 2^32 */
 #define GESPMM_FLAG_SHALLOW_UNROLL 0x10 /* gather 4 instead of 8 B rows per step (fewer VGPRs) */
-#define GESPMM_FLAG_CACHED_CSR     0x40 /* plain (cacheable) loads of colind/val instead of non-temporal */
 #define GESPMM_FLAG_BATCH_STREAM   0x20 /* force the batch-stream kernel (rows walked 64/group at a time) */
 #define GESPMM_FLAG_STRICT_ORDER   0x100 /* never split long rows: every row is one strict CSR-order chain */
 #define GESPMM_FLAG_SPLIT_LONG_ROWS 0x200 /* run the long-row pass regardless of matrix size */
 #define GESPMM_FLAG_SLAB_BLOCKED   0x400 /* force the cache-blocked path (one launch per column slab of B) */
 #define GESPMM_FLAG_NO_SLAB_BLOCKED 0x800 /* never use it */
 #define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (default for group >= 32) */
-#define GESPMM_FLAG_ROW_PER_GROUP  0x8  /* first-generation CRC kernel (one row batch per wavefront);
-                                           kept for A/B measurements, same results */
 
 int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const float* val,
                             const float* B, float* C,

@@ -29,14 +29,11 @@ val = torch.rand(8 * M, device=dev) - 0.5
 C = torch.empty((M, N), device=dev)
 F = _lib
 cfgs = [("seg g4", dict(rows_per_wave=4, flags=0)),
-        ("seg g4 cachedcsr", dict(rows_per_wave=4, flags=F.FLAG_CACHED_CSR)),
-        ("seg g8 cachedcsr", dict(rows_per_wave=8, flags=F.FLAG_CACHED_CSR)),
-        ("seg g16 cachedcsr", dict(rows_per_wave=16, flags=F.FLAG_CACHED_CSR)),
-        ("seg g4 cachedcsr nt", dict(rows_per_wave=4, flags=F.FLAG_CACHED_CSR | F.FLAG_NT_STORE)),
-        ("seg g4 cachedcsr u4", dict(rows_per_wave=4, flags=F.FLAG_CACHED_CSR | F.FLAG_SHALLOW_UNROLL)),
-        ("bs r8", dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM)),
-        ("bs r8 cachedcsr", dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM | F.FLAG_CACHED_CSR)),
-        ("old", dict(flags=F.FLAG_ROW_PER_GROUP))]
+        ("seg g8", dict(rows_per_wave=8, flags=0)),
+        ("seg g16", dict(rows_per_wave=16, flags=0)),
+        ("seg g4 nt", dict(rows_per_wave=4, flags=F.FLAG_NT_STORE)),
+        ("seg g4 u4", dict(rows_per_wave=4, flags=F.FLAG_SHALLOW_UNROLL)),
+        ("bs r8", dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM))]
 for K in (2048, 334863, 1 << 22):
     B = torch.rand((K, N), device=dev)
     for name, rp, z in (("deg~5.5", rowptr, nnz), ("deg=8 exact", rowptr8, 8 * M)):

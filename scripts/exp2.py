@@ -32,7 +32,7 @@ def run(name, g, Ns):
                            ("bs r8", 3, dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM)),
                            ("bs r8 strict", 3, dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM | F.FLAG_STRICT_ORDER)),
                            ("bs r8 split", 3, dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM | F.FLAG_SPLIT_LONG_ROWS)),
-                           ("old", 3, dict(flags=F.FLAG_ROW_PER_GROUP)), ("v4", 4, None), ("v2", 2, None)]:
+                           ("v4", 4, None), ("v2", 2, None)]:
             us = time_fn(lambda: spmm.csr_spmm(rp, ci, val, B, variant=variant, cfg=cfg, out=C))
             line += " | %s %.0f us (%.2f TF)" % (label, us, 2.0 * nnz * N / us / 1e6)
         print(line); sys.stdout.flush()

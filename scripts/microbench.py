@@ -16,6 +16,7 @@ lib = ctypes.CDLL(so)
 P = ctypes.c_void_p
 lib.mb_stream_read.argtypes = [P, ctypes.c_size_t, P, ctypes.c_int, P]
 lib.mb_row_gather.argtypes = [P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P]
+lib.mb_row_gather128.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P]
 
 
 def timeit(fn, iters=20, warm=3):
@@ -57,4 +58,19 @@ for K in (2048, 8192, 32768, 131072, 334863, 1 << 20, 1 << 22):
             best = us if best is None else min(best, us)
         print("  K=%8d (B %7.1f MB) %-13s: %8.1f us  gather %.2f TB/s" %
               (K, K * 512 / 1e6, tag, best, nidx * 512 / best / 1e6))
+    del B, idx, C
+
+print("== random 128-B row gather (N = 32), nidx = 1 851 744 (237 MB gathered)")
+for K in (8192, 334863, 1 << 22):
+    B = torch.rand((K, 32), device=dev)
+    idx = torch.randint(0, K, (nidx,), device=dev, dtype=torch.int32)
+    C = torch.empty((nidx // 5 + 8, 32), device=dev)
+    for per_store, tag in ((0, "no store"), (8, "store/8 rows")):
+        best = None
+        for blocks in (1024, 2048, 4096, 8192):
+            us = timeit(lambda: lib.mb_row_gather128(P(B.data_ptr()), P(idx.data_ptr()), nidx, per_store,
+                                                     P(C.data_ptr()), blocks, st))
+            best = us if best is None else min(best, us)
+        print("  K=%8d (B %7.1f MB) %-13s: %8.1f us  gather %.2f TB/s" %
+              (K, K * 128 / 1e6, tag, best, nidx * 128 / best / 1e6))
     del B, idx, C

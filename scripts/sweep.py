@@ -84,8 +84,6 @@ def main():
                 for vec, strips, grp in geos:
                     G = 64 // grp
                     base = {"vec": vec, "strips": strips, "group": grp}
-                    cands.append(("V%d S%d W%d old" % (vec, strips, grp), 1,
-                                  dict(base, flags=_lib.FLAG_ROW_PER_GROUP)))
                     for rpw in sorted({G, 8, 16}):  # batch-stream kernel (rows per wavefront)
                         if rpw < G or rpw > 32:
                             continue
@@ -122,7 +120,7 @@ def main():
                 print("== %s N=%d %s  M=%d nnz=%d  alg=%.1f MB  copy(same C+B bytes)=%.1f us (%.0f GB/s)" %
                       (gname, N, "valued" if valued else "unweighted", M, nnz, ab / 1e6, copy_us,
                        8.0 * M * N / copy_us / 1e3))
-                for r in rows[:14] + [r for r in rows[14:] if r["cfg"].startswith("v") or r["cfg"].endswith("old")]:
+                for r in rows[:14] + [r for r in rows[14:] if r["cfg"].startswith("v")]:
                     print("   %-22s %9.1f us (min %9.1f)  %9.1f GFLOP/s  %7.1f GB/s  frac %.3f" %
                           (r["cfg"], r["us_med"], r["us_min"], r["gflops"], r["GBs"], r["frac"]))
                 sys.stdout.flush()
