@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
                                                           int M, int nnz, int N) {
     constexpr int G = 64 / W;
     constexpr int EPW = 64;  // edges per wavefront (CSR form): G edges at a time, EPW/G rounds
+    constexpr int UE = 4;    // edges per lane group per step (COO form)
     using T = typename SdVec<V>::type;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -51,28 +52,61 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
     const int l = lane % W;
 
     if constexpr (!CSR) {
-        const int e = (blockIdx.x * kWaves + wave) * G + g;
-        const bool ok = e < nnz;
-        float part = 0.0f;
-        if (ok) {
-            const int r = rows[e];
-            const int c = colind[e];
-            const float* p1 = D1 + (size_t)r * (size_t)N;
-            const float* p2 = D2 + (size_t)c * (size_t)N;
-            for (int j = l * V; j < N; j += W * V) {
-                const T x = *reinterpret_cast<const T*>(p1 + j);
-                const T y = *reinterpret_cast<const T*>(p2 + j);
+        // UE consecutive edges per lane group: all 2*UE row slices are requested before any
+        // is used (for N <= W*V, i.e. one slice per row), so UE gathers are in flight per
+        // group instead of one.
+        const int ebase = ((blockIdx.x * kWaves + wave) * G + g) * UE;
+        float part[UE];
+        if (N <= W * V) {
+            T x[UE], y[UE];
+            const int j = l * V;
+#pragma unroll
+            for (int u = 0; u < UE; ++u) {
+                const int e = ebase + u;
+                x[u] = T{};
+                y[u] = T{};
+                if (e < nnz && j < N) {
+                    x[u] = *reinterpret_cast<const T*>(D1 + (size_t)rows[e] * (size_t)N + j);
+                    y[u] = *reinterpret_cast<const T*>(D2 + (size_t)colind[e] * (size_t)N + j);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UE; ++u) {
+                part[u] = 0.0f;
                 if constexpr (V == 1) {
-                    part = __builtin_fmaf(x, y, part);
+                    part[u] = __builtin_fmaf(x[u], y[u], part[u]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+                    for (int i = 0; i < V; ++i) part[u] = __builtin_fmaf(x[u][i], y[u][i], part[u]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UE; ++u) {
+                const int e = ebase + u;
+                part[u] = 0.0f;
+                if (e < nnz) {
+                    const float* p1 = D1 + (size_t)rows[e] * (size_t)N;
+                    const float* p2 = D2 + (size_t)colind[e] * (size_t)N;
+                    for (int j = l * V; j < N; j += W * V) {
+                        const T x = *reinterpret_cast<const T*>(p1 + j);
+                        const T y = *reinterpret_cast<const T*>(p2 + j);
+                        if constexpr (V == 1) {
+                            part[u] = __builtin_fmaf(x, y, part[u]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < V; ++i) part[u] = __builtin_fmaf(x[i], y[i], part[u]);
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
-        if (ok && l == 0) out[e] = part;
+        for (int u = 0; u < UE; ++u) {
+#pragma unroll
+            for (int m = W >> 1; m > 0; m >>= 1) part[u] += __shfl_xor(part[u], m, 64);
+            if (l == 0 && ebase + u < nnz) out[ebase + u] = part[u];
+        }
     } else {
         // CSR form: the wavefront owns EPW consecutive edges. ONE global binary search
         // (wave-uniform) finds the row of its first edge; the rows of all its edges then
@@ -132,7 +166,7 @@ static hipError_t sddmm_w(int W, const int32_t* rows, const int32_t* colind, con
 #define GESPMM_SD(WW)                                                                                         \
     case WW: {                                                                                                 \
         constexpr int G = 64 / WW;                                                                             \
-        constexpr int per_wave = CSR ? 64 : G; /* edges per wavefront */                                       \
+        constexpr int per_wave = CSR ? 64 : G * 4; /* edges per wavefront (COO: UE = 4 per group) */                                       \
         const int nblk = (int)(((int64_t)nnz + kWaves * per_wave - 1) / (kWaves * per_wave));                  \
         hipLaunchKernelGGL((sddmm_kernel<V, WW, CSR>), dim3(nblk), dim3(kThreads), 0, st, rows, colind, D1, D2, \
                            out, M, nnz, N);                                                                    \
