@@ -8,6 +8,7 @@ reference the feature width is D1.size(1) and, for the CSR form, M = D1.size(0).
 """
 import torch
 
+from ._ext import ext as _ext
 from ._lib import check, lib
 from .spmm import _need, _on_device, _ptr, _same_device, _stream
 
@@ -23,6 +24,8 @@ def _checked(idx0, name0, colind, D1, D2):
 
 
 def coo_sddmm(rowind, colind, D1, D2):
+    if _ext is not None:
+        return _ext.coo_sddmm(rowind, colind, D1, D2)
     dev = _checked(rowind, "rowind", colind, D1, D2)
     nnz = rowind.numel()
     if colind.numel() != nnz:
@@ -36,6 +39,8 @@ def coo_sddmm(rowind, colind, D1, D2):
 
 
 def csr_sddmm(rowptr, colind, D1, D2):
+    if _ext is not None:
+        return _ext.csr_sddmm(rowptr, colind, D1, D2)
     dev = _checked(rowptr, "rowptr", colind, D1, D2)
     M = D1.shape[0]
     if rowptr.numel() != M + 1:

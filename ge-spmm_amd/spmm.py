@@ -7,7 +7,10 @@
 Same names, argument order and meaning. Where the reference only ``assert``s its
 inputs (compiled out under NDEBUG) these functions raise. Outputs are allocated with
 ``torch.empty`` on ``dense.device`` like spmm_kernel.cu:183,434; kernels run on the
-CURRENT torch stream (the reference uses the legacy default stream). Extra keyword
+CURRENT torch stream (the reference uses the legacy default stream). Calls go through
+the pybind11 extension `_gespmm_torch` (csrc/torch_binding.cpp) when it is built and
+through the ctypes binding of the same C ABI otherwise or when tuning knobs are used;
+both validate identically and neither has a CPU path. Extra keyword
 arguments (``variant``, ``cfg``) expose the C ABI's tuning knobs and default to the
 library's choice.
 """
@@ -16,6 +19,7 @@ import ctypes
 import torch
 
 from . import _lib
+from ._ext import ext as _ext
 from ._lib import LaunchCfg, check, lib
 
 
@@ -111,11 +115,15 @@ def csr_spmm(rowptr, colind, values, dense, variant=_lib.VARIANT_AUTO, cfg=None,
     """C = A @ dense with A = CSR(rowptr, colind, values). Mirrors spmm.cpp:24-43."""
     if values is None:
         raise TypeError("csr_spmm needs edge values; use csr_spmm_no_edge_value for A == 1")
+    if _ext is not None and cfg is None and out is None:
+        return _ext.csr_spmm(rowptr, colind, values, dense, int(variant))
     return _spmm(rowptr, colind, values, dense, variant, cfg, out)
 
 
 def csr_spmm_no_edge_value(rowptr, colind, dense, variant=_lib.VARIANT_AUTO, cfg=None, out=None):
     """C = A @ dense with A == 1 on its pattern. Mirrors spmm.cpp:45-60."""
+    if _ext is not None and cfg is None and out is None:
+        return _ext.csr_spmm_no_edge_value(rowptr, colind, dense, int(variant))
     return _spmm(rowptr, colind, None, dense, variant, cfg, out)
 
 
@@ -123,6 +131,8 @@ def csr_spmm_max(rowptr, colind, dense, empty_value=-10000.0, variant=_lib.VARIA
     """C[r, :] = max over neighbours of dense[col, :] (DGL max reducer,
     binary_reduce_max.cu:182-207; rows without neighbours give ``empty_value``, the
     reference's hard-coded -10000)."""
+    if _ext is not None:
+        return _ext.csr_spmm_max(rowptr, colind, dense, float(empty_value), int(variant))
     _need(rowptr, "rowptr", torch.int32, 1)
     _need(colind, "colind", torch.int32, 1)
     _need(dense, "dense", torch.float32, 2)
@@ -142,6 +152,8 @@ def csr2csc(rowptr, colind, colptr, rowind, csr_data):
     and return the values in CSC order. Mirrors spmm.cpp:70-93 (whose CUDA
     implementation is unusable as shipped: spmm_kernel.cu:386 uses an uninitialised
     cuSPARSE handle). The number of columns is ``colptr.numel() - 1``."""
+    if _ext is not None:
+        return _ext.csr2csc(rowptr, colind, colptr, rowind, csr_data)
     _need(rowptr, "rowptr", torch.int32, 1)
     _need(colind, "colind", torch.int32, 1)
     _need(colptr, "colptr", torch.int32, 1)

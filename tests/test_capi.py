@@ -127,3 +127,23 @@ def test_select_variant(pkg):
     assert spmm.select_variant(1000, 5000, 3) == _lib.VARIANT_CRC
     for n in (1, 2, 3, 16, 41, 128, 500, 512):
         assert 0 <= spmm.select_variant(10, 10, n) <= 4, "auto never picks the tolerance-only variant"
+
+
+def test_torch_extension_module(pkg):
+    """The pybind11 extension (csrc/torch_binding.cpp) mirrors the reference's `spmm` and
+    `sddmm` modules; it validates like the ctypes layer and has no CPU path either."""
+    from gespmm_amd import _ext
+
+    if _ext.ext is None:
+        pytest.skip("extension not built (run __graft_entry__.build())")
+    for name in ("csr_spmm", "csr_spmm_no_edge_value", "csr2csc", "coo_sddmm", "csr_sddmm", "csr_spmm_max"):
+        assert callable(getattr(_ext.ext, name))
+    rp = torch.tensor([0, 1, 2], dtype=torch.int32)
+    ci = torch.tensor([0, 1], dtype=torch.int32)
+    B = torch.ones(2, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _ext.ext.csr_spmm_no_edge_value(rp, ci, B)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _ext.ext.coo_sddmm(ci, ci, B, B)
+    ldd = subprocess.run(["ldd", _ext.EXT_PATH], capture_output=True, text=True).stdout
+    assert "libgespmm.so" in ldd and "oracle" not in ldd

@@ -328,3 +328,28 @@ def test_slab_blocked_path_is_bit_exact(pkg, oracle, bundled):
         cfg = {"vec": vec, "group": group, "slab_rows": 50,
                "flags": _lib.FLAG_SLAB_BLOCKED | _lib.FLAG_FORCE_IDX64}
         assert_bits_equal(run(pkg, G, B, None, 3, cfg), ref, "slab blocked cfg %r" % cfg)
+
+
+def test_extension_and_ctypes_bindings_agree(pkg, oracle, bundled):
+    """Default calls go through the pybind11 extension, calls with tuning knobs through
+    ctypes: same C ABI, same bits, same exception types."""
+    from gespmm_amd import _ext, spmm
+
+    G = bundled["citeseer"]
+    rp, ci = dev_csr(G)
+    B = torch.from_numpy(oracle.hash_B(G["K"], 48, seed=4)).cuda()
+    val = torch.from_numpy(oracle.hash_val(G["nnz"], seed=6)).cuda()
+    a = spmm.csr_spmm(rp, ci, val, B)                       # extension when built
+    b = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0})     # ctypes
+    assert torch.equal(a, b)
+    ref = oracle.spmm(G["rowptr"], G["colind"], val.cpu().numpy(), B.cpu().numpy(), "fma")
+    assert_bits_equal(a.cpu().numpy(), ref, "extension path")
+    if _ext.ext is None:
+        pytest.skip("extension not built")
+    for bad, exc in ((lambda: _ext.ext.csr_spmm_no_edge_value(rp, ci, B.t(), -1), ValueError),
+                     (lambda: _ext.ext.csr_spmm_no_edge_value(rp.long(), ci, B, -1), TypeError),
+                     (lambda: _ext.ext.csr_spmm_no_edge_value(rp.cpu(), ci, B, -1), RuntimeError),
+                     (lambda: _ext.ext.csr_spmm(rp, ci, val[:-1], B, -1), ValueError),
+                     (lambda: _ext.ext.csr_spmm_no_edge_value(rp, ci, B, 17), RuntimeError)):
+        with pytest.raises(exc):
+            bad()
