@@ -6,32 +6,37 @@
 // multiply-add per non-zero (what nvcc emits for `acc += a*b`), rows without
 // non-zeros write 0, C fully overwritten.
 //
-// How it is laid out on CDNA4 (this is a re-design, not a translation of the
-// reference's 32-lane kernels):
+// How it is laid out on CDNA4 (a re-design, not a translation of the reference's
+// 32-lane kernels):
 //
-//  * Row groups. A 64-lane wavefront is split into G = 64/W groups of W lanes;
-//    each group owns one row, each lane owns S strips of V CONTIGUOUS output
-//    columns (one dwordx{V} load / store per strip). The reference's "coarse-
-//    grained warp merging" (CWM, lane owns columns c, c+32, ...) becomes
-//    CF = V*S with contiguous vectors, so a group reads/writes W*V*4 contiguous
-//    bytes of a B/C row per instruction (N=128: W=32,V=4 -> 512 B per half-wave).
-//    W is sized to N, so N=32 runs 8 rows per wavefront instead of idling lanes.
+//  * Row groups. A 64-lane wavefront is split into G = 64/W groups of W lanes; a
+//    group works on one row at a time, each lane owns S strips of V CONTIGUOUS output
+//    columns (one dwordx{V} load / store per strip). The reference's "coarse-grained
+//    warp merging" (CWM, lane owns columns c, c+32, ...) becomes CF = V*S with
+//    contiguous vectors, so a group reads/writes W*V*4 contiguous bytes of a B/C row
+//    per instruction (N=128: W=32, V=4 -> 512 B per half-wave).
 //
-//  * Coalesced Row Caching (CRC) in LDS. The G rows of one wavefront are
-//    consecutive, so their CSR entries are ONE contiguous range. The wavefront
-//    streams that range through a private 64-entry LDS tile with a single
-//    coalesced load per 64 entries (column index pre-scaled to a byte offset into
-//    B, as the reference pre-multiplies by N at spmm_test.cu:124), and every
-//    group then walks its own sub-range with LDS broadcast reads. The next tile's
-//    entries are prefetched into registers while the current tile is consumed.
+//  * Coalesced Row Caching (CRC) in LDS. Consecutive rows are ONE contiguous CSR
+//    range, streamed through wavefront-private LDS tiles with coalesced loads (column
+//    index pre-scaled to a byte offset into B, as the reference pre-multiplies by N
+//    at spmm_test.cu:124); the next tile is always prefetched in registers.
 //
-//  * Memory-level parallelism. The walk is unrolled U-wide: U LDS reads, U
-//    independent B-row gathers, then U FMAs in CSR order — the order of the
-//    additions is unchanged, so results stay bit-identical across variants.
+//  * Memory-level parallelism. U (= 8) LDS reads, U independent B-row gathers, then
+//    U FMAs in CSR order — the order of the additions never changes, so all variants
+//    produce the same bits. Gathers are never issued under divergent branches inside
+//    a loop (hipcc then serialises them with s_waitcnt vmcnt(0)).
 //
-//  * XCD-aware mapping. The hardware deals workgroup b to XCD b % 8; we remap so
-//    that each XCD (private 4 MiB L2) sweeps one contiguous eighth of the rows,
-//    and the column tiles of a row block run back-to-back on the same XCD.
+//  * XCD-aware mapping. The hardware deals workgroup b to XCD b % 8; ids are remapped
+//    so each XCD (private 4 MiB L2) sweeps one contiguous eighth of the rows and the
+//    column tiles of a row block run back-to-back on the same XCD.
+//
+// Kernels in this file (selection: select.cpp, measurements: DESIGN.md §3.2):
+//   spmm_naive_kernel      variant 0: no LDS staging
+//   spmm_stream_kernel     batch-stream: rows walked G at a time over a wave-wide tile
+//   spmm_segstream_kernel  segmented-stream: one continuous gather stream per lane group
+//   spmm_longrow_kernel    hub rows of skewed graphs, one workgroup per row (deterministic)
+//   spmm_slabplan_kernel / spmm_slab_kernel   cache blocking for dense graphs
+//   spmm_parreduce_kernel  variant 5: lanes over nnz, xor-butterfly reduction
 //
 // No MFMA: the inner product is a gather, not a dense contraction.
 
