@@ -36,7 +36,13 @@ int auto_variant(int64_t M, int64_t nnz, int64_t N) {
 int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, int max_vec,
                      int cfg_vec, int cfg_strips, int cfg_group, int cfg_rows_per_wave, int cfg_slab_rows, int flags,
                      Selection* out) {
-    if (variant == GESPMM_VARIANT_AUTO) variant = auto_variant(M, nnz, N);
+    if (variant == GESPMM_VARIANT_AUTO) {
+        variant = auto_variant(M, nnz, N);
+        // Opt-in (GESPMM_FLAG_ALLOW_REASSOCIATION): narrow N on dense rows is 1.3-2x faster with
+        // lanes spread over the non-zeros (variant 5) — a re-ordered sum, within 1e-4, not bit-exact.
+        if ((flags & kFlagAllowReassoc) && N <= 16 && nnz > 0 && M > 0 && nnz / M >= 32)
+            variant = GESPMM_VARIANT_PARREDUCE;
+    }
     Geometry g;
     g.reduce = kReduceSum;
     g.idx64 = ((flags & kFlagForceIdx64) != 0) || ((uint64_t)K * (uint64_t)N * 4ull >= (1ull << 32));

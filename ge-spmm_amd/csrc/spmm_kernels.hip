@@ -955,16 +955,25 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
 
 // ----------------------------------------------------------------------------- parallel-reduction kernel
 //
-// Lanes of a W-wide group stride over the row's non-zeros; each lane keeps NC
-// partial sums (NC output columns per pass) and the group combines them with an
-// xor butterfly (ds_bpermute / DPP cross-lane moves, no LDS storage). Meant for
-// narrow N (GCN's class-logit layer, N = 3..8) and long rows, where the row-group
-// kernel would leave most lanes idle. The summation order differs from the
-// reference, so this variant is tolerance-checked, never bit-checked.
+// Variant 5: the lanes of a W-wide group stride over ONE row's non-zeros (lane l takes
+// entries l, l+W, ...), each lane keeps NC partial sums (NC output columns per pass), and
+// the group combines them across lanes with ds_bpermute / DPP moves — no LDS storage:
+//   1. reduce-scatter butterfly: log2(NC) xor steps, each lane passes on the half of its
+//      partial sums that its partner is responsible for (NC-1 moves in total, instead of
+//      NC * log2(W) for a plain all-reduce); afterwards lane l holds the column whose
+//      index is the bit-reversal of its low log2(NC) bits;
+//   2. xor butterfly over the remaining log2(W/NC) lane bits on that single value;
+//   3. the NC low lanes store their column.
+// Meant for narrow N (class logits, N = 1..8) and long rows, where a row-per-group
+// kernel leaves most lanes idle: reddit-like N = 1: 0.7 ms vs 1.4 ms. The summation
+// order differs from the reference's chain, so this variant is tolerance-checked
+// (|delta| <= 1e-4 * max(|ref|, sum|a*b|)) and never chosen automatically.
 
 template <int W, int NC, bool VALUED, bool IDX64>
 __global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
+    static_assert(NC <= W && NC <= 16, "columns per pass");
     constexpr int G = 64 / W;
+    constexpr int LOGNC = (NC == 1) ? 0 : (NC == 2) ? 1 : (NC == 4) ? 2 : (NC == 8) ? 3 : 4;
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
 
     const int lane = threadIdx.x & 63;
@@ -979,28 +988,58 @@ __global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
         lb = a.rowptr[row];
         hb = a.rowptr[row + 1];
     }
+    const bool vec4 = (NC % 4 == 0) && (a.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+    // column this lane ends up owning after the reduce-scatter: bit-reversed low bits
+    int mycol = 0;
+#pragma unroll
+    for (int sft = 0; sft < LOGNC; ++sft) mycol |= ((l >> sft) & 1) << (LOGNC - 1 - sft);
+
     for (int c0 = 0; c0 < a.N; c0 += NC) {
         float part[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) part[i] = 0.0f;
-        for (int k = lb + l; k < hb; k += W) {
+        auto accumulate = [&](int k) {
             const off_t off = (off_t)(uint32_t)a.colind[k] * (off_t)a.N + (off_t)c0;
             const float v = VALUED ? a.val[k] : 1.0f;
             const float* brow = a.B + off;
+            if (vec4 && c0 + NC <= a.N) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i)
-                if (c0 + i < a.N) part[i] = __builtin_fmaf(v, brow[i], part[i]);
+                for (int i = 0; i < NC; i += 4) {
+                    const VecT<4>::type q = *reinterpret_cast<const VecT<4>::type*>(brow + i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) part[(i + j) % NC] = __builtin_fmaf(v, q[j], part[(i + j) % NC]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+                    if (c0 + i < a.N) part[i] = __builtin_fmaf(v, brow[i], part[i]);
+            }
+        };
+        int k = lb + l;
+        for (; k + W < hb; k += 2 * W) {  // two entries per lane in flight
+            accumulate(k);
+            accumulate(k + W);
         }
+        if (k < hb) accumulate(k);
+
+        // 1. reduce-scatter over the low log2(NC) lane bits
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
+        for (int sft = 0; sft < LOGNC; ++sft) {
+            const int half = NC >> (sft + 1);
+            const bool upper = (l >> sft) & 1;
 #pragma unroll
-            for (int m = W >> 1; m > 0; m >>= 1) part[i] += __shfl_xor(part[i], m, 64);
-        if (rowok && l == 0) {
-            float* crow = a.C + (size_t)row * (size_t)a.N + c0;
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                if (c0 + i < a.N) crow[i] = part[i];
+            for (int i = 0; i < half; ++i) {
+                const float keep = upper ? part[half + i] : part[i];
+                const float give = upper ? part[i] : part[half + i];
+                part[i] = keep + __shfl_xor(give, 1 << sft, 64);
+            }
         }
+        // 2. all-reduce of the remaining single value over the other lane bits
+        float total = part[0];
+#pragma unroll
+        for (int m = NC; m < W; m <<= 1) total += __shfl_xor(total, m, 64);
+        // 3. NC low lanes write their column
+        if (rowok && l < NC && c0 + mycol < a.N) a.C[(size_t)row * (size_t)a.N + c0 + mycol] = total;
     }
 }
 
@@ -1300,15 +1339,25 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, hipS
     return e != hipSuccess ? e : ef;
 }
 
-template <int W, bool VALUED, bool IDX64>
-static hipError_t launch_parreduce_w(const SpmmArgs& a, hipStream_t st) {
+template <int W, int NC, bool VALUED, bool IDX64>
+static hipError_t launch_parreduce_nc(const SpmmArgs& a, hipStream_t st) {
     constexpr int G = 64 / W;
     SpmmArgs args = a;
     args.nblk = (int)(((int64_t)a.M + kWaves * G - 1) / (kWaves * G));
     args.ntile = 1;
     if (args.nblk <= 0) return hipSuccess;
-    hipLaunchKernelGGL((spmm_parreduce_kernel<W, 4, VALUED, IDX64>), dim3(args.nblk), dim3(kThreads), 0, st, args);
+    hipLaunchKernelGGL((spmm_parreduce_kernel<W, NC, VALUED, IDX64>), dim3(args.nblk), dim3(kThreads), 0, st, args);
     return hipGetLastError();
+}
+
+template <int W, bool VALUED, bool IDX64>
+static hipError_t launch_parreduce_w(const SpmmArgs& a, hipStream_t st) {
+    // columns per pass: the smallest power of two covering N, at most 16 (and at most W)
+    if (a.N <= 1) return launch_parreduce_nc<W, 1, VALUED, IDX64>(a, st);
+    if (a.N <= 2) return launch_parreduce_nc<W, 2, VALUED, IDX64>(a, st);
+    if (a.N <= 4 || W < 8) return launch_parreduce_nc<W, 4, VALUED, IDX64>(a, st);
+    if (a.N <= 8 || W < 16) return launch_parreduce_nc<W, (W >= 8 ? 8 : 4), VALUED, IDX64>(a, st);
+    return launch_parreduce_nc<W, (W >= 16 ? 16 : 4), VALUED, IDX64>(a, st);
 }
 
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
