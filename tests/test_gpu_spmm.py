@@ -128,7 +128,7 @@ def test_explicit_geometries_and_flags(pkg, oracle, bundled):
 
 
 def test_parallel_reduction_variant_within_tolerance(pkg, oracle, bundled):
-    for g, Ns in (("cora", (1, 3, 7, 16, 41)), ("pubmed", (3, 8))):
+    for g, Ns in (("cora", (1, 2, 3, 4, 7, 8, 12, 16, 20, 32, 41)), ("pubmed", (3, 8))):
         G = bundled[g]
         val = oracle.hash_val(G["nnz"], seed=2)
         for N in Ns:
@@ -145,6 +145,29 @@ def test_parallel_reduction_variant_within_tolerance(pkg, oracle, bundled):
     for group in (4, 8, 16, 32, 64):
         C = run(pkg, G, B, None, variant=5, cfg={"group": group})
         assert np.abs(C - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_reassociation_flag_is_opt_in(pkg, oracle):
+    """AUTO stays bit-exact on a dense narrow-N problem; with ALLOW_REASSOCIATION it may
+    take the parallel-reduction variant (within tolerance, and equal to variant 5's bits)."""
+    from gespmm_amd import _lib
+
+    rng = np.random.RandomState(11)
+    M, K = 1500, 2000
+    degs = rng.randint(40, 160, size=M)
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)
+    G = {"M": M, "K": K, "nnz": int(rowptr[-1]), "rowptr": rowptr, "colind": colind}
+    val = oracle.hash_val(G["nnz"], seed=4)
+    for N in (1, 4, 8, 16):
+        B = oracle.hash_B(G["K"], N, seed=N)
+        ref = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+        scale = oracle.spmm_abs(G["rowptr"], G["colind"], val, B)
+        assert_bits_equal(run(pkg, G, B, val, -1), ref, "auto N=%d" % N)
+        C = run(pkg, G, B, val, -1, cfg={"flags": _lib.FLAG_ALLOW_REASSOCIATION})
+        assert np.all(np.abs(C.astype(np.float64) - ref) <= 1e-4 * np.maximum(np.abs(ref), scale) + 1e-30)
+        assert_bits_equal(C, run(pkg, G, B, val, 5), "reassoc == v5, N=%d" % N)
 
 
 def test_misaligned_and_strided_inputs(pkg, oracle, bundled):
