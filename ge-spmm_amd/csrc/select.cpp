@@ -114,19 +114,43 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // spmm_kernels.hip): worth it when B per column tile is much larger than an L2 and a
     // row still finds several of its entries in every slab.
     {
-        const int64_t row_bytes = (int64_t)g.group * g.vec * g.strips * 4;
-        int64_t slab_rows = cfg_slab_rows > 0 ? cfg_slab_rows : (6 << 20) / row_bytes;
-        if (slab_rows < 64 && cfg_slab_rows <= 0) slab_rows = 64;
-        if (slab_rows > 0x3fffffff) slab_rows = 0x3fffffff;
+        auto plan = [&](int64_t row_bytes, int64_t* slab_rows_out, int64_t* nslab_out) {
+            int64_t slab_rows = cfg_slab_rows > 0 ? cfg_slab_rows : (6 << 20) / row_bytes;
+            if (slab_rows < 64 && cfg_slab_rows <= 0) slab_rows = 64;
+            if (slab_rows > 0x3fffffff) slab_rows = 0x3fffffff;
+            const int64_t nslab = (K + slab_rows - 1) / slab_rows;
+            *slab_rows_out = slab_rows;
+            *nslab_out = nslab;
+            // measured on reddit-like (profiles/r01/slab_blocking.log): 1.5-1.7x for N >= 64 with 4-6 MB
+            // slabs, a loss at N = 32 (128-byte row slices)
+            return nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 4 * nslab &&
+                   avg_deg >= 64;
+        };
+        int64_t slab_rows = 0, nslab = 0;
+        bool dense = plan((int64_t)g.group * g.vec * g.strips * 4, &slab_rows, &nslab);
+        // Column tiles are dealt to workgroups round-robin (tile = id mod ntile) and workgroup ids to
+        // XCDs round-robin (id mod 8): with 2, 4 or 8 tiles an XCD only ever sees ONE tile, so its L2
+        // holds slab_rows x (tile bytes) of B. 512-byte tiles (W = 32, V = 4, one strip) instead of 1-KB
+        // ones let the slab be twice as tall for the same footprint and halve the number of slabs
+        // (N = 256: 9.96 -> 8.79 ms, N = 512: 19.2 -> 17.4 on reddit-like,
+        // profiles/r01/slab_size_sweep_v2.log).
+        const bool forced = (flags & kFlagSlabBlocked) != 0;
+        if ((dense || forced) && (flags & kFlagNoSlabBlocked) == 0 && g.vec == 4 && cfg_strips == 0 && cfg_group == 0 &&
+            (int64_t)g.group * g.strips > 32) {
+            const int64_t ntile1 = (N + 127) / 128;
+            int64_t sr1 = 0, ns1 = 0;
+            if ((ntile1 == 2 || ntile1 == 4 || ntile1 == 8) && (plan(512, &sr1, &ns1) || forced)) {
+                g.group = 32;
+                g.strips = 1;
+                slab_rows = sr1;
+                nslab = ns1;
+                dense = true;
+            }
+        }
         g.slab_rows = (int)slab_rows;
         g.K = K;
-        const int64_t nslab = (K + slab_rows - 1) / slab_rows;
-        // measured on reddit-like (profiles/r01/slab_blocking.log): 1.5-1.7x for N >= 64 with 4-6 MB
-        // slabs, a loss at N = 32 (128-byte row slices)
-        const bool dense = nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 &&
-                           avg_deg >= 4 * nslab && avg_deg >= 64;
-        g.slab_blocked = ((flags & kFlagSlabBlocked) != 0 || dense) && (flags & kFlagNoSlabBlocked) == 0 &&
-                         nslab <= 65536 && variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
+        g.slab_blocked = (forced || dense) && (flags & kFlagNoSlabBlocked) == 0 && nslab <= 65536 &&
+                         variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
     }
     g.split_long_rows = ((flags & kFlagSplitLongRows) != 0 || nnz >= kLongRowMinNnz) && (flags & kFlagStrictOrder) == 0 &&
                         variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;

@@ -67,6 +67,18 @@ __device__ __forceinline__ void load_vec(float (&dst)[V], const char* base) {
     }
 }
 
+template <int V>
+__device__ __forceinline__ void load_vec_nt(float (&dst)[V], const char* base) {
+    using T = typename VecT<V>::type;
+    T v = __builtin_nontemporal_load(reinterpret_cast<const T*>(base));
+    if constexpr (V == 1) {
+        dst[0] = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = v[i];
+    }
+}
+
 template <int V, bool NT>
 __device__ __forceinline__ void store_vec(float* p, const float (&src)[V]) {
     using T = typename VecT<V>::type;
@@ -764,38 +776,68 @@ __global__ __launch_bounds__(kThreads) void spmm_longrow_kernel(SpmmArgs a) {
 // to the other variants. The split points live in a stream-ordered temporary
 // (hipMallocAsync) — no plan object, no API change.
 
+// Slab id of a column: min(col / slab_rows, nslab - 1). The quotient is estimated with one fp32
+// multiply by the reciprocal and fixed up: nslab <= 4096 keeps the estimate within one of the
+// true quotient (relative error ~2^-23), and an integer division per CSR entry would cost more
+// than the rest of the scan.
+__device__ __forceinline__ int slab_of(int col, int slab_rows, float inv, int nslab) {
+    int q = (int)((float)col * inv);
+    if (q > nslab - 1) q = nslab - 1;
+    const uint32_t lo = (uint32_t)q * (uint32_t)slab_rows;  // <= K + slab_rows < 2^32
+    if (lo > (uint32_t)col) --q;
+    else if ((uint32_t)col - lo >= (uint32_t)slab_rows && q < nslab - 1) ++q;
+    return q;
+}
+
 __global__ __launch_bounds__(kThreads) void spmm_slabplan_kernel(const int32_t* __restrict__ rowptr,
                                                                   const int32_t* __restrict__ colind,
                                                                   int32_t* __restrict__ split, int M, int nslab,
-                                                                  int slab_rows) {
-    // split is [nslab + 1][M]. One wavefront per row: 64 entries per coalesced load, the
-    // slab id of the forward scan at entry p is the running maximum of col/slab_rows over
-    // the row's entries up to p (a prefix max, done with 6 shuffles per chunk); wherever
-    // it steps up from m' to m, positions split[m'+1..m] = p.
+                                                                  int slab_rows, float inv) {
+    // split is [nslab + 1][M]. One wavefront per row, 64 entries per coalesced load, four
+    // loads in flight. The slab id of the forward scan at entry p is the running maximum of
+    // slab_of(col) over the row's entries up to p; wherever it steps up from m' to m,
+    // split[m'+1..m] = p. Chunks whose ids are already non-decreasing (ascending columns, the
+    // usual case — one wave-wide vote) skip the 6-step shuffle prefix maximum. (Deriving the
+    // boundaries from ballots instead of per-entry ids was tried: slower, 302 vs 251 us on
+    // reddit-like; the kernel is bound by its dependent rowptr -> colind -> store chain.)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * kWaves + (threadIdx.x >> 6);
     if (r >= M) return;
     const int lb = rowptr[r], hb = rowptr[r + 1];
     if (lane == 0) split[r] = lb;
     int run = 0;  // running maximum before the current chunk (wave-uniform)
-    for (int base = lb; base < hb; base += 64) {
-        const int p = base + lane;
-        int m = 0;
-        if (p < hb) {
-            m = colind[p] / slab_rows;
-            if (m > nslab - 1) m = nslab - 1;
+    constexpr int D = 4;  // chunks (coalesced 256-byte loads) in flight per wavefront
+    for (int sbase = lb; sbase < hb; sbase += 64 * D) {
+        int c[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {  // clamped, unconditional: the D loads issue back to back
+            const int p = sbase + 64 * k + lane;
+            c[k] = load_csr(colind + (p < hb ? p : hb - 1));
         }
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(m, d, 64);
-            if (lane >= d && t > m) m = t;
+        for (int k = 0; k < D; ++k) {
+            const int base = sbase + 64 * k;
+            if (base >= hb) break;  // wave-uniform
+            const int p = base + lane;
+            const bool valid = p < hb;
+            int m = valid ? slab_of(c[k], slab_rows, inv, nslab) : 0;
+            if (m < run) m = run;
+            int prev = __shfl_up(m, 1, 64);
+            if (lane == 0) prev = run;
+            if (__any(valid && m < prev)) {  // columns not ascending here: prefix maximum
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(m, d, 64);
+                    if (lane >= d && t > m) m = t;
+                }
+                prev = __shfl_up(m, 1, 64);
+                if (lane == 0) prev = run;
+            }
+            if (valid)
+                for (int sl = prev + 1; sl <= m; ++sl) split[(size_t)sl * M + r] = p;
+            const int nvalid = (hb - base < 64) ? hb - base : 64;
+            run = __shfl(m, nvalid - 1, 64);
         }
-        if (m < run) m = run;
-        int prev = __shfl_up(m, 1, 64);
-        if (lane == 0) prev = run;
-        if (p < hb)
-            for (int sl = prev + 1; sl <= m; ++sl) split[(size_t)sl * M + r] = p;
-        run = __shfl(m, 63, 64);
     }
     for (int sl = run + 1 + lane; sl <= nslab; sl += 64) split[(size_t)sl * M + r] = hb;
 }
@@ -805,7 +847,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
     constexpr int G = 64 / W;
     constexpr int T = (W > 32) ? W : 32;
     constexpr int E = T / W;
-    constexpr int U = (V * S >= 8) ? 4 : 8;
+    constexpr int U = (V * S >= 8) ? 4 : 8;  // U = 4 measured: 6.1 vs 4.8 ms on reddit-like (misses need the depth)
     constexpr int R = kSlabRowsPerGroup;  // consecutive rows one lane group walks per launch
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
 
@@ -828,8 +870,8 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
     // split points of the group's R rows for this slab: two coalesced loads -> LDS
     for (int i = l; i < R; i += W) {
         const bool ok = row0 + i < a.M;
-        s_b[wave][g][i] = ok ? a.row_begin[row0 + i] : 0;
-        s_e[wave][g][i] = ok ? a.row_end[row0 + i] : 0;
+        s_b[wave][g][i] = ok ? load_csr(a.row_begin + row0 + i) : 0;
+        s_e[wave][g][i] = ok ? load_csr(a.row_end + row0 + i) : 0;
     }
     wave_lds_sync();
     const bool first = a.accumulate == 0;
@@ -858,8 +900,8 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
             qc[k] = 0;
             qv[k] = 0.0f;
             if (p < e) {
-                qc[k] = a.colind[p];
-                if constexpr (VALUED) qv[k] = a.val[p];
+                qc[k] = load_csr(a.colind + p);
+                if constexpr (VALUED) qv[k] = load_csr(a.val + p);
             }
         }
 #pragma unroll
@@ -870,7 +912,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
             const float* Crow = a.C + (size_t)(row0 + i) * (size_t)a.N + col0;
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (colok[s]) load_vec<V>(qacc[s], reinterpret_cast<const char*>(Crow + s * (W * V)));
+                if (colok[s]) load_vec_nt<V>(qacc[s], reinterpret_cast<const char*>(Crow + s * (W * V)));
         }
     };
     prefetch_row(0);
@@ -907,8 +949,8 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
                     for (int e = 0; e < E; ++e) {
                         const int p = tbase + T + l * E + e;
                         if (p < ge) {
-                            pc[e] = a.colind[p];
-                            if constexpr (VALUED) pv[e] = a.val[p];
+                            pc[e] = load_csr(a.colind + p);
+                            if constexpr (VALUED) pv[e] = load_csr(a.val + p);
                         }
                     }
                 }
@@ -948,7 +990,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
             float* Crow = a.C + (size_t)(row0 + i) * (size_t)a.N + col0;
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (colok[s]) store_vec<V, false>(Crow + s * (W * V), acc[s]);
+                if (colok[s]) store_vec<V, true>(Crow + s * (W * V), acc[s]);
         }
     }
 }
@@ -989,6 +1031,7 @@ __global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
         hb = a.rowptr[row + 1];
     }
     const bool vec4 = (NC % 4 == 0) && (a.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+    const bool vec2 = (NC == 2) && (a.N % 2 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 7) == 0);
     // column this lane ends up owning after the reduce-scatter: bit-reversed low bits
     int mycol = 0;
 #pragma unroll
@@ -1009,6 +1052,10 @@ __global__ __launch_bounds__(kThreads) void spmm_parreduce_kernel(SpmmArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) part[(i + j) % NC] = __builtin_fmaf(v, q[j], part[(i + j) % NC]);
                 }
+            } else if (vec2) {
+                const VecT<2>::type q = *reinterpret_cast<const VecT<2>::type*>(brow);
+                part[0] = __builtin_fmaf(v, q[0], part[0]);
+                part[1 % NC] = __builtin_fmaf(v, q[1], part[1 % NC]);
             } else {
 #pragma unroll
                 for (int i = 0; i < NC; ++i)
@@ -1324,7 +1371,7 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, hipS
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&split), (size_t)(nslab + 1) * (size_t)M * 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(spmm_slabplan_kernel, dim3((M + kWaves - 1) / kWaves), dim3(kThreads), 0, st, a0.rowptr,
-                       a0.colind, split, M, nslab, geo.slab_rows);
+                       a0.colind, split, M, nslab, geo.slab_rows, 1.0f / (float)geo.slab_rows);
     e = hipGetLastError();
     const bool valued = a0.val != nullptr;
     for (int sl = 0; sl < nslab && e == hipSuccess; ++sl) {
