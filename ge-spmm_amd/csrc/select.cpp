@@ -80,14 +80,21 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         if (cfg_group < 4 || cfg_group > 64 || (cfg_group & (cfg_group - 1))) return GESPMM_EINVAL;
         g.group = cfg_group;
     }
-    // Rows per wavefront of the streaming kernel: aim at ~2 LDS tiles (128 CSR entries)
-    // per wavefront so row pointers and tiles are fetched in full coalesced loads, but
-    // keep >= ~4 wavefronts per wave slot of the chip (256 CUs x 32 slots) in the grid.
+    // Rows per wavefront of the batch-stream kernel. Measured over the graph families at
+    // N = 32..512 (profiles/r01/rows_per_wave_sweep.log): the best task size is ~12 KB of B
+    // gathered per wavefront task — 96 CSR entries at N = 32, 24 at N = 128 — never fewer
+    // than 16 entries; larger tasks lose 5-17 % (coarser dynamic balance over the CUs).
+    // Keep >= ~4 wavefronts per wave slot of the chip (256 CUs x 32 slots) in the grid.
     const int rows_in_flight = 64 / g.group;
     {
         const int64_t avg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
+        const int64_t tile_cols = (int64_t)g.group * g.vec * g.strips;
+        const int64_t entry_bytes = 4 * (N < tile_cols ? N : tile_cols);
+        int64_t target = (12 << 10) / (entry_bytes > 0 ? entry_bytes : 4);
+        if (target < 16) target = 16;
+        if (target > 96) target = 96;
         int rpw = kMaxRowsPerWave;
-        while (rpw > rows_in_flight && (int64_t)rpw * avg > 128) rpw >>= 1;
+        while (rpw > rows_in_flight && (int64_t)rpw * avg > target) rpw >>= 1;
         while (rpw > rows_in_flight && M / rpw < 4 * 8192) rpw >>= 1;
         if (rpw < rows_in_flight) rpw = rows_in_flight;
         g.rows_per_wave = rpw;
@@ -163,9 +170,10 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         if (thr > 0x3fffffff) thr = 0x3fffffff;
         g.long_row_threshold = (int)thr;
     }
-    // The segmented kernel pays off for short rows only; long rows (and the long-row
-    // split, which the batch kernel implements) go to the batch kernel.
-    g.segmented = g.group >= 32 && avg_deg <= 12 && !g.split_long_rows;
+    // The segmented kernel is opt-in (GESPMM_FLAG_SEG_STREAM): with task sizes tuned per kernel
+    // the batch kernel is equal or faster on every graph family measured
+    // (profiles/r01/rows_per_wave_sweep.log), and it implements the long-row split.
+    g.segmented = (flags & kFlagSegStream) != 0 && !g.split_long_rows;
     out->variant = variant;
     out->geo = g;
     return 0;
