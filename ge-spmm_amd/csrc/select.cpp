@@ -86,6 +86,7 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // than 16 entries; larger tasks lose 5-17 % (coarser dynamic balance over the CUs).
     // Keep >= ~4 wavefronts per wave slot of the chip (256 CUs x 32 slots) in the grid.
     const int rows_in_flight = 64 / g.group;
+    const bool b_resident = (uint64_t)K * (uint64_t)N * 4ull <= (8ull << 20);
     {
         const int64_t avg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
         const int64_t tile_cols = (int64_t)g.group * g.vec * g.strips;
@@ -93,6 +94,9 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         int64_t target = (12 << 10) / (entry_bytes > 0 ? entry_bytes : 4);
         if (target < 16) target = 16;
         if (target > 96) target = 96;
+        // B small enough to live in the L2s: the kernel is issue-bound, not fabric-bound, and the
+        // per-task prologue counts — larger tasks (73-82 vs 97 us at K = 2048, cache_regime_sweep*.log)
+        if (b_resident) target = 128;
         int rpw = kMaxRowsPerWave;
         while (rpw > rows_in_flight && (int64_t)rpw * avg > target) rpw >>= 1;
         while (rpw > rows_in_flight && M / rpw < 4 * 8192) rpw >>= 1;
@@ -106,6 +110,7 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         int rpg = kMaxRowsPerWave;
         while (rpg > 1 && (int64_t)rpg * avg > 64) rpg >>= 1;
         while (rpg > 1 && M / ((int64_t)rpg * rows_in_flight) < 4 * 8192) rpg >>= 1;
+        if (b_resident && rpg > 4) rpg = 4;  // kernel_generations_cache_regimes.log: g4 58 us, g8 65
         g.rows_per_group = rpg;
     }
     if (cfg_rows_per_wave) {
@@ -170,10 +175,12 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         if (thr > 0x3fffffff) thr = 0x3fffffff;
         g.long_row_threshold = (int)thr;
     }
-    // The segmented kernel is opt-in (GESPMM_FLAG_SEG_STREAM): with task sizes tuned per kernel
-    // the batch kernel is equal or faster on every graph family measured
-    // (profiles/r01/rows_per_wave_sweep.log), and it implements the long-row split.
-    g.segmented = (flags & kFlagSegStream) != 0 && !g.split_long_rows;
+    // With task sizes tuned per kernel the batch kernel is equal or faster on every graph family
+    // whose B exceeds the L2s (profiles/r01/rows_per_wave_sweep.log), and it implements the long-row
+    // split. The segmented kernel keeps the short-row, L2-resident-B corner (58 vs 68 us,
+    // kernel_generations_cache_regimes.log) and is otherwise opt-in (GESPMM_FLAG_SEG_STREAM).
+    g.segmented = ((flags & kFlagSegStream) != 0 || (b_resident && g.group >= 32 && avg_deg <= 12)) &&
+                  !g.split_long_rows;
     out->variant = variant;
     out->geo = g;
     return 0;
