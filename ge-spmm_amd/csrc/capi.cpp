@@ -96,7 +96,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
             a.rpw = sel.geo.rows_per_wave;
             a.long_row = sel.geo.split_long_rows ? sel.geo.long_row_threshold : 0;
             e = gespmm::launch_spmm_stream(a, sel.geo, st);
-            if (e == hipSuccess && sel.geo.split_long_rows) e = gespmm::launch_spmm_longrows(a, sel.geo, st);
+            if (e == hipSuccess && sel.geo.split_long_rows) e = gespmm::launch_spmm_longrows(a, sel.geo, nnz, st);
         }
     }
     return (int)e;

@@ -164,7 +164,8 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         g.slab_blocked = (forced || dense) && (flags & kFlagNoSlabBlocked) == 0 && nslab <= 65536 &&
                          variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
     }
-    g.split_long_rows = ((flags & kFlagSplitLongRows) != 0 || nnz >= kLongRowMinNnz) && (flags & kFlagStrictOrder) == 0 &&
+    // (needs nnz to size its workspace: callers that pass nnz = -1 keep the strict chain)
+    g.split_long_rows = nnz > 0 && ((flags & kFlagSplitLongRows) != 0 || nnz >= kLongRowMinNnz) && (flags & kFlagStrictOrder) == 0 &&
                         variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
     // A row is "long" when it dwarfs the average wavefront's work: 32x the mean degree,
     // at least kLongRowThreshold entries (reddit-like graphs, mean degree ~500, keep

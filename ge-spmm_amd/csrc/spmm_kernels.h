@@ -23,6 +23,7 @@ constexpr int kFlagBatchStream = 0x20;   // == GESPMM_FLAG_BATCH_STREAM (force t
 constexpr int kFlagStrictOrder = 0x100;  // == GESPMM_FLAG_STRICT_ORDER (never split long rows)
 constexpr int kFlagSplitLongRows = 0x200; // == GESPMM_FLAG_SPLIT_LONG_ROWS (always run the long-row pass)
 constexpr int kLongRowThreshold = 2048;  // entries; lower bound of the long-row threshold (32 x mean degree)
+constexpr int kLongRowChunk = 2048;      // entries of a long row one workgroup sums per partial row
 constexpr int64_t kLongRowMinNnz = 1 << 23;  // auto: only matrices this large get the long-row pass
 constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force the cache-blocked path)
 constexpr int kFlagNoSlabBlocked = 0x800; // == GESPMM_FLAG_NO_SLAB_BLOCKED
@@ -68,7 +69,7 @@ struct Geometry {
 hipError_t launch_spmm_naive(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
-hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, hipStream_t st);
 hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 

@@ -579,35 +579,72 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
 }
 
 
-// ----------------------------------------------------------------------------- long-row kernel
+// ----------------------------------------------------------------------------- long-row pass
 //
-// Load balance for skewed graphs (RMAT hubs, reddit): a row of 10^5..10^6 non-zeros
-// walked by ONE lane group is a serial chain that outlasts the rest of the launch.
-// Rows longer than `long_row` entries are therefore skipped by the main kernel and
-// done here by a whole workgroup: the NG = 4*G lane groups of the workgroup take the
-// row's 64-entry tiles round-robin (group q: tiles q, q+NG, ...), each keeps ONE
-// accumulator chain over its tiles in ascending order, and the NG partial rows are
-// added in fixed order q = 0..NG-1 through LDS. The result does not depend on
-// scheduling (bit-reproducible run to run) but is a re-association of the strict
-// CSR-order sum, so these rows are checked to north_star's 1e-4 tolerance instead
-// of bit-for-bit. GESPMM_FLAG_STRICT_ORDER turns the split off.
+// Load balance for skewed graphs (RMAT hubs): a row of 10^4..10^6 non-zeros walked by ONE
+// lane group is a serial chain that outlasts the rest of the launch, and even a whole
+// workgroup per row is too little for the biggest hubs (a workgroup keeps ~32 KB of
+// gathers in flight: tens of GB/s). Rows longer than `long_row` entries are therefore
+// skipped by the main kernel and done here in CHUNKS of kLongRowChunk entries:
 //
-// No list of long rows is built: every workgroup scans its own slice of rowptr
-// (coalesced, 256 rows per pass) and serves the long rows it finds.
+//   1. spmm_longrow_list_kernel   one thread per row; a long row reserves ceil(len/chunk)
+//                                 consecutive chunk slots (atomic counter) and one entry of
+//                                 the long-row list {row, first slot, #chunks};
+//   2. spmm_longrow_chunk_kernel  workgroups walk the chunk list grid-stride; the NG = 4*G
+//                                 lane groups of a workgroup take the chunk's 64-entry tiles
+//                                 round-robin (group q: tiles q, q+NG, ...), each keeps ONE
+//                                 accumulator chain over its tiles in ascending order, the NG
+//                                 partial rows are added in fixed order q = 0..NG-1 through
+//                                 LDS and written to partial[slot][0..N);
+//   3. spmm_longrow_combine_kernel  per long row: C[row] = partial[first] + partial[first+1]
+//                                 + ... in chunk order.
+//
+// Which slot a row gets depends on scheduling, its value does not: the result is
+// bit-reproducible run to run, but it is a re-association of the strict CSR-order sum, so
+// these rows are checked to north_star's 1e-4 tolerance instead of bit-for-bit.
+// GESPMM_FLAG_STRICT_ORDER turns the split off. RMAT-20, N=128: the previous form (one
+// workgroup per 4096-row slice serving the long rows it finds) took 1.11 ms of a 2.0 ms
+// launch pair because the hubs cluster in a few slices.
+
+struct LongRowHeader {
+    int nchunks;
+    int nrows;
+    int pad[2];
+};
+
+__global__ __launch_bounds__(kThreads) void spmm_longrow_list_kernel(const int32_t* __restrict__ rowptr, int M,
+                                                                      int long_row, int chunk, int max_chunks,
+                                                                      int max_rows, LongRowHeader* hdr,
+                                                                      int4* __restrict__ rowlist,
+                                                                      int2* __restrict__ chunklist) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= M) return;
+    const int lb = rowptr[r];
+    const int len = rowptr[r + 1] - lb;
+    if (len <= long_row) return;
+    const int nch = (len + chunk - 1) / chunk;
+    const int base = atomicAdd(&hdr->nchunks, nch);
+    const int j = atomicAdd(&hdr->nrows, 1);
+    if (j >= max_rows || base + nch > max_chunks) return;  // cannot happen: bounds are nnz/long_row, nnz/chunk + rows
+    rowlist[j] = make_int4(r, base, nch, 0);
+    for (int c = 0; c < nch; ++c) chunklist[base + c] = make_int2(r, c);
+}
 
 template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
-__global__ __launch_bounds__(kThreads) void spmm_longrow_kernel(SpmmArgs a) {
+__global__ __launch_bounds__(kThreads) void spmm_longrow_chunk_kernel(SpmmArgs a, int chunk, int max_chunks,
+                                                                       const LongRowHeader* __restrict__ hdr,
+                                                                       const int2* __restrict__ chunklist,
+                                                                       float* __restrict__ partial) {
     constexpr int G = 64 / W;
     constexpr int NG = kWaves * G;
-    constexpr int T = 64;               // entries per tile (all 64 lanes of the wavefront load one tile per group round)
+    constexpr int T = 64;  // entries per tile
+    constexpr int E = T / W;
     constexpr int U = (V * S >= 8) ? 4 : 8;
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
 
     __shared__ off_t s_off[kWaves][G][T];
     __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? G : 1][VALUED ? T : 1];
     __shared__ float s_part[NG][W * V * S];
-    __shared__ int s_rows[kThreads];
-    __shared__ int s_nrows;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -616,133 +653,133 @@ __global__ __launch_bounds__(kThreads) void spmm_longrow_kernel(SpmmArgs a) {
     const int l = lane % W;
     const int q = wave * G + g;  // group id inside the workgroup
 
-    const int rows_per_block = (a.M + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int slice_begin = (int)blockIdx.x * rows_per_block;
-    const int slice_end = (slice_begin + rows_per_block < a.M) ? slice_begin + rows_per_block : a.M;
     const char* Bbase = reinterpret_cast<const char*>(a.B);
     const off_t rowbytes = (off_t)a.N * 4u;
     const float init = (RED == kReduceMax) ? a.empty : 0.0f;
     const int ntile = (a.N + W * V * S - 1) / (W * V * S);
+    int nchunks = hdr->nchunks;
+    if (nchunks > max_chunks) nchunks = max_chunks;
 
-    for (int base = slice_begin; base < slice_end; base += kThreads) {
-        // ---- find the long rows among rows [base, base+256): ascending row order
-        if (tid == 0) s_nrows = 0;
-        __syncthreads();
-        const int row = base + tid;
-        bool is_long = false;
-        if (row < slice_end) is_long = (a.rowptr[row + 1] - a.rowptr[row]) > a.long_row;
-        const unsigned long long m = __ballot(is_long);
-        __shared__ int s_wcount[kWaves];
-        if (lane == 0) s_wcount[wave] = __popcll(m);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_wcount[w];
-        if (is_long) s_rows[woff + __popcll(m & ((1ull << lane) - 1ull))] = row;
-        if (tid == 0) s_nrows = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-        __syncthreads();
-        const int nlong = s_nrows;
+    for (int slot = blockIdx.x; slot < nchunks; slot += gridDim.x) {
+        const int2 job = chunklist[slot];
+        const int lb = a.rowptr[job.x] + job.y * chunk;
+        const int rend = a.rowptr[job.x + 1];
+        const int hb = (lb + chunk < rend) ? lb + chunk : rend;
+        const int ntiles_row = (hb - lb + T - 1) / T;
+        float* dst = partial + (size_t)slot * (size_t)a.N;
+        for (int ct = 0; ct < ntile; ++ct) {
+            const int col0 = ct * (W * V * S) + l * V;
+            bool colok[S];
+            off_t cbytes[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                colok[s] = (col0 + s * W * V) < a.N;
+                cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
+            }
+            float acc[S][V];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int k2 = 0; k2 < V; ++k2) acc[s][k2] = init;
 
-        for (int i = 0; i < nlong; ++i) {
-            const int r = s_rows[i];
-            const int lb = a.rowptr[r];
-            const int hb = a.rowptr[r + 1];
-            const int ntiles_row = (hb - lb + T - 1) / T;
-            for (int ct = 0; ct < ntile; ++ct) {
-                const int col0 = ct * (W * V * S) + l * V;
-                bool colok[S];
-                off_t cbytes[S];
+            // group q walks tiles q, q+NG, ... ; the W lanes of the group stage T/W entries each
+            int pc[E];
+            float pv[E];
+            auto fetch = [&](int t) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int p = lb + t * T + l * E + e;
+                    pc[e] = 0;
+                    pv[e] = 0.0f;
+                    if (t < ntiles_row && p < hb) {
+                        pc[e] = load_csr(a.colind + p);
+                        if constexpr (VALUED) pv[e] = load_csr(a.val + p);
+                    }
+                }
+            };
+            fetch(q);
+            for (int t = q; t < ntiles_row; t += NG) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    s_off[wave][g][l * E + e] = (off_t)(uint32_t)pc[e] * rowbytes;
+                    if constexpr (VALUED) s_val[wave][g][l * E + e] = pv[e];
+                }
+                fetch(t + NG);
+                wave_lds_sync();
+                const int cnt_tile = (hb - (lb + t * T) < T) ? hb - (lb + t * T) : T;
+                for (int k = 0; k < cnt_tile; k += U) {
+                    const int cnt = cnt_tile - k;
+                    off_t off[U];
+                    float v[U];
+                    float bv[U][S][V];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const int kj = k + ((j < cnt) ? j : cnt - 1);
+                        off[j] = s_off[wave][g][kj];
+                        if constexpr (VALUED) v[j] = s_val[wave][g][kj];
+                        else v[j] = 1.0f;
+#pragma unroll
+                        for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        if (j < cnt) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s)
+#pragma unroll
+                                for (int k2 = 0; k2 < V; ++k2)
+                                    acc[s][k2] = combine<RED, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            }
+            // ---- fixed-order combine of the NG partial rows
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int k2 = 0; k2 < V; ++k2) s_part[q][(s * W + l) * V + k2] = acc[s][k2];
+            __syncthreads();
+            if (q == 0) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    colok[s] = (col0 + s * W * V) < a.N;
-                    cbytes[s] = colok[s] ? (off_t)(col0 + s * W * V) * 4u : (off_t)0;
-                }
-                float acc[S][V];
 #pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int k2 = 0; k2 < V; ++k2) acc[s][k2] = init;
-
-                // group q walks tiles q, q+NG, ... ; the W lanes of the group stage T/W entries each
-                constexpr int E = T / W;
-                int pc[E];
-                float pv[E];
-                auto fetch = [&](int t) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int p = lb + t * T + l * E + e;
-                        pc[e] = 0;
-                        pv[e] = 0.0f;
-                        if (t < ntiles_row && p < hb) {
-                            pc[e] = a.colind[p];
-                            if constexpr (VALUED) pv[e] = a.val[p];
+                    for (int k2 = 0; k2 < V; ++k2) {
+                        float t2 = s_part[0][(s * W + l) * V + k2];
+                        for (int qq = 1; qq < NG; ++qq) {
+                            const float pq = s_part[qq][(s * W + l) * V + k2];
+                            if constexpr (RED == kReduceMax) t2 = fmaxf(t2, pq);
+                            else t2 = t2 + pq;
                         }
-                    }
-                };
-                fetch(q);
-                for (int t = q; t < ntiles_row; t += NG) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        s_off[wave][g][l * E + e] = (off_t)(uint32_t)pc[e] * rowbytes;
-                        if constexpr (VALUED) s_val[wave][g][l * E + e] = pv[e];
-                    }
-                    fetch(t + NG);
-                    wave_lds_sync();
-                    const int cnt_tile = (hb - (lb + t * T) < T) ? hb - (lb + t * T) : T;
-                    for (int k = 0; k < cnt_tile; k += U) {
-                        const int cnt = cnt_tile - k;
-                        off_t off[U];
-                        float v[U];
-                        float bv[U][S][V];
-#pragma unroll
-                        for (int j = 0; j < U; ++j) {
-                            const int kj = k + ((j < cnt) ? j : cnt - 1);
-                            off[j] = s_off[wave][g][kj];
-                            if constexpr (VALUED) v[j] = s_val[wave][g][kj];
-                            else v[j] = 1.0f;
-#pragma unroll
-                            for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
-                        }
-#pragma unroll
-                        for (int j = 0; j < U; ++j) {
-                            if (j < cnt) {
-#pragma unroll
-                                for (int s = 0; s < S; ++s)
-#pragma unroll
-                                    for (int k2 = 0; k2 < V; ++k2)
-                                        acc[s][k2] = combine<RED, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                }
-                // ---- fixed-order combine of the NG partial rows
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int k2 = 0; k2 < V; ++k2) s_part[q][(s * W + l) * V + k2] = acc[s][k2];
-                __syncthreads();
-                if (q == 0) {
-                    float* Crow = a.C + (size_t)r * (size_t)a.N + col0;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        float outv[V];
-#pragma unroll
-                        for (int k2 = 0; k2 < V; ++k2) {
-                            float t2 = s_part[0][(s * W + l) * V + k2];
-                            for (int qq = 1; qq < NG; ++qq) {
-                                const float pq = s_part[qq][(s * W + l) * V + k2];
-                                if constexpr (RED == kReduceMax) t2 = fmaxf(t2, pq);
-                                else t2 = t2 + pq;
-                            }
-                            outv[k2] = t2;
-                        }
-                        if (colok[s]) store_vec<V, false>(Crow + s * (W * V), outv);
+                        if (colok[s]) dst[col0 + s * W * V + k2] = t2;
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
-        __syncthreads();
+    }
+}
+
+template <int RED>
+__global__ __launch_bounds__(kThreads) void spmm_longrow_combine_kernel(float* __restrict__ C, int N, int max_rows,
+                                                                         const LongRowHeader* __restrict__ hdr,
+                                                                         const int4* __restrict__ rowlist,
+                                                                         const float* __restrict__ partial) {
+    int nrows = hdr->nrows;
+    if (nrows > max_rows) nrows = max_rows;
+    for (int j = blockIdx.x; j < nrows; j += gridDim.x) {
+        const int4 e = rowlist[j];  // {row, first slot, #chunks}
+        const float* src = partial + (size_t)e.y * (size_t)N;
+        float* dst = C + (size_t)e.x * (size_t)N;
+        for (int col = threadIdx.x; col < N; col += kThreads) {
+            float acc = src[col];
+            for (int c = 1; c < e.z; ++c) {
+                const float pq = src[(size_t)c * (size_t)N + col];
+                if constexpr (RED == kReduceMax) acc = fmaxf(acc, pq);
+                else acc = acc + pq;
+            }
+            dst[col] = acc;
+        }
     }
 }
 
@@ -1272,53 +1309,103 @@ hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStre
 }
 
 
+// Workspace of one long-row pass: header, long-row list, chunk list, partial rows — one
+// stream-ordered allocation sized by upper bounds (#long rows < nnz / long_row, #chunks <=
+// nnz / chunk + #long rows), zeroed header, freed stream-ordered after the combine kernel.
+struct LongRowWs {
+    LongRowHeader* hdr;
+    int4* rowlist;
+    int2* chunklist;
+    float* partial;
+    int max_rows, max_chunks, chunk;
+};
+
 template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
-static hipError_t launch_longrow(const SpmmArgs& a, hipStream_t st) {
-    SpmmArgs args = a;
-    // One workgroup per 4096-row slice, capped at 4 workgroups per CU: the scan is a
-    // few MB of rowptr and the long rows are spread by whatever id order the graph has.
-    int64_t blocks = ((int64_t)a.M + 4095) / 4096;
-    if (blocks > 1024) blocks = 1024;
+static hipError_t launch_longrow(const SpmmArgs& a, const LongRowWs& ws, hipStream_t st) {
+    // at most 8 workgroups per CU; the chunk list is walked grid-stride
+    int blocks = ws.max_chunks < 2048 ? ws.max_chunks : 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((spmm_longrow_kernel<V, S, W, VALUED, IDX64, RED>), dim3((unsigned)blocks), dim3(kThreads), 0,
-                       st, args);
+    hipLaunchKernelGGL((spmm_longrow_chunk_kernel<V, S, W, VALUED, IDX64, RED>), dim3((unsigned)blocks),
+                       dim3(kThreads), 0, st, a, ws.chunk, ws.max_chunks, ws.hdr, ws.chunklist, ws.partial);
     return hipGetLastError();
 }
 
 template <int V, int S, bool VALUED, bool IDX64, int RED>
-static hipError_t longrow_w(const SpmmArgs& a, int W, hipStream_t st) {
+static hipError_t longrow_w(const SpmmArgs& a, const LongRowWs& ws, int W, hipStream_t st) {
     switch (W) {
-        case 4: return launch_longrow<V, S, 4, VALUED, IDX64, RED>(a, st);
-        case 8: return launch_longrow<V, S, 8, VALUED, IDX64, RED>(a, st);
-        case 16: return launch_longrow<V, S, 16, VALUED, IDX64, RED>(a, st);
-        case 32: return launch_longrow<V, S, 32, VALUED, IDX64, RED>(a, st);
-        case 64: return launch_longrow<V, S, 64, VALUED, IDX64, RED>(a, st);
+        case 4: return launch_longrow<V, S, 4, VALUED, IDX64, RED>(a, ws, st);
+        case 8: return launch_longrow<V, S, 8, VALUED, IDX64, RED>(a, ws, st);
+        case 16: return launch_longrow<V, S, 16, VALUED, IDX64, RED>(a, ws, st);
+        case 32: return launch_longrow<V, S, 32, VALUED, IDX64, RED>(a, ws, st);
+        case 64: return launch_longrow<V, S, 64, VALUED, IDX64, RED>(a, ws, st);
     }
     return hipErrorInvalidValue;
 }
 
 template <bool VALUED, bool IDX64, int RED>
-static hipError_t longrow_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
+static hipError_t longrow_vs(const SpmmArgs& a, const LongRowWs& ws, const Geometry& g, hipStream_t st) {
     if (g.strips == 2) {
-        if (g.vec == 4) return longrow_w<4, 2, VALUED, IDX64, RED>(a, g.group, st);
+        if (g.vec == 4) return longrow_w<4, 2, VALUED, IDX64, RED>(a, ws, g.group, st);
         return hipErrorInvalidValue;
     }
     switch (g.vec) {
-        case 1: return longrow_w<1, 1, VALUED, IDX64, RED>(a, g.group, st);
-        case 2: return longrow_w<2, 1, VALUED, IDX64, RED>(a, g.group, st);
-        case 4: return longrow_w<4, 1, VALUED, IDX64, RED>(a, g.group, st);
+        case 1: return longrow_w<1, 1, VALUED, IDX64, RED>(a, ws, g.group, st);
+        case 2: return longrow_w<2, 1, VALUED, IDX64, RED>(a, ws, g.group, st);
+        case 4: return longrow_w<4, 1, VALUED, IDX64, RED>(a, ws, g.group, st);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, hipStream_t st) {
+hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, hipStream_t st) {
     const bool valued = a.val != nullptr;
-    if (geo.reduce == kReduceMax) {
-        if (valued) return hipErrorInvalidValue;
-        return geo.idx64 ? longrow_vs<false, true, kReduceMax>(a, geo, st) : longrow_vs<false, false, kReduceMax>(a, geo, st);
+    if (geo.reduce == kReduceMax && valued) return hipErrorInvalidValue;
+    if (a.long_row <= 0 || nnz <= a.long_row) return hipSuccess;  // no row can be long
+    LongRowWs ws;
+    ws.chunk = kLongRowChunk;
+    const int64_t max_rows = nnz / a.long_row + 1;
+    const int64_t max_chunks = nnz / ws.chunk + max_rows;
+    if (max_chunks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    ws.max_rows = (int)max_rows;
+    ws.max_chunks = (int)max_chunks;
+    const size_t off_rows = sizeof(LongRowHeader);
+    const size_t off_chunks = off_rows + (size_t)max_rows * sizeof(int4);
+    size_t off_partial = off_chunks + (size_t)max_chunks * sizeof(int2);
+    off_partial = (off_partial + 255) & ~(size_t)255;
+    const size_t bytes = off_partial + (size_t)max_chunks * (size_t)a.N * sizeof(float);
+    char* base = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&base), bytes, st);
+    if (e != hipSuccess) return e;
+    ws.hdr = reinterpret_cast<LongRowHeader*>(base);
+    ws.rowlist = reinterpret_cast<int4*>(base + off_rows);
+    ws.chunklist = reinterpret_cast<int2*>(base + off_chunks);
+    ws.partial = reinterpret_cast<float*>(base + off_partial);
+    e = hipMemsetAsync(base, 0, sizeof(LongRowHeader), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spmm_longrow_list_kernel, dim3((unsigned)((a.M + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                           st, a.rowptr, a.M, a.long_row, ws.chunk, ws.max_chunks, ws.max_rows, ws.hdr, ws.rowlist,
+                           ws.chunklist);
+        e = hipGetLastError();
     }
-    if (valued) return geo.idx64 ? longrow_vs<true, true, kReduceSum>(a, geo, st) : longrow_vs<true, false, kReduceSum>(a, geo, st);
-    return geo.idx64 ? longrow_vs<false, true, kReduceSum>(a, geo, st) : longrow_vs<false, false, kReduceSum>(a, geo, st);
+    if (e == hipSuccess) {
+        if (geo.reduce == kReduceMax)
+            e = geo.idx64 ? longrow_vs<false, true, kReduceMax>(a, ws, geo, st) : longrow_vs<false, false, kReduceMax>(a, ws, geo, st);
+        else if (valued)
+            e = geo.idx64 ? longrow_vs<true, true, kReduceSum>(a, ws, geo, st) : longrow_vs<true, false, kReduceSum>(a, ws, geo, st);
+        else
+            e = geo.idx64 ? longrow_vs<false, true, kReduceSum>(a, ws, geo, st) : longrow_vs<false, false, kReduceSum>(a, ws, geo, st);
+    }
+    if (e == hipSuccess) {
+        const int blocks = ws.max_rows < 1024 ? ws.max_rows : 1024;
+        if (geo.reduce == kReduceMax)
+            hipLaunchKernelGGL(spmm_longrow_combine_kernel<kReduceMax>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a.C,
+                               a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
+        else
+            hipLaunchKernelGGL(spmm_longrow_combine_kernel<kReduceSum>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a.C,
+                               a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
+        e = hipGetLastError();
+    }
+    const hipError_t ef = hipFreeAsync(base, st);
+    return e != hipSuccess ? e : ef;
 }
 
 
