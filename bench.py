@@ -215,6 +215,11 @@ def main():
             for valued in (True, False):
                 if n2 == N and valued:
                     continue
+                torch.cuda.empty_cache()
+                need = 4 * (K + M) * n2 * 1.05 + 8 * K * n2  # B + C, plus make_B's int32 temporaries
+                if need > torch.cuda.mem_get_info(dev)[0]:
+                    extra["N%d_%s" % (n2, "valued" if valued else "unweighted")] = {"skipped": "operands exceed free HBM"}
+                    continue
                 r2 = measure(n2, valued, max(args.steps // 4, 10), max(args.warmup // 2, 5), args.variant)
                 ab = algorithmic_bytes(M, K, n2, nnz, valued)
                 extra["N%d_%s" % (n2, "valued" if valued else "unweighted")] = {

@@ -23,6 +23,7 @@ constexpr int kFlagBatchStream = 0x20;   // == GESPMM_FLAG_BATCH_STREAM (force t
 constexpr int kFlagStrictOrder = 0x100;  // == GESPMM_FLAG_STRICT_ORDER (never split long rows)
 constexpr int kFlagSplitLongRows = 0x200; // == GESPMM_FLAG_SPLIT_LONG_ROWS (always run the long-row pass)
 constexpr int kLongRowThreshold = 2048;  // entries; lower bound of the long-row threshold (32 x mean degree)
+constexpr int64_t kMaxGridBlocks = (1ll << 24) - 1;  // 2^32 threads per launch / 256 threads per workgroup
 constexpr int kLongRowChunk = 2048;      // entries of a long row one workgroup sums per partial row
 constexpr int64_t kLongRowMinNnz = 1 << 23;  // auto: only matrices this large get the long-row pass
 constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force the cache-blocked path)

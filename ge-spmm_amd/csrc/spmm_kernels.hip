@@ -45,6 +45,7 @@
 #include <type_traits>
 
 #include "spmm_kernels.h"
+#include "workspace.h"
 
 namespace gespmm {
 
@@ -1137,7 +1138,7 @@ static hipError_t launch_naive(const SpmmArgs& a, hipStream_t st) {
     args.ntile = (a.N + W * V * S - 1) / (W * V * S);
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
-    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL((spmm_naive_kernel<V, S, W, VALUED, IDX64>), dim3((unsigned)nitems), dim3(kThreads), 0, st,
                        args);
     return hipGetLastError();
@@ -1183,12 +1184,17 @@ static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {
     if (rpw < G) rpw = G;
     if (rpw > kMaxRowsPerWave) rpw = kMaxRowsPerWave;
     rpw = rpw / G * G;
+    args.ntile = (a.N + W * V * S - 1) / (W * V * S);
+    // HIP caps a launch at 2^32 threads (gridDim.x * blockDim.x): with 256-thread workgroups that is
+    // kMaxGridBlocks workgroups. Tasks grow until the grid fits (M = 2^26 rows: >= 2 rows per task).
+    while (rpw < kMaxRowsPerWave &&
+           (((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw)) * args.ntile > kMaxGridBlocks)
+        rpw *= 2;
     args.rpw = rpw;
     args.nblk = (int)(((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw));
-    args.ntile = (a.N + W * V * S - 1) / (W * V * S);
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
-    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
     // Gather depth U: 8 B-row loads in flight per lane group unless the accumulators are
     // already wide (CF = 8) or the caller asks for the shallow form.
     if constexpr (V * S >= 8) {
@@ -1253,7 +1259,7 @@ static hipError_t launch_segstream(const SpmmArgs& a, int rpg, hipStream_t st) {
     args.ntile = (a.N + W * V * S - 1) / (W * V * S);
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
-    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
     if constexpr (V * S >= 8) {
         hipLaunchKernelGGL((spmm_segstream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
                            dim3(kThreads), 0, st, args);
@@ -1373,7 +1379,7 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
     off_partial = (off_partial + 255) & ~(size_t)255;
     const size_t bytes = off_partial + (size_t)max_chunks * (size_t)a.N * sizeof(float);
     char* base = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&base), bytes, st);
+    hipError_t e = workspace_alloc(reinterpret_cast<void**>(&base), bytes, st);
     if (e != hipSuccess) return e;
     ws.hdr = reinterpret_cast<LongRowHeader*>(base);
     ws.rowlist = reinterpret_cast<int4*>(base + off_rows);
@@ -1404,7 +1410,7 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
                                a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
         e = hipGetLastError();
     }
-    const hipError_t ef = hipFreeAsync(base, st);
+    const hipError_t ef = workspace_free(base, st);
     return e != hipSuccess ? e : ef;
 }
 
@@ -1417,7 +1423,7 @@ static hipError_t launch_slab(const SpmmArgs& a, hipStream_t st) {
     args.ntile = (a.N + W * V * S - 1) / (W * V * S);
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
-    if (nitems > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL((spmm_slab_kernel<V, S, W, VALUED, IDX64>), dim3((unsigned)nitems), dim3(kThreads), 0, st,
                        args);
     return hipGetLastError();
@@ -1455,7 +1461,7 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, hipS
     const int nslab = (int)(((int64_t)geo.K + geo.slab_rows - 1) / geo.slab_rows);
     if (nslab < 1 || M <= 0) return hipErrorInvalidValue;
     int32_t* split = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&split), (size_t)(nslab + 1) * (size_t)M * 4, st);
+    hipError_t e = workspace_alloc(reinterpret_cast<void**>(&split), (size_t)(nslab + 1) * (size_t)M * 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(spmm_slabplan_kernel, dim3((M + kWaves - 1) / kWaves), dim3(kThreads), 0, st, a0.rowptr,
                        a0.colind, split, M, nslab, geo.slab_rows, 1.0f / (float)geo.slab_rows);
@@ -1469,7 +1475,7 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, hipS
         if (valued) e = geo.idx64 ? slab_vs<true, true>(a, geo, st) : slab_vs<true, false>(a, geo, st);
         else e = geo.idx64 ? slab_vs<false, true>(a, geo, st) : slab_vs<false, false>(a, geo, st);
     }
-    const hipError_t ef = hipFreeAsync(split, st);
+    const hipError_t ef = workspace_free(split, st);
     return e != hipSuccess ? e : ef;
 }
 

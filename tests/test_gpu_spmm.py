@@ -316,10 +316,31 @@ def test_long_row_split_is_deterministic_and_within_tolerance(pkg, oracle):
             strict = {"flags": _lib.FLAG_SPLIT_LONG_ROWS | _lib.FLAG_STRICT_ORDER}
             assert_bits_equal(run(pkg, G, B, v, -1, strict), ref, "STRICT_ORDER N=%d" % N)
             assert_bits_equal(run(pkg, G, B, v, -1, None), ref, "small matrices never split, N=%d" % N)
-    # max reducer: exact under any association
+    # nnz unknown to the caller (the DGL entry point passes -1): the pass
+    # cannot size its workspace, so even with the split requested every row keeps the strict chain
+    import ctypes
+
     from gespmm_amd import spmm
 
     rp, ci = dev_csr(G)
+    B = oracle.hash_B(G["K"], 128, seed=5)
+    Bd = torch.from_numpy(B).cuda()
+    out = torch.empty(G["M"], 128, dtype=torch.float32, device="cuda")
+    c = _lib.LaunchCfg()
+    c.flags = _lib.FLAG_SPLIT_LONG_ROWS
+    rc = _lib.lib.gespmm_csr_spmm_f32_cfg(rp.data_ptr(), ci.data_ptr(), None, Bd.data_ptr(), out.data_ptr(), G["M"],
+                                          2**31 - 1, 128, -1, -1, ctypes.byref(c),
+                                          torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert_bits_equal(out.cpu().numpy(), oracle.spmm(G["rowptr"], G["colind"], None, B, "golden"), "nnz = -1")
+    # many launches back to back: the stream-ordered workspace is recycled, results identical
+    val_d = torch.from_numpy(val).cuda()
+    first = spmm.csr_spmm(rp, ci, val_d, Bd, cfg=split).clone()
+    for _ in range(20):
+        again = spmm.csr_spmm(rp, ci, val_d, Bd, cfg=split)
+    assert torch.equal(first, again)
+    # max reducer: exact under any association
     Bm = oracle.hash_B(G["K"], 64, seed=3)
     assert_bits_equal(spmm.csr_spmm_max(rp, ci, torch.from_numpy(Bm).cuda()).cpu().numpy(),
                       oracle.spmm_max(G["rowptr"], G["colind"], Bm), "max")
