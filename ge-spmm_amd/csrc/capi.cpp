@@ -56,6 +56,21 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     gespmm::Selection sel;
     int flags = 0;
     if (cfg) flags = cfg->flags;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {
+        // Under stream capture the paths that need a stream-ordered temporary are switched off: a
+        // captured allocation becomes a mem-alloc graph node, and replaying those costs seconds per
+        // launch on this runtime (measured: 14 s per GCN epoch on reddit-like instead of 20 ms).
+        // The streaming kernels need no workspace and give the same bits (slab path) or the strict
+        // CSR-order chain (long-row pass).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            flags |= gespmm::kFlagNoSlabBlocked | gespmm::kFlagStrictOrder;
+            flags &= ~(gespmm::kFlagSlabBlocked | gespmm::kFlagSplitLongRows);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
                                              cfg ? cfg->strips : 0, cfg ? cfg->group : 0,
                                              cfg ? cfg->rows_per_wave : 0, cfg ? cfg->slab_rows : 0, flags, &sel);
@@ -79,7 +94,6 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.row_end = nullptr;
     a.accumulate = 0;
 
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
     a.rpw = sel.geo.rows_per_group;
     if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);

@@ -44,8 +44,10 @@ hipError_t pool_for_current_device(hipMemPool_t* out) {
 
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t st) {
     hipMemPool_t pool = nullptr;
-    const hipError_t e = pool_for_current_device(&pool);
-    if (e != hipSuccess) return e;
+    if (pool_for_current_device(&pool) != hipSuccess) {
+        (void)hipGetLastError();  // no explicit pools on this runtime: the device's default pool will do
+        return hipMallocAsync(ptr, bytes ? bytes : 1, st);
+    }
     return hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, st);
 }
 

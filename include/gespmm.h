@@ -89,7 +89,11 @@ const char* gespmm_error_string(int code);
 /*
  * C[M x N] = A[M x K] * B[K x N], A in CSR (rowptr[M+1], colind[nnz], val[nnz]).
  * val == NULL means A == 1 on its pattern (the "topo"/no_edge_value kernels).
- * nnz may be passed as -1 when unknown (it only feeds the variant heuristic).
+ * nnz may be passed as -1 when unknown (it feeds the variant heuristic and sizes the
+ * long-row pass's temporary: with -1 every row keeps the strict chain).
+ * Temporaries (dense-graph cache blocking, long-row pass) are stream-ordered allocations
+ * from a pool the library owns; on a stream under capture both paths are switched off, so
+ * a captured call never allocates.
  */
 int gespmm_csr_spmm_f32(const int32_t* rowptr, const int32_t* colind, const float* val,
                         const float* B, float* C,

@@ -346,6 +346,37 @@ def test_long_row_split_is_deterministic_and_within_tolerance(pkg, oracle):
                       oracle.spmm_max(G["rowptr"], G["colind"], Bm), "max")
 
 
+def test_hip_graph_capture_uses_no_workspace(pkg, oracle):
+    """Captured into a HIP graph, the slab-blocked path and the long-row pass (both need a
+    stream-ordered temporary) fall back to the streaming kernel / the strict chain: the
+    replayed result is bit-exact everywhere and replay stays cheap."""
+    from gespmm_amd import _lib, spmm
+
+    G, _ = _skewed_csr(3)
+    rp, ci = dev_csr(G)
+    val = oracle.hash_val(G["nnz"], seed=2)
+    B = oracle.hash_B(G["K"], 128, seed=9)
+    ref = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+    vd, Bd = torch.from_numpy(val).cuda(), torch.from_numpy(B).cuda()
+    for flags in (_lib.FLAG_SPLIT_LONG_ROWS, _lib.FLAG_SLAB_BLOCKED):
+        out = torch.zeros(G["M"], 128, device="cuda")
+        cfg = {"flags": flags, "slab_rows": 500}
+        spmm.csr_spmm(rp, ci, vd, Bd, cfg=cfg, out=out)  # eager warm-up (allocates its temporaries)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                spmm.csr_spmm(rp, ci, vd, Bd, cfg=cfg, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        out.zero_()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert_bits_equal(out.cpu().numpy(), ref, "graph replay, flags=%#x" % flags)
+
+
 def test_slab_blocked_path_is_bit_exact(pkg, oracle, bundled):
     """The cache-blocked kernel for dense graphs consumes every row's entries in CSR
     order whatever the slab size — sorted, unsorted and repeated columns alike."""
