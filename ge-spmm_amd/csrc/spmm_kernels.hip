@@ -361,12 +361,19 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
                 off_t off[U - 1];
                 float v[U - 1];
                 float bv[U - 1][S][V];
+                // LDS reads first, all of them (clamped slot: always inside the tile), THEN the
+                // predicated gathers: with the read inside the predicate every gather waited for
+                // its own LDS round trip (tail of r entries cost r serial LDS latencies).
+#pragma unroll
+                for (int j = 0; j < U - 1; ++j) {
+                    const int kj = k + ((j < rem) ? j : rem - 1);
+                    off[j] = s_off[wave][kj];
+                    if constexpr (VALUED) v[j] = s_val[wave][kj];
+                    else v[j] = 1.0f;
+                }
 #pragma unroll
                 for (int j = 0; j < U - 1; ++j) {
                     if (j < rem) {
-                        off[j] = s_off[wave][k + j];
-                        if constexpr (VALUED) v[j] = s_val[wave][k + j];
-                        else v[j] = 1.0f;
 #pragma unroll
                         for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
                     }
@@ -844,7 +851,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slabplan_kernel(const int32_t* 
     const int lb = rowptr[r], hb = rowptr[r + 1];
     if (lane == 0) split[r] = lb;
     int run = 0;  // running maximum before the current chunk (wave-uniform)
-    constexpr int D = 4;  // chunks (coalesced 256-byte loads) in flight per wavefront
+    constexpr int D = 8;  // chunks (coalesced 256-byte loads) in flight per wavefront
     for (int sbase = lb; sbase < hb; sbase += 64 * D) {
         int c[D];
 #pragma unroll
