@@ -40,6 +40,8 @@ EXPORTS = [
     "gespmm_csr_spmm_max_f32",
     "gespmm_select_variant",
     "gespmm_csr_spmm_f32_cfg",
+    "gespmm_csr_spmm_workspace_bytes",
+    "gespmm_csr_spmm_f32_ws",
     "gespmm_sddmm_coo_f32",
     "gespmm_sddmm_csr_f32",
     "gespmm_csr2csc_workspace_bytes",
@@ -84,6 +86,11 @@ def _load():
     lib.gespmm_csr_spmm_f32_cfg.restype = c_int
     lib.gespmm_csr_spmm_f32_cfg.argtypes = [p, p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
                                             POINTER(LaunchCfg), p]
+    lib.gespmm_csr_spmm_workspace_bytes.restype = c_int64
+    lib.gespmm_csr_spmm_workspace_bytes.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(LaunchCfg)]
+    lib.gespmm_csr_spmm_f32_ws.restype = c_int
+    lib.gespmm_csr_spmm_f32_ws.argtypes = [p, p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                           POINTER(LaunchCfg), p, c_int64, p]
     lib.gespmm_csr_spmm_max_f32.restype = c_int
     lib.gespmm_csr_spmm_max_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_float, c_int, p]
     lib.gespmm_select_variant.restype = c_int

@@ -37,7 +37,7 @@ int check_common(const int32_t* rowptr, const int32_t* colind, const float* val,
 
 int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
              int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
-             void* stream) {
+             void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
     const int rc = check_common(rowptr, colind, val, B, C, M, K, N, nnz);
     if (rc != 0) return rc;
     if (M == 0 || N == 0) return 0;
@@ -64,7 +64,10 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
         // The streaming kernels need no workspace and give the same bits (slab path) or the strict
         // CSR-order chain (long-row pass).
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        if (ws != nullptr && ws_bytes > 0) {
+            // the caller's workspace: nothing is allocated whether capturing or not (a workspace that
+            // turns out too small falls back to the pool — gespmm_csr_spmm_workspace_bytes is an upper bound)
+        } else if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
             flags |= gespmm::kFlagNoSlabBlocked | gespmm::kFlagStrictOrder;
             flags &= ~(gespmm::kFlagSlabBlocked | gespmm::kFlagSplitLongRows);
         } else {
@@ -100,7 +103,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     else if (sel.variant == GESPMM_VARIANT_NAIVE)
         e = gespmm::launch_spmm_naive(a, sel.geo, st);
     else if (sel.geo.slab_blocked && reduce == gespmm::kReduceSum) {
-        e = gespmm::launch_spmm_slabblocked(a, sel.geo, st);
+        e = gespmm::launch_spmm_slabblocked(a, sel.geo, ws, (size_t)(ws_bytes > 0 ? ws_bytes : 0), st);
     } else {
         bool seg = sel.geo.segmented;
         if (flags & gespmm::kFlagBatchStream) seg = false;
@@ -110,7 +113,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
             a.rpw = sel.geo.rows_per_wave;
             a.long_row = sel.geo.split_long_rows ? sel.geo.long_row_threshold : 0;
             e = gespmm::launch_spmm_stream(a, sel.geo, st);
-            if (e == hipSuccess && sel.geo.split_long_rows) e = gespmm::launch_spmm_longrows(a, sel.geo, nnz, st);
+            if (e == hipSuccess && sel.geo.split_long_rows) e = gespmm::launch_spmm_longrows(a, sel.geo, nnz, ws, (size_t)(ws_bytes > 0 ? ws_bytes : 0), st);
         }
     }
     return (int)e;
@@ -155,6 +158,37 @@ int gespmm_csr_spmm_max_f32(const int32_t* rowptr, const int32_t* colind, const 
                             int64_t K, int64_t N, int64_t nnz, float empty_value, int variant, void* stream) {
     return run_spmm(rowptr, colind, nullptr, B, C, M, K, N, nnz, variant, nullptr, gespmm::kReduceMax, empty_value,
                     stream);
+}
+
+int64_t gespmm_csr_spmm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant,
+                                        const gespmm_launch_cfg* cfg) {
+    if (M < 0 || K < 0 || N < 0 || nnz < -1) return GESPMM_EINVAL;
+    if (variant < GESPMM_VARIANT_AUTO || variant >= GESPMM_NUM_VARIANTS) return GESPMM_EINVAL;
+    if (M == 0 || N == 0) return 0;
+    // the geometry depends on the alignment of B and C, unknown here: take the largest need
+    size_t need = 0;
+    for (int max_vec = 1; max_vec <= 4; max_vec *= 2) {
+        if (N % max_vec != 0) break;
+        gespmm::Selection sel;
+        if (gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0, cfg ? cfg->strips : 0,
+                                     cfg ? cfg->group : 0, cfg ? cfg->rows_per_wave : 0, cfg ? cfg->slab_rows : 0,
+                                     cfg ? cfg->flags : 0, &sel) != 0)
+            return GESPMM_EINVAL;
+        size_t b = 0;
+        if (sel.variant == GESPMM_VARIANT_PARREDUCE || sel.variant == GESPMM_VARIANT_NAIVE) b = 0;
+        else if (sel.geo.slab_blocked) b = gespmm::slabblocked_workspace_bytes(M, sel.geo);
+        else if (sel.geo.split_long_rows) b = gespmm::longrows_workspace_bytes(nnz, N, sel.geo.long_row_threshold);
+        if (b > need) need = b;
+    }
+    return (int64_t)need;
+}
+
+int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C,
+                           int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && workspace == nullptr)) return GESPMM_EINVAL;
+    return run_spmm(rowptr, colind, val, B, C, M, K, N, nnz, variant, cfg, gespmm::kReduceSum, 0.0f, stream, workspace,
+                    workspace_bytes);
 }
 
 int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N) { return gespmm::auto_variant(M, nnz, N); }

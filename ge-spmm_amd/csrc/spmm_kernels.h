@@ -2,6 +2,7 @@
 // kernel translation units. Not installed; the public surface is include/gespmm.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace gespmm {
@@ -70,8 +71,14 @@ struct Geometry {
 hipError_t launch_spmm_naive(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
-hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, hipStream_t st);
-hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+// The two paths below need a temporary: the caller's (ext_ws, 16-byte aligned, >= *_workspace_bytes) or,
+// when that is absent or too small, a stream-ordered block from the library's pool (workspace.h).
+size_t longrows_workspace_bytes(int64_t nnz, int64_t N, int long_row);
+hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, void* ext_ws, size_t ext_bytes,
+                                hipStream_t st);
+size_t slabblocked_workspace_bytes(int64_t M, const Geometry& geo);
+hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void* ext_ws, size_t ext_bytes,
+                                   hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
 // sddmm_kernels.hip

@@ -1369,7 +1369,17 @@ static hipError_t longrow_vs(const SpmmArgs& a, const LongRowWs& ws, const Geome
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, hipStream_t st) {
+size_t longrows_workspace_bytes(int64_t nnz, int64_t N, int long_row) {
+    if (long_row <= 0 || nnz <= long_row) return 0;
+    const int64_t max_rows = nnz / long_row + 1;
+    const int64_t max_chunks = nnz / kLongRowChunk + max_rows;
+    size_t off = sizeof(LongRowHeader) + (size_t)max_rows * sizeof(int4) + (size_t)max_chunks * sizeof(int2);
+    off = (off + 255) & ~(size_t)255;
+    return off + (size_t)max_chunks * (size_t)N * sizeof(float);
+}
+
+hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, void* ext_ws, size_t ext_bytes,
+                                hipStream_t st) {
     const bool valued = a.val != nullptr;
     if (geo.reduce == kReduceMax && valued) return hipErrorInvalidValue;
     if (a.long_row <= 0 || nnz <= a.long_row) return hipSuccess;  // no row can be long
@@ -1386,7 +1396,10 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
     off_partial = (off_partial + 255) & ~(size_t)255;
     const size_t bytes = off_partial + (size_t)max_chunks * (size_t)a.N * sizeof(float);
     char* base = nullptr;
-    hipError_t e = workspace_alloc(reinterpret_cast<void**>(&base), bytes, st);
+    hipError_t e = hipSuccess;
+    const bool own = !(ext_ws && ext_bytes >= bytes && (reinterpret_cast<uintptr_t>(ext_ws) & 15) == 0);
+    if (own) e = workspace_alloc(reinterpret_cast<void**>(&base), bytes, st);
+    else base = static_cast<char*>(ext_ws);
     if (e != hipSuccess) return e;
     ws.hdr = reinterpret_cast<LongRowHeader*>(base);
     ws.rowlist = reinterpret_cast<int4*>(base + off_rows);
@@ -1417,7 +1430,7 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
                                a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
         e = hipGetLastError();
     }
-    const hipError_t ef = workspace_free(base, st);
+    const hipError_t ef = own ? workspace_free(base, st) : hipSuccess;
     return e != hipSuccess ? e : ef;
 }
 
@@ -1462,13 +1475,23 @@ static hipError_t slab_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, hipStream_t st) {
+size_t slabblocked_workspace_bytes(int64_t M, const Geometry& geo) {
+    const int64_t nslab = ((int64_t)geo.K + geo.slab_rows - 1) / geo.slab_rows;
+    return (size_t)(nslab + 1) * (size_t)M * 4;
+}
+
+hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, void* ext_ws, size_t ext_bytes,
+                                   hipStream_t st) {
     if (geo.reduce != kReduceSum) return hipErrorInvalidValue;
     const int M = a0.M;
     const int nslab = (int)(((int64_t)geo.K + geo.slab_rows - 1) / geo.slab_rows);
     if (nslab < 1 || M <= 0) return hipErrorInvalidValue;
     int32_t* split = nullptr;
-    hipError_t e = workspace_alloc(reinterpret_cast<void**>(&split), (size_t)(nslab + 1) * (size_t)M * 4, st);
+    const size_t bytes = (size_t)(nslab + 1) * (size_t)M * 4;
+    hipError_t e = hipSuccess;
+    const bool own = !(ext_ws && ext_bytes >= bytes && (reinterpret_cast<uintptr_t>(ext_ws) & 15) == 0);
+    if (own) e = workspace_alloc(reinterpret_cast<void**>(&split), bytes, st);
+    else split = static_cast<int32_t*>(ext_ws);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(spmm_slabplan_kernel, dim3((M + kWaves - 1) / kWaves), dim3(kThreads), 0, st, a0.rowptr,
                        a0.colind, split, M, nslab, geo.slab_rows, 1.0f / (float)geo.slab_rows);
@@ -1482,7 +1505,7 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, hipS
         if (valued) e = geo.idx64 ? slab_vs<true, true>(a, geo, st) : slab_vs<true, false>(a, geo, st);
         else e = geo.idx64 ? slab_vs<false, true>(a, geo, st) : slab_vs<false, false>(a, geo, st);
     }
-    const hipError_t ef = workspace_free(split, st);
+    const hipError_t ef = own ? workspace_free(split, st) : hipSuccess;
     return e != hipSuccess ? e : ef;
 }
 

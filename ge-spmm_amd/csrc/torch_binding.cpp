@@ -58,8 +58,19 @@ torch::Tensor spmm_impl(const torch::Tensor& rowptr, const torch::Tensor& colind
     const int64_t M = rowptr.numel() - 1, K = dense.size(0), N = dense.size(1), nnz = colind.numel();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dense.device());
     auto out = torch::empty({M, N}, dense.options());
-    check_rc(gespmm_csr_spmm_f32(rowptr.data_ptr<int32_t>(), colind.data_ptr<int32_t>(), val, dense.data_ptr<float>(),
-                                 out.data_ptr<float>(), M, K, N, nnz, (int)variant, current_stream(dense)),
+    // Scratch for the two paths that need it (dense-graph cache blocking, long-row pass) comes from
+    // torch's caching allocator: no driver allocation per call, and legal under torch.cuda.graph.
+    const int64_t ws_bytes = gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, (int)variant, nullptr);
+    TORCH_CHECK(ws_bytes >= 0, "gespmm_csr_spmm_workspace_bytes failed: ", gespmm_error_string((int)ws_bytes));
+    torch::Tensor ws;
+    void* ws_ptr = nullptr;
+    if (ws_bytes > 0) {
+        ws = torch::empty({ws_bytes}, dense.options().dtype(torch::kUInt8));
+        ws_ptr = ws.data_ptr();
+    }
+    check_rc(gespmm_csr_spmm_f32_ws(rowptr.data_ptr<int32_t>(), colind.data_ptr<int32_t>(), val,
+                                    dense.data_ptr<float>(), out.data_ptr<float>(), M, K, N, nnz, (int)variant, nullptr,
+                                    ws_ptr, ws_bytes, current_stream(dense)),
              "gespmm_csr_spmm_f32");
     return out;
 }

@@ -103,10 +103,16 @@ def _spmm(rowptr, colind, values, dense, variant, cfg, out):
         if tuple(out.shape) != (M, N) or out.device != dev:
             raise ValueError("out must be f32[M, N] on the same device")
     c = _make_cfg(cfg)
+    cref = ctypes.byref(c) if c is not None else None
+    # scratch for the cache-blocked / long-row paths from torch's allocator (see torch_binding.cpp)
+    ws_bytes = lib.gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, int(variant), cref)
+    if ws_bytes < 0:
+        check(int(ws_bytes), "gespmm_csr_spmm_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
     with _on_device(dev):
-        rc = lib.gespmm_csr_spmm_f32_cfg(_ptr(rowptr), _ptr(colind), _ptr(values) if values is not None else None,
-                                         _ptr(dense), _ptr(out), M, K, N, nnz, int(variant),
-                                         ctypes.byref(c) if c is not None else None, _stream(dev))
+        rc = lib.gespmm_csr_spmm_f32_ws(_ptr(rowptr), _ptr(colind), _ptr(values) if values is not None else None,
+                                        _ptr(dense), _ptr(out), M, K, N, nnz, int(variant), cref,
+                                        _ptr(ws) if ws is not None else None, ws_bytes, _stream(dev))
     check(rc, "gespmm_csr_spmm_f32")
     return out
 

@@ -151,6 +151,25 @@ int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const 
                             int variant, const gespmm_launch_cfg* cfg, void* stream);
 
 /*
+ * The same product with a CALLER-PROVIDED temporary (cuSPARSE/rocSPARSE style: query, allocate,
+ * run). Two paths of the library need scratch memory — column-slab cache blocking for dense
+ * graphs (per-row split points) and the chunked long-row pass (partial rows). The plain entry
+ * points above take it stream-ordered from a pool the library owns; this one uses
+ * `workspace` (device memory, 16-byte aligned, at least gespmm_csr_spmm_workspace_bytes() for
+ * the same shape/variant/cfg) and never allocates — which also keeps both paths available on a
+ * stream that is being captured into a HIP graph. workspace_bytes == 0 behaves like
+ * gespmm_csr_spmm_f32_cfg. A framework binding passes memory from the framework's own
+ * caching allocator here.
+ */
+int64_t gespmm_csr_spmm_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant,
+                                        const gespmm_launch_cfg* cfg /* may be NULL */);
+int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C,
+                           int64_t M, int64_t K, int64_t N, int64_t nnz, int variant,
+                           const gespmm_launch_cfg* cfg /* may be NULL */, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+
+
+/*
  * SDDMM: out[e] = sum_j D1[row(e), j] * D2[col(e), j], e in pattern order.
  * COO: row(e) = rowind[e].  CSR: row(e) = the row whose [rowptr[r], rowptr[r+1]) holds e.
  * D1 is M x N, D2 is K x N, row-major; out has nnz floats.

@@ -24,12 +24,17 @@ g = graphs.synthetic_graph(name, device=dev)
 M, K, nnz = g["M"], g["K"], g["nnz"]
 rp, ci = g["rowptr"], g["colind"]
 val = torch.rand(nnz, device=dev)
+UNW = os.environ.get("UNWEIGHTED") == "1"
+def call(cfg=None):
+    if UNW:
+        return spmm.csr_spmm_no_edge_value(rp, ci, B, out=C, cfg=cfg)
+    return spmm.csr_spmm(rp, ci, val, B, out=C, cfg=cfg)
 B = torch.rand(K, N, device=dev); C = torch.empty(M, N, device=dev)
-print("%s N=%d auto: %.1f us" % (name, N, time_fn(lambda: spmm.csr_spmm(rp, ci, val, B, out=C))))
+print("%s N=%d auto: %.1f us" % (name, N, time_fn(lambda: call())))
 for kname, flag in (("seg", F.FLAG_SEG_STREAM), ("batch", F.FLAG_BATCH_STREAM)):
     line = "  %-5s:" % kname
     for r in (1, 2, 4, 8, 16):
         for extra, tag in ((0, ""),):
             cfg = dict(rows_per_wave=r, flags=flag | extra)
-            line += " r%d%s %.1f |" % (r, tag, time_fn(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, cfg=cfg)))
+            line += " r%d%s %.1f |" % (r, tag, time_fn(lambda: call(cfg)))
     print(line); sys.stdout.flush()

@@ -346,35 +346,68 @@ def test_long_row_split_is_deterministic_and_within_tolerance(pkg, oracle):
                       oracle.spmm_max(G["rowptr"], G["colind"], Bm), "max")
 
 
-def test_hip_graph_capture_uses_no_workspace(pkg, oracle):
-    """Captured into a HIP graph, the slab-blocked path and the long-row pass (both need a
-    stream-ordered temporary) fall back to the streaming kernel / the strict chain: the
-    replayed result is bit-exact everywhere and replay stays cheap."""
+def test_hip_graph_capture(pkg, oracle):
+    """Captured into a HIP graph nothing may be allocated by the library. Through the bindings
+    the scratch of the slab-blocked path and the long-row pass is a framework tensor
+    (gespmm_csr_spmm_f32_ws): both paths run inside the graph. Through the plain entry point
+    (no workspace) they fall back to the streaming kernel / the strict chain. Either way the
+    replay is cheap and correct."""
+    import ctypes
+
     from gespmm_amd import _lib, spmm
 
-    G, _ = _skewed_csr(3)
+    G, long_rows = _skewed_csr(3)
     rp, ci = dev_csr(G)
     val = oracle.hash_val(G["nnz"], seed=2)
     B = oracle.hash_B(G["K"], 128, seed=9)
     ref = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+    scale = oracle.spmm_abs(G["rowptr"], G["colind"], val, B)
     vd, Bd = torch.from_numpy(val).cuda(), torch.from_numpy(B).cuda()
-    for flags in (_lib.FLAG_SPLIT_LONG_ROWS, _lib.FLAG_SLAB_BLOCKED):
-        out = torch.zeros(G["M"], 128, device="cuda")
-        cfg = {"flags": flags, "slab_rows": 500}
-        spmm.csr_spmm(rp, ci, vd, Bd, cfg=cfg, out=out)  # eager warm-up (allocates its temporaries)
+
+    def capture(fn):
+        fn()  # eager warm-up
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
-                spmm.csr_spmm(rp, ci, vd, Bd, cfg=cfg, out=out)
+                fn()
         torch.cuda.current_stream().wait_stream(side)
+        return graph
+
+    for flags in (_lib.FLAG_SPLIT_LONG_ROWS, _lib.FLAG_SLAB_BLOCKED):
+        cfg = {"flags": flags, "slab_rows": 500}
+        out = torch.zeros(G["M"], 128, device="cuda")
+        eager = spmm.csr_spmm(rp, ci, vd, Bd, cfg=cfg).clone()
+        graph = capture(lambda: spmm.csr_spmm(rp, ci, vd, Bd, cfg=cfg, out=out))
         out.zero_()
         for _ in range(3):
             graph.replay()
         torch.cuda.synchronize()
-        assert_bits_equal(out.cpu().numpy(), ref, "graph replay, flags=%#x" % flags)
+        assert torch.equal(out, eager), "binding: the captured call takes the same path as the eager one"
+        got = out.cpu().numpy()
+        short = np.setdiff1d(np.arange(G["M"]), long_rows)
+        assert np.array_equal(bits(got[short]), bits(ref[short]))
+        tol = 1e-4 * np.maximum(np.abs(ref[long_rows]), scale[long_rows])
+        assert np.all(np.abs(got[long_rows].astype(np.float64) - ref[long_rows]) <= tol + 1e-30)
+
+        # plain C entry point, no workspace: strict / streaming fallback under capture, bit-exact everywhere
+        c = _lib.LaunchCfg()
+        c.flags, c.slab_rows = flags, 500
+        out2 = torch.zeros(G["M"], 128, device="cuda")
+
+        def raw():
+            rc = _lib.lib.gespmm_csr_spmm_f32_cfg(rp.data_ptr(), ci.data_ptr(), vd.data_ptr(), Bd.data_ptr(),
+                                                  out2.data_ptr(), G["M"], G["K"], 128, G["nnz"], -1, ctypes.byref(c),
+                                                  torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+
+        graph2 = capture(raw)
+        out2.zero_()
+        graph2.replay()
+        torch.cuda.synchronize()
+        assert_bits_equal(out2.cpu().numpy(), ref, "plain entry point under capture, flags=%#x" % flags)
 
 
 def test_slab_blocked_path_is_bit_exact(pkg, oracle, bundled):
