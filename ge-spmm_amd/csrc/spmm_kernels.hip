@@ -1007,22 +1007,41 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
             float v[U];
             float bv[U][S][V];
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
+            for (int j = 0; j < U; ++j) {  // LDS reads are unconditional (clamped slot)
                 const int tj = t + ((j < cnt) ? j : cnt - 1);
                 off[j] = s_off[wave][g][tj];
                 if constexpr (VALUED) v[j] = s_val[wave][g][tj];
                 else v[j] = 1.0f;
-#pragma unroll
-                for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
             }
+            if (cnt >= U) {  // full step: U gathers back to back
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                if (j < cnt) {
+                for (int j = 0; j < U; ++j)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+#pragma unroll
+                for (int j = 0; j < U; ++j)
 #pragma unroll
                     for (int s = 0; s < S; ++s)
 #pragma unroll
                         for (int k2 = 0; k2 < V; ++k2)
                             acc[s][k2] = combine<kReduceSum, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
+            } else {  // last step of the segment: only the cnt live gathers are issued
+#pragma unroll
+                for (int j = 0; j < U - 1; ++j) {
+                    if (j < cnt) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U - 1; ++j) {
+                    if (j < cnt) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int k2 = 0; k2 < V; ++k2)
+                                acc[s][k2] = combine<kReduceSum, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
+                    }
                 }
             }
             if (k + U >= tbase + T) {

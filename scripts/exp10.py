@@ -15,10 +15,12 @@ g = graphs.synthetic_graph(name, device=dev)
 M, K, nnz = g["M"], g["K"], g["nnz"]
 val = torch.rand(nnz, device=dev)
 B = torch.rand(K, N, device=dev); C = torch.empty(M, N, device=dev)
+import json
+cfg = json.loads(os.environ["GESPMM_CFG"]) if "GESPMM_CFG" in os.environ else None
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C)
+spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C, cfg=cfg)
 torch.cuda.synchronize(); e0.record()
 for _ in range(iters):
-    spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C)
+    spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C, cfg=cfg)
 e1.record(); torch.cuda.synchronize()
 print("%s N=%d: %.1f us per call" % (name, N, e0.elapsed_time(e1) / iters * 1e3))
