@@ -893,13 +893,14 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
     constexpr int T = (W > 32) ? W : 32;
     constexpr int E = T / W;
     constexpr int U = (V * S >= 8) ? 4 : 8;  // U = 4 measured: 6.1 vs 4.8 ms on reddit-like (misses need the depth)
-    constexpr int R = kSlabRowsPerGroup;  // consecutive rows one lane group walks per launch
+    constexpr int RMAX = kSlabRowsPerGroup;
+    const int R = a.rpw;  // consecutive rows one lane group walks per launch (1..RMAX, wave-uniform)
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
 
     __shared__ off_t s_off[kWaves][G][T];
     __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? G : 1][VALUED ? T : 1];
-    __shared__ int s_b[kWaves][G][R];
-    __shared__ int s_e[kWaves][G][R];
+    __shared__ int s_b[kWaves][G][RMAX];
+    __shared__ int s_e[kWaves][G][RMAX];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1458,7 +1459,11 @@ template <int V, int S, int W, bool VALUED, bool IDX64>
 static hipError_t launch_slab(const SpmmArgs& a, hipStream_t st) {
     constexpr int G = 64 / W;
     SpmmArgs args = a;
-    args.nblk = (int)(((int64_t)a.M + kWaves * G * kSlabRowsPerGroup - 1) / (kWaves * G * kSlabRowsPerGroup));
+    int R = a.rpw;  // rows per lane group (slab path)
+    if (R < 1) R = 1;
+    if (R > kSlabRowsPerGroup) R = kSlabRowsPerGroup;
+    args.rpw = R;
+    args.nblk = (int)(((int64_t)a.M + kWaves * G * R - 1) / (kWaves * G * R));
     args.ntile = (a.N + W * V * S - 1) / (W * V * S);
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
