@@ -25,7 +25,9 @@ inline bool aligned_to(const void* p, uintptr_t a) { return (reinterpret_cast<ui
 int check_common(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, const float* C,
                  int64_t M, int64_t K, int64_t N, int64_t nnz) {
     if (M < 0 || K < 0 || N < 0 || nnz < -1) return GESPMM_EINVAL;
-    if (M > 0x7fffffffLL - 64 || K > 0x7fffffffLL || N > 0x7fffffffLL / 4 || nnz > 0x7fffffffLL) return GESPMM_ERANGE;
+    // CSR positions are int32 and the kernels look up to a few tiles past a row's end before clamping
+    if (M > 0x7fffffffLL - 64 || K > 0x7fffffffLL || N > 0x7fffffffLL / 4 || nnz > 0x7fffffffLL - 4096)
+        return GESPMM_ERANGE;
     if (M == 0 || N == 0) return 0;  // nothing to do; pointers may be null
     if (!rowptr || !C) return GESPMM_EINVAL;
     if ((nnz != 0) && (!colind || !B)) return GESPMM_EINVAL;
