@@ -32,11 +32,14 @@
 //
 // Kernels in this file (selection: select.cpp, measurements: DESIGN.md §3.2):
 //   spmm_naive_kernel      variant 0: no LDS staging
-//   spmm_stream_kernel     batch-stream: rows walked G at a time over a wave-wide tile
+//   spmm_stream_kernel     batch-stream (default): rows walked G at a time over a wave-wide tile,
+//                          small tasks (~12 KB of gathered B per wavefront)
 //   spmm_segstream_kernel  segmented-stream: one continuous gather stream per lane group
-//   spmm_longrow_kernel    hub rows of skewed graphs, one workgroup per row (deterministic)
+//                          (short rows with B resident in L2; otherwise opt-in)
+//   spmm_longrow_{list,chunk,combine}_kernel   hub rows of skewed graphs in 2048-entry chunks
+//                          spread over the chip, ordered combine (deterministic)
 //   spmm_slabplan_kernel / spmm_slab_kernel   cache blocking for dense graphs
-//   spmm_parreduce_kernel  variant 5: lanes over nnz, xor-butterfly reduction
+//   spmm_parreduce_kernel  variant 5: lanes over nnz, reduce-scatter + xor butterfly
 //
 // No MFMA: the inner product is a gather, not a dense contraction.
 
