@@ -190,8 +190,14 @@ hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, co
     while (V > 1 && ((N % V) != 0 || (reinterpret_cast<uintptr_t>(D1) % (4u * V)) != 0 ||
                      (reinterpret_cast<uintptr_t>(D2) % (4u * V)) != 0))
         V >>= 1;
+    // Lanes per edge: a lane walks ~2 dwordx4 vectors (8 scalars when the rows allow no vector loads)
+    // of both rows, so a wavefront has 64/W edges in flight and the butterfly is log2(W) steps.
+    // Measured against "just enough lanes to cover N" (profiles/r01/sddmm_group_width.log):
+    // N=41 2.4-2.8x, N=64 1.35x, N=128 1.2x faster on reddit-like, equal or better on com-Amazon-like.
+    // Both forms use the same width, so COO and CSR results agree bit for bit.
+    const int64_t per_lane = (V == 4) ? 2 : 8;
     int W = 4;
-    while (W < 64 && (int64_t)W * V < N) W <<= 1;
+    while (W < 64 && (int64_t)W * V * per_lane < N) W <<= 1;
     const int m = (int)M, z = (int)nnz, n = (int)N;
     if (csr) {
         if (V == 4) return sddmm_w<4, true>(W, rows, colind, D1, D2, out, m, z, n, st);
