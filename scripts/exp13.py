@@ -20,7 +20,8 @@ def time_fn(fn, iters=ITERS, warm=max(2, ITERS // 10)):
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "com-amazon-like"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-g = graphs.synthetic_graph(name, device=dev)
+LOC = float(os.environ.get("LOCALITY", "0"))
+g = graphs.synthetic_graph(name, device=dev, locality=LOC)
 M, K, nnz = g["M"], g["K"], g["nnz"]
 rp, ci = g["rowptr"], g["colind"]
 val = torch.rand(nnz, device=dev)
