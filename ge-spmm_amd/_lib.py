@@ -39,6 +39,8 @@ EXPORTS = [
     "gespmm_csr_spmm_f32",
     "gespmm_csr_spmm_max_f32",
     "gespmm_select_variant",
+    "gespmm_dgl_csrmm_sum_f32",
+    "gespmm_dgl_csrmm_max_f32",
     "gespmm_csr_spmm_f32_cfg",
     "gespmm_csr_spmm_workspace_bytes",
     "gespmm_csr_spmm_f32_ws",
@@ -93,6 +95,9 @@ def _load():
                                            POINTER(LaunchCfg), p, c_int64, p]
     lib.gespmm_csr_spmm_max_f32.restype = c_int
     lib.gespmm_csr_spmm_max_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, c_float, c_int, p]
+    for fn in (lib.gespmm_dgl_csrmm_sum_f32, lib.gespmm_dgl_csrmm_max_f32):
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_int, p, p, p, p, p]
     lib.gespmm_select_variant.restype = c_int
     lib.gespmm_select_variant.argtypes = [c_int64, c_int64, c_int64]
     lib.gespmm_sddmm_coo_f32.restype = c_int

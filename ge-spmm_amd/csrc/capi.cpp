@@ -198,6 +198,18 @@ int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const f
 
 int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N) { return gespmm::auto_variant(M, nnz, N); }
 
+int gespmm_dgl_csrmm_sum_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,
+                             void* stream) {
+    return run_spmm(indptr, indices, nullptr, B, C, m, /*K unknown*/ 0x7fffffffLL, n, /*nnz unknown*/ -1,
+                    GESPMM_VARIANT_AUTO, nullptr, gespmm::kReduceSum, 0.0f, stream);
+}
+
+int gespmm_dgl_csrmm_max_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,
+                             void* stream) {
+    return run_spmm(indptr, indices, nullptr, B, C, m, 0x7fffffffLL, n, -1, GESPMM_VARIANT_AUTO, nullptr,
+                    gespmm::kReduceMax, -10000.0f, stream);
+}
+
 int gespmm_sddmm_coo_f32(const int32_t* rowind, const int32_t* colind, const float* D1, const float* D2, float* out,
                          int64_t nnz, int64_t N, void* stream) {
     if (nnz < 0 || N < 0) return GESPMM_EINVAL;

@@ -170,6 +170,21 @@ int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const f
 
 
 /*
+ * The DGL kernel patch's entry points (dgl-custom/binary_reduce_sum.cu:310-335 XTopoCsrmm<float>,
+ * binary_reduce_max.cu:182-207 XTopoCsrmmmax<float>) with their argument list — (m, n, indptr,
+ * indices, B, C) plus the stream DGL keeps in its RuntimeConfig: C[m x n] = sum / max over the
+ * row's neighbours of B[neighbour, :], A == 1 on the CSR pattern. DGL passes neither the number
+ * of source nodes nor nnz at that point: 64-bit offsets into B are used and every row keeps the
+ * strict CSR-order chain. Rows without neighbours give 0 (sum) or -10000 (max: the patch's
+ * max_init, binary_reduce_max.cu:22-24). Returns 0 or an error code as above (the patch returns
+ * its cudaError the same way).
+ */
+int gespmm_dgl_csrmm_sum_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,
+                             void* stream);
+int gespmm_dgl_csrmm_max_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,
+                             void* stream);
+
+/*
  * SDDMM: out[e] = sum_j D1[row(e), j] * D2[col(e), j], e in pattern order.
  * COO: row(e) = rowind[e].  CSR: row(e) = the row whose [rowptr[r], rowptr[r+1]) holds e.
  * D1 is M x N, D2 is K x N, row-major; out has nnz floats.

@@ -255,6 +255,30 @@ def test_max_reducer(pkg, oracle, bundled):
                     assert_bits_equal(C, ref, "max N=%d init=%r v%d" % (N, init, variant))
 
 
+def test_dgl_entry_points(pkg, oracle, bundled):
+    """gespmm_dgl_csrmm_{sum,max}_f32 take exactly what the DGL patch's XTopoCsrmm /
+    XTopoCsrmmmax receive (no K, no nnz): same bits as the oracle's golden loop."""
+    from gespmm_amd import _lib
+
+    for G in (bundled["cora"], edge_case_csr(5), _skewed_csr(2)[0]):
+        rp, ci = dev_csr(G)
+        for N in (7, 64, 128):
+            B = oracle.hash_B(G["K"], N, seed=N + 3)
+            Bd = torch.from_numpy(B).cuda()
+            out = torch.empty(G["M"], N, dtype=torch.float32, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            rc = _lib.lib.gespmm_dgl_csrmm_sum_f32(G["M"], N, rp.data_ptr(), ci.data_ptr(), Bd.data_ptr(),
+                                                   out.data_ptr(), st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert_bits_equal(out.cpu().numpy(), oracle.spmm(G["rowptr"], G["colind"], None, B, "golden"), "dgl sum")
+            rc = _lib.lib.gespmm_dgl_csrmm_max_f32(G["M"], N, rp.data_ptr(), ci.data_ptr(), Bd.data_ptr(),
+                                                   out.data_ptr(), st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert_bits_equal(out.cpu().numpy(), oracle.spmm_max(G["rowptr"], G["colind"], B), "dgl max")
+
+
 def test_stream_semantics(pkg, oracle, bundled):
     """Launches go to the CURRENT torch stream (the reference uses the legacy default
     stream, spmm_kernel.cu:189,196,203)."""
