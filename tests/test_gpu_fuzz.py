@@ -72,3 +72,28 @@ def test_random_shapes_and_knobs(pkg, oracle):
             scale = oracle.spmm_abs(G["rowptr"], G["colind"], val, B)
             tol = 1e-4 * np.maximum(np.abs(ref[long_rows]), scale[long_rows])
             assert np.all(np.abs(C[long_rows].astype(np.float64) - ref[long_rows]) <= tol + 1e-30), what
+
+
+def test_wide_outputs_use_several_column_tiles(pkg, oracle):
+    """N beyond one column tile (512 columns at V=4, S=2): the tile index joins the work-item id."""
+    from gespmm_amd import _lib, spmm
+
+    rng = np.random.RandomState(7)
+    for N in (513, 777, 1024, 1500, 2048):
+        G, _ = random_csr(rng)
+        val = oracle.hash_val(G["nnz"], seed=N)
+        B = oracle.hash_B(G["K"], N, seed=N)
+        ref = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
+        rp, ci = torch.from_numpy(G["rowptr"]).cuda(), torch.from_numpy(G["colind"]).cuda()
+        vd, Bd = torch.from_numpy(val).cuda(), torch.from_numpy(B).cuda()
+        for variant in (-1, 0, 1, 3, 4, 5):
+            for flags in (0, _lib.FLAG_SEG_STREAM, _lib.FLAG_SLAB_BLOCKED, _lib.FLAG_NO_XCD_REMAP):
+                if variant in (0, 5) and flags:
+                    continue
+                C = spmm.csr_spmm(rp, ci, vd, Bd, variant=variant, cfg={"flags": flags, "slab_rows": 300}).cpu().numpy()
+                what = "N=%d variant=%d flags=%#x M=%d nnz=%d" % (N, variant, flags, G["M"], G["nnz"])
+                if variant == 5:
+                    scale = oracle.spmm_abs(G["rowptr"], G["colind"], val, B)
+                    assert np.all(np.abs(C.astype(np.float64) - ref) <= 1e-4 * np.maximum(np.abs(ref), scale) + 1e-30), what
+                else:
+                    assert np.array_equal(bits(C), bits(ref)), what
