@@ -43,13 +43,20 @@ name = sys.argv[1] if len(sys.argv) > 1 else "com-amazon-like"
 g = graphs.synthetic_graph(name)
 M, K = g["M"], g["K"]
 rp = g["rowptr"].numpy().astype(np.int64); ci = g["colind"].numpy().astype(np.int64)
-order = bfs_order(rp, ci, M)
+MODE = os.environ.get("ORDER", "bfs")
+if MODE == "bfs":
+    order = bfs_order(rp, ci, M)
+elif MODE == "degdesc":
+    order = np.argsort(-np.diff(rp), kind="stable")
+elif MODE == "heavyfirst":  # rows above 64 entries first (in natural order), the rest in natural order
+    d = np.diff(rp)
+    order = np.concatenate([np.nonzero(d > 64)[0], np.nonzero(d <= 64)[0]])
 rp2, ci2 = permute_rows(rp, ci, order)
 for N in (128, 32, 512):
     B = torch.rand(K, N, device=dev); C = torch.empty(M, N, device=dev)
     line = "%s N=%d:" % (name, N)
-    for label, (a, b) in (("natural", (g["rowptr"].to(dev), g["colind"].to(dev))), ("bfs rows", (torch.from_numpy(rp2).to(dev), torch.from_numpy(ci2).to(dev)))):
+    for label, (a, b) in (("natural", (g["rowptr"].to(dev), g["colind"].to(dev))), (MODE + " rows", (torch.from_numpy(rp2).to(dev), torch.from_numpy(ci2).to(dev)))):
         val = torch.rand(b.numel(), device=dev)
-        for kname, cfg in (("auto", None), ("seg r4", dict(rows_per_wave=4, flags=F.FLAG_SEG_STREAM)), ("batch r8", dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM))):
+        for kname, cfg in (("auto", None), ("noremap", dict(flags=F.FLAG_NO_XCD_REMAP)), ("batch r8", dict(rows_per_wave=8, flags=F.FLAG_BATCH_STREAM))):
             line += " %s/%s %.1f |" % (label, kname, time_fn(lambda: spmm.csr_spmm(a, b, val, B, out=C, cfg=cfg)))
     print(line); sys.stdout.flush()
