@@ -88,6 +88,37 @@ def test_loader_large_random_file(pkg, oracle, tmp_path):
     assert np.array_equal(got["val"], ref["val"])
 
 
+@pytest.mark.parametrize("kind", ["real general", "pattern symmetric", "real general, entries split over lines"])
+def test_loader_multithreaded_parse(pkg, oracle, tmp_path, kind):
+    """Files above 8 MB are parsed in pieces by several host threads and ordered by a counting sort +
+    per-row sorts: same rows / cols / values as the oracle's serial restatement, in the same order
+    (ties keep file order). A file whose entries are split over lines takes the serial path."""
+    rng = np.random.RandomState(5)
+    M, K, n = 50000, 40000, 700000
+    r = rng.randint(1, M + 1, n)
+    c = rng.randint(1, (M if "symmetric" in kind else K) + 1, n)
+    c[::97] = c[1::97][: len(c[::97])]  # sprinkle repeats
+    v = rng.randint(-999, 1000, n) / 8.0
+    p = tmp_path / "big.mtx"
+    field, sym = ("pattern", "symmetric") if "pattern" in kind else ("real", "general")
+    with open(p, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s %s\n%% generated\n%d %d %d\n" % (field, sym, M, M if sym == "symmetric" else K, n))
+        if field == "pattern":
+            f.write("".join("%d %d\n" % (r[i], c[i]) for i in range(n)))
+            f.write("".join("%d   %d\n" % (r[i], c[i]) for i in range(0, n, 2)))  # pad above 8 MB: extra lines past n are ignored
+        elif "split" in kind:
+            f.write("".join("%d\n%d %.3f\n" % (r[i], c[i], v[i]) for i in range(n)))
+        else:
+            f.write("".join("%d %d %.3f\n" % (r[i], c[i], v[i]) for i in range(n)))
+    assert os.path.getsize(p) > (8 << 20)
+    from gespmm_amd import graphs
+
+    got, ref = graphs.read_mtx(p), oracle.read_mtx(p)
+    assert ref["rc"] == 0 and got["nnz"] == ref["nnz"] and got["nnz"] > 0
+    assert np.array_equal(got["row"], ref["row"]) and np.array_equal(got["col"], ref["col"])
+    assert np.array_equal(got["val"], ref["val"])
+
+
 def test_coo_to_csr_matches_oracle(pkg, oracle):
     from gespmm_amd import _lib, graphs
 
