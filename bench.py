@@ -295,6 +295,10 @@ def main():
                 "kernel_us": res["kernel_ms"] * 1e3,
                 "roof_gflops": roof_gflops,
                 "gflops_kernel": 2.0 * nnz * N / (res["kernel_ms"] * 1e-3) / 1e9,
+                # diagnostic: B-row gathers without reuse, 4*nnz*N bytes, and their rate —
+                # what the memory system actually moves when B does not fit the L2s
+                "gather_bytes_per_launch": 4 * nnz * N,
+                "gather_GBs": 4.0 * nnz * N / (res["kernel_ms"] * 1e-3) / 1e9,
             },
             "cpu_baseline": cpu,
             "verified_vs_oracle": verified,
