@@ -219,7 +219,7 @@ int gespmm_sddmm_coo_f32(const int32_t* rowind, const int32_t* colind, const flo
     if (!aligned_to(rowind, 4) || !aligned_to(colind, 4) || !aligned_to(D1, 4) || !aligned_to(D2, 4) ||
         !aligned_to(out, 4))
         return GESPMM_EALIGN;
-    return (int)gespmm::launch_sddmm(rowind, false, colind, D1, D2, out, 0, nnz, N,
+    return (int)gespmm::launch_sddmm(rowind, false, colind, D1, D2, out, 0, nnz, N, 0,
                                      reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -232,7 +232,7 @@ int gespmm_sddmm_csr_f32(const int32_t* rowptr, const int32_t* colind, const flo
     if (!aligned_to(rowptr, 4) || !aligned_to(colind, 4) || !aligned_to(D1, 4) || !aligned_to(D2, 4) ||
         !aligned_to(out, 4))
         return GESPMM_EALIGN;
-    return (int)gespmm::launch_sddmm(rowptr, true, colind, D1, D2, out, M, nnz, N,
+    return (int)gespmm::launch_sddmm(rowptr, true, colind, D1, D2, out, M, nnz, N, 0,
                                      reinterpret_cast<hipStream_t>(stream));
 }
 

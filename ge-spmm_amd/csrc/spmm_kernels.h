@@ -82,9 +82,13 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void*
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
 // sddmm_kernels.hip
+constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form
 hipError_t launch_sddmm(const int32_t* rowind_or_rowptr, bool csr, const int32_t* colind,
                         const float* D1, const float* D2, float* out,
-                        int64_t M, int64_t nnz, int64_t N, hipStream_t st);
+                        int64_t M, int64_t nnz, int64_t N, int flags, hipStream_t st);
+// split[(nslab+1)][M]: per-row forward-scan split points of the column slabs (spmm_kernels.hip)
+hipError_t launch_slabplan(const int32_t* rowptr, const int32_t* colind, int32_t* split, int M, int nslab,
+                           int slab_rows, hipStream_t st);
 
 // csr2csc.hip
 int64_t csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);

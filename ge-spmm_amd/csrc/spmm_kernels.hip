@@ -1502,6 +1502,13 @@ static hipError_t slab_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) 
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_slabplan(const int32_t* rowptr, const int32_t* colind, int32_t* split, int M, int nslab,
+                           int slab_rows, hipStream_t st) {
+    hipLaunchKernelGGL(spmm_slabplan_kernel, dim3((M + kWaves - 1) / kWaves), dim3(kThreads), 0, st, rowptr, colind,
+                       split, M, nslab, slab_rows, 1.0f / (float)slab_rows);
+    return hipGetLastError();
+}
+
 size_t slabblocked_workspace_bytes(int64_t M, const Geometry& geo) {
     const int64_t nslab = ((int64_t)geo.K + geo.slab_rows - 1) / geo.slab_rows;
     return (size_t)(nslab + 1) * (size_t)M * 4;
