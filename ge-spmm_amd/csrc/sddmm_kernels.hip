@@ -6,12 +6,15 @@
 // (COO: row(e) = rowind[e]; CSR: row(e) found by binary search in rowptr). The
 // reference packs 4 edges per 8/16/32-lane slice of a 32-lane warp and needs
 // 16-byte-aligned index arrays plus single-edge tail blocks; none of that shape
-// is kept. Here a W-lane group of a 64-lane wavefront owns one edge, every lane
-// reads V contiguous floats of both rows per step (dwordx4 when N % 4 == 0), and
-// the W partial dot products meet in an xor butterfly (cross-lane ds_bpermute /
-// DPP moves). Edges of a wavefront are consecutive, so the out[] stores and the
-// index loads coalesce. Summation order is not sequential (neither is the
-// reference's shuffle tree): parity for SDDMM is tolerance-based.
+// is kept. Here a W-lane group of a 64-lane wavefront owns one edge at a time, with W
+// chosen so that a lane walks ~2 dwordx4 vectors (8 scalars for odd N) of both rows; two
+// to four edges per group are in flight, their slices requested before the first FMA, and
+// the W partial dot products meet in an xor butterfly (cross-lane ds_bpermute / DPP
+// moves). Edges of a wavefront are consecutive, so the out[] stores and the index loads
+// coalesce. Dense patterns in CSR form take a cache-blocked kernel (one launch per column
+// slab of D2, sddmm_slab_kernel). Summation order is not sequential (neither is the
+// reference's shuffle tree): parity for SDDMM is tolerance-based; COO, CSR and the
+// cache-blocked form agree with each other bit for bit.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
     constexpr int G = 64 / W;
     constexpr int EPW = 64;  // edges per wavefront (CSR form): G edges at a time, EPW/G rounds
     constexpr int UE = 4;    // edges per lane group per step (COO form)
+    constexpr int IT = (V == 4) ? 2 : 8;  // vectors per lane that cover a row under launch_sddmm's width rule
     using T = typename SdVec<V>::type;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -79,6 +83,41 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
                 } else {
 #pragma unroll
                     for (int i = 0; i < V; ++i) part[u] = __builtin_fmaf(x[u][i], y[u][i], part[u]);
+                }
+            }
+        } else if (N <= W * V * IT) {
+            // a lane walks up to IT vectors of each row: two edges at a time, all 4*IT slices requested
+            // before the first FMA (an edge past the end re-reads the last edge and is dropped)
+#pragma unroll
+            for (int u0 = 0; u0 < UE; u0 += 2) {
+                T x[2][IT], y[2][IT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = (ebase + u0 + u < nnz) ? ebase + u0 + u : nnz - 1;
+                    const float* p1 = D1 + (size_t)rows[e] * (size_t)N;
+                    const float* p2 = D2 + (size_t)colind[e] * (size_t)N;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int j = l * V + it * W * V;
+                        x[u][it] = *reinterpret_cast<const T*>(p1 + (j < N ? j : 0));
+                        y[u][it] = *reinterpret_cast<const T*>(p2 + (j < N ? j : 0));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        if (l * V + it * W * V < N) {  // the FMAs of the plain loop, in its order
+                            if constexpr (V == 1) {
+                                acc = __builtin_fmaf(x[u][it], y[u][it], acc);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < V; ++i) acc = __builtin_fmaf(x[u][it][i], y[u][it][i], acc);
+                            }
+                        }
+                    }
+                    part[u0 + u] = acc;
                 }
             }
         } else {
@@ -127,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int e = e0 + g; e < e1; e += G) {
+        auto row_of = [&](int e) {
             // largest i in [0, EPW+1] with s_rp[i] <= e   (s_rp[0] = rowptr[r0] <= e0 <= e)
             int lo = 0, hi = EPW + 1;
             if (s_rp[wave][hi] <= e) {  // more than EPW empty rows in the window: fall back
@@ -139,36 +178,75 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
                 if (s_rp[wave][mid] <= e) lo = mid;
                 else hi = mid;
             }
-            const int r = r0 + lo;
-            const int c = s_col[wave][e - e0];
-            const float* p1 = D1 + (size_t)r * (size_t)N;
-            const float* p2 = D2 + (size_t)c * (size_t)N;
-            float part = 0.0f;
-            for (int j = l * V; j < N; j += W * V) {
-                const T x = *reinterpret_cast<const T*>(p1 + j);
-                const T y = *reinterpret_cast<const T*>(p2 + j);
-                if constexpr (V == 1) {
-                    part = __builtin_fmaf(x, y, part);
-                } else {
+            return r0 + lo;
+        };
+        if (N <= W * V * IT) {
+            // two edges per lane group and step, every slice requested before the first FMA
+            for (int e = e0 + g; e < e1; e += 2 * G) {
+                T x[2][IT], y[2][IT];
 #pragma unroll
-                    for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+                for (int u = 0; u < 2; ++u) {
+                    const int ee = (e + u * G < e1) ? e + u * G : e;
+                    const float* p1 = D1 + (size_t)row_of(ee) * (size_t)N;
+                    const float* p2 = D2 + (size_t)s_col[wave][ee - e0] * (size_t)N;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int j = l * V + it * W * V;
+                        x[u][it] = *reinterpret_cast<const T*>(p1 + (j < N ? j : 0));
+                        y[u][it] = *reinterpret_cast<const T*>(p2 + (j < N ? j : 0));
+                    }
+                }
+                float part[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    part[u] = 0.0f;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        if (l * V + it * W * V < N) {
+                            if constexpr (V == 1) {
+                                part[u] = __builtin_fmaf(x[u][it], y[u][it], part[u]);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < V; ++i) part[u] = __builtin_fmaf(x[u][it][i], y[u][it][i], part[u]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = W >> 1; m > 0; m >>= 1) {
+                    part[0] += __shfl_xor(part[0], m, 64);
+                    part[1] += __shfl_xor(part[1], m, 64);
+                }
+                if (l == 0) {
+                    out[e] = part[0];
+                    if (e + G < e1) out[e + G] = part[1];
                 }
             }
+        } else {
+            for (int e = e0 + g; e < e1; e += G) {
+                const int r = row_of(e);
+                const int c = s_col[wave][e - e0];
+                const float* p1 = D1 + (size_t)r * (size_t)N;
+                const float* p2 = D2 + (size_t)c * (size_t)N;
+                float part = 0.0f;
+                for (int j = l * V; j < N; j += W * V) {
+                    const T x = *reinterpret_cast<const T*>(p1 + j);
+                    const T y = *reinterpret_cast<const T*>(p2 + j);
+                    if constexpr (V == 1) {
+                        part = __builtin_fmaf(x, y, part);
+                    } else {
 #pragma unroll
-            for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
-            if (l == 0) out[e] = part;
+                        for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
+                    }
+                }
+#pragma unroll
+                for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+                if (l == 0) out[e] = part;
+            }
         }
     }
 }
 
-// Cache-blocked CSR form for dense patterns (reddit-like: every D2 row is used ~500 times but D2 is
-// 30x an L2). Same idea as the SpMM slab path (spmm_kernels.hip) and the same per-row split points
-// (spmm_slabplan_kernel): one launch per column slab, every launch computes the edges of every row
-// that fall into that slab, so the slab's D2 rows stay in L2. Unlike SpMM there is nothing to
-// accumulate across slabs — each out[e] is written once. The row's D1 slice stays in registers and 4
-// edges per lane group are in flight. reddit-like N=128: 7.7 -> 4.2 ms (profiles/r01/sddmm_slab.log). The
-// per-edge arithmetic (lanes per edge, order of the partial sums) is that of sddmm_kernel, so the
-// results are bit-identical to the streaming forms.
 template <int V, int W>
 __global__ __launch_bounds__(kThreads) void sddmm_slab_kernel(const int32_t* __restrict__ row_begin,
                                                                const int32_t* __restrict__ row_end,
