@@ -147,3 +147,30 @@ def test_torch_extension_module(pkg):
         _ext.ext.coo_sddmm(ci, ci, B, B)
     ldd = subprocess.run(["ldd", _ext.EXT_PATH], capture_output=True, text=True).stdout
     assert "libgespmm.so" in ldd and "oracle" not in ldd
+
+
+def test_workspace_query_is_host_only(pkg):
+    """gespmm_csr_spmm_workspace_bytes: pure host arithmetic on the shape — zero for problems that take
+    a streaming kernel, split points for dense graphs, partial rows when the long-row pass is on."""
+    import ctypes as C
+
+    from gespmm_amd import _lib
+
+    q = _lib.lib.gespmm_csr_spmm_workspace_bytes
+    assert q(334863, 334863, 128, 1851744, -1, None) == 0          # com-Amazon-shaped: streaming kernel
+    assert q(19717, 19717, 128, -1, -1, None) == 0                 # nnz unknown: nothing that needs scratch
+    # reddit-shaped: dense -> (nslab + 1) * M int32 split points, 6 MB slabs of 512-byte rows
+    M, nnz = 232965, 114615892
+    nslab = -(-M // ((6 << 20) // 512))
+    assert q(M, M, 128, nnz, -1, None) == (nslab + 1) * M * 4
+    assert q(M, M, 128, nnz, 5, None) == 0                         # parallel-reduction variant: none
+    # RMAT-shaped (mean degree 16, >= 2^23 entries): long-row pass, bounded by nnz/2048 chunks + nnz/2048 rows
+    M, nnz, N = 1 << 22, 1 << 26, 128
+    b = q(M, M, N, nnz, -1, None)
+    chunks = nnz // 2048 + nnz // 2048 + 1
+    assert chunks * N * 4 <= b <= chunks * (N * 4 + 8) + (nnz // 2048 + 1) * 16 + 1024
+    # STRICT_ORDER switches the pass off
+    c = _lib.LaunchCfg()
+    c.flags = _lib.FLAG_STRICT_ORDER
+    assert q(M, M, N, nnz, -1, C.byref(c)) == 0
+    assert q(-1, 4, 4, 4, -1, None) < 0 and q(4, 4, 4, 4, 99, None) < 0
