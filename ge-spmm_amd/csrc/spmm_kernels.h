@@ -29,6 +29,7 @@ constexpr int kLongRowChunk = 2048;      // entries of a long row one workgroup 
 constexpr int64_t kLongRowMinNnz = 1 << 23;  // auto: only matrices this large get the long-row pass
 constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force the cache-blocked path)
 constexpr int kFlagNoSlabBlocked = 0x800; // == GESPMM_FLAG_NO_SLAB_BLOCKED
+constexpr int kFlagReuseSplit = 0x2000;   // == GESPMM_FLAG_REUSE_SPLIT
 constexpr int kFlagAllowReassoc = 0x1000; // == GESPMM_FLAG_ALLOW_REASSOCIATION
 constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
 

@@ -917,10 +917,20 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
     const int row0 = ((rb * kWaves + wave) * G + g) * R;
     if (((rb * kWaves + wave) * G) * R >= a.M) return;
     // split points of the group's R rows for this slab: two coalesced loads -> LDS
+    // (clamped to the row's own CSR range: split points come from the caller's workspace when it asks
+    // to reuse them, and a stale workspace must not turn into out-of-range reads or unbounded loops)
     for (int i = l; i < R; i += W) {
         const bool ok = row0 + i < a.M;
-        s_b[wave][g][i] = ok ? load_csr(a.row_begin + row0 + i) : 0;
-        s_e[wave][g][i] = ok ? load_csr(a.row_end + row0 + i) : 0;
+        int sb = 0, se = 0;
+        if (ok) {
+            const int lb = a.rowptr[row0 + i], hb = a.rowptr[row0 + i + 1];
+            sb = load_csr(a.row_begin + row0 + i);
+            se = load_csr(a.row_end + row0 + i);
+            sb = sb < lb ? lb : (sb > hb ? hb : sb);
+            se = se < sb ? sb : (se > hb ? hb : se);
+        }
+        s_b[wave][g][i] = sb;
+        s_e[wave][g][i] = se;
     }
     wave_lds_sync();
     const bool first = a.accumulate == 0;
@@ -1527,9 +1537,9 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, void
     if (own) e = workspace_alloc(reinterpret_cast<void**>(&split), bytes, st);
     else split = static_cast<int32_t*>(ext_ws);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(spmm_slabplan_kernel, dim3((M + kWaves - 1) / kWaves), dim3(kThreads), 0, st, a0.rowptr,
-                       a0.colind, split, M, nslab, geo.slab_rows, 1.0f / (float)geo.slab_rows);
-    e = hipGetLastError();
+    // a caller that keeps its workspace across calls on an unchanged graph may skip the scan
+    if (!(!own && (a0.flags & kFlagReuseSplit)))
+        e = launch_slabplan(a0.rowptr, a0.colind, split, M, nslab, geo.slab_rows, st);
     const bool valued = a0.val != nullptr;
     for (int sl = 0; sl < nslab && e == hipSuccess; ++sl) {
         SpmmArgs a = a0;

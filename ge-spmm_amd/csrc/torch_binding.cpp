@@ -41,7 +41,8 @@ void* current_stream(const torch::Tensor& t) {
 }
 
 torch::Tensor spmm_impl(const torch::Tensor& rowptr, const torch::Tensor& colind,
-                        const c10::optional<torch::Tensor>& values, const torch::Tensor& dense, int64_t variant) {
+                        const c10::optional<torch::Tensor>& values, const torch::Tensor& dense, int64_t variant,
+                        const c10::optional<torch::Tensor>& workspace = c10::nullopt, int64_t flags = 0) {
     need(rowptr, "rowptr", torch::kInt32, 1);
     need(colind, "colind", torch::kInt32, 1);
     need(dense, "dense", torch::kFloat32, 2);
@@ -60,29 +61,41 @@ torch::Tensor spmm_impl(const torch::Tensor& rowptr, const torch::Tensor& colind
     auto out = torch::empty({M, N}, dense.options());
     // Scratch for the two paths that need it (dense-graph cache blocking, long-row pass) comes from
     // torch's caching allocator: no driver allocation per call, and legal under torch.cuda.graph.
-    const int64_t ws_bytes = gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, (int)variant, nullptr);
+    // A caller-kept workspace (ge-spmm_amd/spmm.py: SpmmPlan) is used as is.
+    gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, (int32_t)flags};
+    const int64_t ws_bytes = gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, (int)variant, &cfg);
     TORCH_CHECK(ws_bytes >= 0, "gespmm_csr_spmm_workspace_bytes failed: ", gespmm_error_string((int)ws_bytes));
     torch::Tensor ws;
     void* ws_ptr = nullptr;
-    if (ws_bytes > 0) {
+    if (workspace.has_value() && workspace->defined() && workspace->numel() > 0) {
+        TORCH_CHECK(workspace->is_cuda() && workspace->device() == dense.device() && workspace->is_contiguous() &&
+                        workspace->scalar_type() == torch::kUInt8,
+                    "workspace must be a contiguous uint8 tensor on the device of `dense`");
+        TORCH_CHECK_VALUE(workspace->numel() >= ws_bytes, "workspace holds ", workspace->numel(), " bytes, need ", ws_bytes);
+        ws = *workspace;
+        ws_ptr = ws.data_ptr();
+    } else if (ws_bytes > 0) {
         ws = torch::empty({ws_bytes}, dense.options().dtype(torch::kUInt8));
         ws_ptr = ws.data_ptr();
+        cfg.flags &= ~GESPMM_FLAG_REUSE_SPLIT;  // a fresh block holds nothing to reuse
     }
     check_rc(gespmm_csr_spmm_f32_ws(rowptr.data_ptr<int32_t>(), colind.data_ptr<int32_t>(), val,
-                                    dense.data_ptr<float>(), out.data_ptr<float>(), M, K, N, nnz, (int)variant, nullptr,
-                                    ws_ptr, ws_bytes, current_stream(dense)),
+                                    dense.data_ptr<float>(), out.data_ptr<float>(), M, K, N, nnz, (int)variant, &cfg,
+                                    ws_ptr, ws_ptr ? ws.numel() : 0, current_stream(dense)),
              "gespmm_csr_spmm_f32");
     return out;
 }
 
 torch::Tensor csr_spmm(const torch::Tensor& rowptr, const torch::Tensor& colind, const torch::Tensor& values,
-                       const torch::Tensor& dense, int64_t variant) {
-    return spmm_impl(rowptr, colind, values, dense, variant);
+                       const torch::Tensor& dense, int64_t variant, const c10::optional<torch::Tensor>& workspace,
+                       int64_t flags) {
+    return spmm_impl(rowptr, colind, values, dense, variant, workspace, flags);
 }
 
 torch::Tensor csr_spmm_no_edge_value(const torch::Tensor& rowptr, const torch::Tensor& colind,
-                                     const torch::Tensor& dense, int64_t variant) {
-    return spmm_impl(rowptr, colind, c10::nullopt, dense, variant);
+                                     const torch::Tensor& dense, int64_t variant,
+                                     const c10::optional<torch::Tensor>& workspace, int64_t flags) {
+    return spmm_impl(rowptr, colind, c10::nullopt, dense, variant, workspace, flags);
 }
 
 torch::Tensor csr_spmm_max(const torch::Tensor& rowptr, const torch::Tensor& colind, const torch::Tensor& dense,
@@ -172,9 +185,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               "without), csr2csc format transformation, SDDMM in COO and CSR format";
     namespace py = pybind11;
     m.def("csr_spmm", &csr_spmm, "CSR SPMM", py::arg("rowptr"), py::arg("colind"), py::arg("values"),
-          py::arg("dense"), py::arg("variant") = -1);
+          py::arg("dense"), py::arg("variant") = -1, py::arg("workspace") = py::none(), py::arg("flags") = 0);
     m.def("csr_spmm_no_edge_value", &csr_spmm_no_edge_value, "CSR SPMM NO EDGE VALUE", py::arg("rowptr"),
-          py::arg("colind"), py::arg("dense"), py::arg("variant") = -1);
+          py::arg("colind"), py::arg("dense"), py::arg("variant") = -1, py::arg("workspace") = py::none(),
+          py::arg("flags") = 0);
     m.def("csr_spmm_max", &csr_spmm_max, "CSR SPMM, max reducer", py::arg("rowptr"), py::arg("colind"),
           py::arg("dense"), py::arg("empty_value") = -10000.0, py::arg("variant") = -1);
     m.def("csr2csc", &csr2csc, "csr2csc");

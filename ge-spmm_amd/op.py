@@ -40,11 +40,12 @@ _warned_no_grad = False
 class SPMMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, colptr, rowind, feat, edge_weight_csr=None, edge_weight_csc=None,
-                need_edge_grad=False):
+                need_edge_grad=False, plans=None):
+        fwd_plan, ctx.bwd_plan = plans if plans is not None else (None, None)
         if edge_weight_csr is None:
-            out = _spmm.csr_spmm_no_edge_value(rowptr, colind, feat)
+            out = _spmm.csr_spmm_no_edge_value(rowptr, colind, feat, plan=fwd_plan)
         else:
-            out = _spmm.csr_spmm(rowptr, colind, edge_weight_csr, feat)
+            out = _spmm.csr_spmm(rowptr, colind, edge_weight_csr, feat, plan=fwd_plan)
         ctx.backward_csc = (colptr, rowind, feat, edge_weight_csr, edge_weight_csc)
         ctx.forward_csr = (rowptr, colind)
         ctx.need_edge_grad = bool(need_edge_grad)
@@ -62,7 +63,7 @@ class SPMMFunction(torch.autograd.Function):
                     "Backward of SPMM require edge values in both src-first and dst-first order, "
                     "and do not support gradients for edge values. Call with SPMMFunction.apply("
                     "rowptr, colind, colptr, rowind, in_feat, edge_value_row_first, edge_value_col_first")
-            grad_feat = _spmm.csr_spmm(colptr, rowind, edge_weight_csc, grad_out)
+            grad_feat = _spmm.csr_spmm(colptr, rowind, edge_weight_csc, grad_out, plan=ctx.bwd_plan)
             if ctx.need_edge_grad:
                 rowptr, colind = ctx.forward_csr
                 grad_edge_weight = _sddmm.csr_sddmm(rowptr, colind, grad_out, feat.detach().contiguous())
@@ -70,8 +71,8 @@ class SPMMFunction(torch.autograd.Function):
                 print("[I] Treat edge weight as no_grad.")
                 _warned_no_grad = True
         else:
-            grad_feat = _spmm.csr_spmm_no_edge_value(colptr, rowind, grad_out)
-        return None, None, None, None, grad_feat, grad_edge_weight, None, None
+            grad_feat = _spmm.csr_spmm_no_edge_value(colptr, rowind, grad_out, plan=ctx.bwd_plan)
+        return None, None, None, None, grad_feat, grad_edge_weight, None, None, None
 
 
 def glorot(tensor):
@@ -111,6 +112,7 @@ class GCNConv(torch.nn.Module):
         zeros(self.bias)
         self.cached_result = None
         self.cached_num_edges = None
+        self.cached_plans = None
 
     @staticmethod
     def _inv_sqrt_degree(indptr):
@@ -137,7 +139,15 @@ class GCNConv(torch.nn.Module):
         in_scale, out_scale = self._scalings(h, rowptr, colptr)
         if self.normalize:
             h = h * out_scale
-        h = SPMMFunction.apply(rowptr, colind, colptr, rowind, h, edge_weight_csr, edge_weight_csc)
+        plans = None
+        if self.cached:  # `cached` is the caller's promise of a static graph: keep the SpMM scratch as well
+            key = (rowptr.data_ptr(), colind.data_ptr(), colptr.data_ptr(), rowind.data_ptr(), h.shape[1])
+            if self.cached_plans is None or self.cached_plans[0] != key:
+                n = rowptr.numel() - 1
+                self.cached_plans = (key, (_spmm.SpmmPlan(rowptr, colind, colptr.numel() - 1, h.shape[1]),
+                                           _spmm.SpmmPlan(colptr, rowind, n, h.shape[1])))
+            plans = self.cached_plans[1]
+        h = SPMMFunction.apply(rowptr, colind, colptr, rowind, h, edge_weight_csr, edge_weight_csc, False, plans)
         if self.normalize:
             h = h * in_scale
         return h if self.bias is None else h + self.bias

@@ -142,6 +142,9 @@ typedef struct gespmm_launch_cfg {
 #define GESPMM_FLAG_SPLIT_LONG_ROWS 0x200 /* run the long-row pass regardless of matrix size */
 #define GESPMM_FLAG_SLAB_BLOCKED   0x400 /* force the cache-blocked path (one launch per column slab of B) */
 #define GESPMM_FLAG_NO_SLAB_BLOCKED 0x800 /* never use it */
+#define GESPMM_FLAG_REUSE_SPLIT     0x2000 /* gespmm_csr_spmm_f32_ws only: `workspace` already holds the split points an earlier call
+                                             wrote for the SAME rowptr/colind/N/cfg (cache-blocked path): skip the scan. The caller
+                                             vouches that the graph did not change; ignored on every other path */
 #define GESPMM_FLAG_ALLOW_REASSOCIATION 0x1000 /* AUTO may pick the parallel-reduction variant (N <= 16, dense rows) */
 #define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (default for group >= 32) */
 

@@ -17,10 +17,11 @@ val = torch.rand(nnz, device=dev)
 B = torch.rand(K, N, device=dev); C = torch.empty(M, N, device=dev)
 import json
 cfg = json.loads(os.environ["GESPMM_CFG"]) if "GESPMM_CFG" in os.environ else None
+plan = spmm.SpmmPlan(g["rowptr"], g["colind"], K, N) if os.environ.get("PLAN") == "1" else None
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C, cfg=cfg)
+spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C, cfg=cfg, plan=plan)
 torch.cuda.synchronize(); e0.record()
 for _ in range(iters):
-    spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C, cfg=cfg)
+    spmm.csr_spmm(g["rowptr"], g["colind"], val, B, out=C, cfg=cfg, plan=plan)
 e1.record(); torch.cuda.synchronize()
 print("%s N=%d: %.1f us per call" % (name, N, e0.elapsed_time(e1) / iters * 1e3))

