@@ -15,14 +15,17 @@ Semantics kept from the reference:
   * edge weights are treated as constants (op.py:30-31 prints
     "[I] Treat edge weight as no_grad." — printed once per process here, not once
     per backward call).
-One optional extension (off by default, so default behaviour is the reference's):
+Two optional extensions (off by default, so default behaviour is the reference's):
 ``need_edge_grad=True`` as an 8th argument returns d loss / d edge_weight_csr via
 SDDMM, grad_w[e] = <grad_out[row(e), :], feat[col(e), :]> — the "SpMM fwd + SDDMM
-bwd" pairing BASELINE.json's config 4 names.
+bwd" pairing BASELINE.json's config 4 names; ``plans=(forward, backward)`` as a 9th
+argument passes ``spmm.SpmmPlan`` objects (scratch kept across calls on a static graph).
 
 GCNConv computes  D_in^-1/2 · A · (D_out^-1/2 ⊙ (X W)) + b  with degrees taken from
 the rowptr / colptr differences (op.py:103-109, 128-147). ``glorot`` / ``zeros`` are
 re-implemented (the reference imports them from torch_geometric, op.py:75).
+With ``cached=True`` — which already promises a static graph for the cached normalisation — GCNConv
+also keeps one SpmmPlan per direction (dense graphs: the split scan runs once, not per call).
 The reference's ``normalize=False`` branch raises TypeError (``rowptr.shape(0)``,
 op.py:133-134); here it does what the branch evidently intends: no scaling.
 """
