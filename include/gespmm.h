@@ -13,6 +13,8 @@
  *                               spmm_cuda_no_edge_value()     pytorch-custom/spmm_kernel.cu:175-207
  *                               XTopoCsrmm<float>()           dgl-custom/binary_reduce_sum.cu:310-335
  *   gespmm_csr_spmm_max_f32  <- XTopoCsrmmmax<float>()        dgl-custom/binary_reduce_max.cu:182-207
+ *   gespmm_dgl_csrmm_{sum,max}_f32  <- the same two, with exactly their argument lists
+ *   gespmm_csr_spmm_workspace_bytes / gespmm_csr_spmm_f32_ws  <- (new) caller-owned scratch, no reference counterpart
  *   gespmm_select_variant    <- the N-based 3-way dispatch    pytorch-custom/spmm_kernel.cu:186-206,437-457
  *   gespmm_sddmm_coo_f32     <- sddmm_cuda_coo()              pytorch-custom/sddmm.cu:427-457
  *   gespmm_sddmm_csr_f32     <- sddmm_cuda_csr()              pytorch-custom/sddmm.cu:459-484
@@ -30,7 +32,9 @@
  *     NULL = the legacy default stream, which is what the reference launches on);
  *   - the return value is a hipError_t cast to int (0 = success) or one of the
  *     negative GESPMM_E* codes below; the library never calls exit();
- *   - re-entrant; the only global state is cached, immutable device properties.
+ *   - re-entrant; the only global state is cached, immutable device properties and one memory
+ *     pool per device for stream-ordered temporaries (created on first use);
+ *   - the device that owns `stream` and the pointers is the calling thread's current device.
  *
  * There is NO CPU fallback: without a HIP device every compute entry point
  * returns the HIP error (hipErrorNoDevice = 100).
