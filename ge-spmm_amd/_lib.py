@@ -40,6 +40,7 @@ EXPORTS = [
     "gespmm_csr_spmm_f32",
     "gespmm_csr_spmm_max_f32",
     "gespmm_select_variant",
+    "gespmm_describe_launch",
     "gespmm_dgl_csrmm_sum_f32",
     "gespmm_dgl_csrmm_max_f32",
     "gespmm_csr_spmm_f32_cfg",
@@ -99,6 +100,8 @@ def _load():
     for fn in (lib.gespmm_dgl_csrmm_sum_f32, lib.gespmm_dgl_csrmm_max_f32):
         fn.restype = c_int
         fn.argtypes = [c_int, c_int, p, p, p, p, p]
+    lib.gespmm_describe_launch.restype = c_int
+    lib.gespmm_describe_launch.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(LaunchCfg), c_char_p, c_int64]
     lib.gespmm_select_variant.restype = c_int
     lib.gespmm_select_variant.argtypes = [c_int64, c_int64, c_int64]
     lib.gespmm_sddmm_coo_f32.restype = c_int

@@ -198,6 +198,46 @@ int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const f
 
 int gespmm_select_variant(int64_t M, int64_t nnz, int64_t N) { return gespmm::auto_variant(M, nnz, N); }
 
+int gespmm_describe_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg,
+                           char* out, int64_t capacity) {
+    if (!out || capacity <= 0 || M < 0 || K < 0 || N < 0 || nnz < -1) return GESPMM_EINVAL;
+    if (variant < GESPMM_VARIANT_AUTO || variant >= GESPMM_NUM_VARIANTS) return GESPMM_EINVAL;
+    int max_vec = 4;
+    while (max_vec > 1 && (N % max_vec) != 0) max_vec >>= 1;
+    gespmm::Selection sel;
+    const int flags = cfg ? cfg->flags : 0;
+    const int rc = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0, cfg ? cfg->strips : 0,
+                                            cfg ? cfg->group : 0, cfg ? cfg->rows_per_wave : 0, cfg ? cfg->slab_rows : 0,
+                                            flags, &sel);
+    if (rc != 0) return rc;
+    const gespmm::Geometry& g = sel.geo;
+    const char* idx = g.idx64 ? "idx64" : "idx32";
+    int n;
+    if (sel.variant == GESPMM_VARIANT_PARREDUCE)
+        n = snprintf(out, (size_t)capacity, "variant=5 kernel=parallel-reduction W=%d %s", g.group, idx);
+    else if (sel.variant == GESPMM_VARIANT_NAIVE)
+        n = snprintf(out, (size_t)capacity, "variant=0 kernel=naive V=%d S=%d W=%d %s", g.vec, g.strips, g.group, idx);
+    else if (g.slab_blocked)
+        n = snprintf(out, (size_t)capacity, "variant=%d kernel=slab-blocked V=%d S=%d W=%d slab_rows=%d slabs=%lld %s",
+                     sel.variant, g.vec, g.strips, g.group, g.slab_rows,
+                     (long long)((K + g.slab_rows - 1) / g.slab_rows), idx);
+    else {
+        bool seg = g.segmented;
+        if (flags & gespmm::kFlagBatchStream) seg = false;
+        if ((flags & gespmm::kFlagSegStream) && !g.split_long_rows) seg = true;
+        char tail[64] = "";
+        if (!seg && g.split_long_rows) snprintf(tail, sizeof tail, " long_rows>%d chunk=%d", g.long_row_threshold, gespmm::kLongRowChunk);
+        if (seg)
+            n = snprintf(out, (size_t)capacity, "variant=%d kernel=segmented-stream V=%d S=%d W=%d rows_per_group=%d %s",
+                         sel.variant, g.vec, g.strips, g.group, g.rows_per_group, idx);
+        else
+            n = snprintf(out, (size_t)capacity, "variant=%d kernel=batch-stream V=%d S=%d W=%d rows_per_wave=%d %s%s",
+                         sel.variant, g.vec, g.strips, g.group, g.rows_per_wave, idx, tail);
+    }
+    if (n < 0) return GESPMM_EINVAL;
+    return n < capacity ? n : (int)capacity - 1;
+}
+
 int gespmm_dgl_csrmm_sum_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,
                              void* stream) {
     return run_spmm(indptr, indices, nullptr, B, C, m, /*K unknown*/ 0x7fffffffLL, n, /*nnz unknown*/ -1,

@@ -175,6 +175,16 @@ int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const f
                            const gespmm_launch_cfg* cfg /* may be NULL */, void* workspace, int64_t workspace_bytes,
                            void* stream);
 
+/*
+ * What a call with these arguments would launch, as one line of text (host-only; no device work): kernel
+ * family, vector width V, strips S, lanes per row W, task size, and for the two special paths the slab /
+ * long-row parameters — e.g. "variant=3 kernel=batch-stream V=4 S=1 W=32 rows_per_wave=4 idx32" or
+ * "variant=3 kernel=slab-blocked V=4 S=1 W=32 slab_rows=12288 slabs=19 idx32". B and C are assumed
+ * 16-byte aligned. Returns the length written (excluding the NUL), or a negative code.
+ */
+int gespmm_describe_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant,
+                           const gespmm_launch_cfg* cfg /* may be NULL */, char* out, int64_t capacity);
+
 
 /*
  * The DGL kernel patch's entry points (dgl-custom/binary_reduce_sum.cu:310-335 XTopoCsrmm<float>,

@@ -174,3 +174,43 @@ def test_workspace_query_is_host_only(pkg):
     c.flags = _lib.FLAG_STRICT_ORDER
     assert q(M, M, N, nnz, -1, C.byref(c)) == 0
     assert q(-1, 4, 4, 4, -1, None) < 0 and q(4, 4, 4, 4, 99, None) < 0
+
+
+def test_describe_launch_pins_the_selection_rules(pkg):
+    """gespmm_describe_launch is host-only: the kernel family and geometry AUTO picks for the
+    BASELINE.json shapes are pinned here, so a change of the selection rules is a deliberate one
+    (measurements behind them: profiles/r01/rows_per_wave_sweep.log, slab_size_sweep_v2.log, ...)."""
+    import ctypes as C
+
+    from gespmm_amd import _lib
+
+    def describe(M, K, N, nnz, variant=-1, flags=0):
+        buf = C.create_string_buffer(256)
+        cfg = _lib.LaunchCfg(0, 0, 0, 0, 0, flags)
+        n = _lib.lib.gespmm_describe_launch(M, K, N, nnz, variant, C.byref(cfg), buf, 256)
+        assert n > 0
+        return buf.value.decode()
+
+    amazon = (334863, 334863, None, 1851744)
+    assert describe(amazon[0], amazon[1], 128, amazon[3]) == \
+        "variant=3 kernel=batch-stream V=4 S=1 W=32 rows_per_wave=4 idx32"
+    assert describe(amazon[0], amazon[1], 32, amazon[3]) == \
+        "variant=1 kernel=batch-stream V=1 S=1 W=32 rows_per_wave=8 idx32"
+    reddit = (232965, 232965, None, 114615892)
+    for N in (128, 256, 512):  # 512-byte column tiles bound to XCDs, 6 MB slabs
+        assert describe(reddit[0], reddit[1], N, reddit[3]) == \
+            "variant=3 kernel=slab-blocked V=4 S=1 W=32 slab_rows=12288 slabs=19 idx32"
+    assert "kernel=batch-stream" in describe(reddit[0], reddit[1], 128, reddit[3], flags=_lib.FLAG_NO_SLAB_BLOCKED)
+    assert describe(1 << 22, 1 << 22, 128, 1 << 26).endswith("rows_per_wave=2 idx32 long_rows>2048 chunk=2048")
+    assert "long_rows" not in describe(1 << 22, 1 << 22, 128, 1 << 26, flags=_lib.FLAG_STRICT_ORDER)
+    assert describe(1 << 26, 1 << 26, 256, 1 << 30).startswith("variant=3 kernel=batch-stream V=4 S=1 W=64")
+    assert "idx64" in describe(1 << 26, 1 << 26, 256, 1 << 30)
+    assert "kernel=segmented-stream" in describe(2048, 2048, 128, 10000)      # short rows, B resident in L2
+    assert describe(reddit[0], reddit[1], 4, reddit[3], variant=5) == "variant=5 kernel=parallel-reduction W=64 idx32"
+    assert "kernel=parallel-reduction" in describe(reddit[0], reddit[1], 8, reddit[3], flags=_lib.FLAG_ALLOW_REASSOCIATION)
+    assert "kernel=parallel-reduction" not in describe(reddit[0], reddit[1], 8, reddit[3])
+    assert describe(100, 100, 41, 1000).startswith("variant=1 ")               # odd N: one column per lane
+    assert describe(100, 100, 130, 1000).startswith("variant=2 ") and " V=2 " in describe(100, 100, 130, 1000)
+    buf = C.create_string_buffer(8)
+    assert _lib.lib.gespmm_describe_launch(10, 10, 8, 20, -1, None, buf, 8) == 7  # truncated, NUL-terminated
+    assert _lib.lib.gespmm_describe_launch(10, 10, 8, 20, 99, None, buf, 8) < 0
