@@ -32,6 +32,7 @@
 //   --cpu-baseline  time that CPU loop (1 thread) and print its GFLOP/s
 //   --out path      CSV side file                     (default spmm_test_out.out)
 //   --no-vendor     skip the rocSPARSE comparison column
+//   --describe      print what the library launches for each N (gespmm_describe_launch)
 //   --cache dir     keep the parsed matrix as a binary file in `dir` and reuse it next time
 //
 // There is no CPU fallback: without a HIP device the driver fails with EXIT_FAILURE.
@@ -201,7 +202,7 @@ int main(int argc, char** argv) {
     int dev_id = 0;
     int method = GESPMM_VARIANT_CRC_CWM2;
     int iters = 200;
-    bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true;
+    bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true, describe = false;
     unsigned seed = 0;
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
@@ -226,13 +227,14 @@ int main(int argc, char** argv) {
         else if (a == "--cpu-baseline") cpu_baseline = true;
         else if (a == "--use-values") use_values = true;
         else if (a == "--no-vendor") vendor = false;
+        else if (a == "--describe") describe = true;
         else if (a == "--cache") cache_dir = next("--cache");
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
     if (!mtx_path) {
         fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
-                        "[--use-values] [--validate] [--cpu-baseline] [--no-vendor] [--out path]\n", argv[0]);
+                        "[--use-values] [--validate] [--cpu-baseline] [--no-vendor] [--describe] [--out path]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (iters < 1) iters = 1;
@@ -378,6 +380,10 @@ int main(int argc, char** argv) {
         for (int n = 128; n <= max_ncols; n *= 2) ncols_list.push_back(n);
     for (int N : ncols_list) {
         if (N > max_ncols || N < 1) continue;
+        if (describe) {
+            char what[256];
+            if (gespmm_describe_launch(M, K, N, nnz, method, nullptr, what, sizeof what) > 0) printf("N=%d launches: %s\n", N, what);
+        }
         const double gflop = (double)nnz * 2 / 1000000 * N;
         float rt = 0.0f;
         // vendor column (reference: cusparseScsrmm2, spmm_test.cu:730-738)
