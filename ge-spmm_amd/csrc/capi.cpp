@@ -104,7 +104,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     if (sel.variant == GESPMM_VARIANT_PARREDUCE) e = gespmm::launch_spmm_parreduce(a, sel.geo, st);
     else if (sel.variant == GESPMM_VARIANT_NAIVE)
         e = gespmm::launch_spmm_naive(a, sel.geo, st);
-    else if (sel.geo.slab_blocked && reduce == gespmm::kReduceSum) {
+    else if (sel.geo.slab_blocked) {
         // rows per lane group and launch: 2 measured best on reddit-like at N = 64..256 (hub rows make
         // 8-row tasks a long tail: 45 % average occupancy in the PMC run), profiles/r01/slab_task_size.log
         a.rpw = (cfg && cfg->rows_per_wave > 0) ? cfg->rows_per_wave : 2;

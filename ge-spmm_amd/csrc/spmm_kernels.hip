@@ -890,7 +890,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slabplan_kernel(const int32_t* 
     for (int sl = run + 1 + lane; sl <= nslab; sl += 64) split[(size_t)sl * M + r] = hb;
 }
 
-template <int V, int S, int W, bool VALUED, bool IDX64>
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
 __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
     constexpr int G = 64 / W;
     constexpr int T = (W > 32) ? W : 32;
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int k = 0; k < V; ++k) qacc[s][k] = 0.0f;
+            for (int k = 0; k < V; ++k) qacc[s][k] = (RED == kReduceMax) ? a.empty : 0.0f;
         if (!first && b < e) {
             const float* Crow = a.C + (size_t)(row0 + i) * (size_t)a.N + col0;
 #pragma unroll
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
                     for (int s = 0; s < S; ++s)
 #pragma unroll
                         for (int k2 = 0; k2 < V; ++k2)
-                            acc[s][k2] = combine<kReduceSum, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
+                            acc[s][k2] = combine<RED, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
             } else {  // last step of the segment: only the cnt live gathers are issued
 #pragma unroll
                 for (int j = 0; j < U - 1; ++j) {
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
                         for (int s = 0; s < S; ++s)
 #pragma unroll
                             for (int k2 = 0; k2 < V; ++k2)
-                                acc[s][k2] = combine<kReduceSum, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
+                                acc[s][k2] = combine<RED, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
                     }
                 }
             }
@@ -1468,7 +1468,7 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
 }
 
 
-template <int V, int S, int W, bool VALUED, bool IDX64>
+template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
 static hipError_t launch_slab(const SpmmArgs& a, hipStream_t st) {
     constexpr int G = 64 / W;
     SpmmArgs args = a;
@@ -1481,33 +1481,33 @@ static hipError_t launch_slab(const SpmmArgs& a, hipStream_t st) {
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
     if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((spmm_slab_kernel<V, S, W, VALUED, IDX64>), dim3((unsigned)nitems), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL((spmm_slab_kernel<V, S, W, VALUED, IDX64, RED>), dim3((unsigned)nitems), dim3(kThreads), 0, st,
                        args);
     return hipGetLastError();
 }
 
-template <int V, int S, bool VALUED, bool IDX64>
+template <int V, int S, bool VALUED, bool IDX64, int RED>
 static hipError_t slab_w(const SpmmArgs& a, int W, hipStream_t st) {
     switch (W) {
-        case 4: return launch_slab<V, S, 4, VALUED, IDX64>(a, st);
-        case 8: return launch_slab<V, S, 8, VALUED, IDX64>(a, st);
-        case 16: return launch_slab<V, S, 16, VALUED, IDX64>(a, st);
-        case 32: return launch_slab<V, S, 32, VALUED, IDX64>(a, st);
-        case 64: return launch_slab<V, S, 64, VALUED, IDX64>(a, st);
+        case 4: return launch_slab<V, S, 4, VALUED, IDX64, RED>(a, st);
+        case 8: return launch_slab<V, S, 8, VALUED, IDX64, RED>(a, st);
+        case 16: return launch_slab<V, S, 16, VALUED, IDX64, RED>(a, st);
+        case 32: return launch_slab<V, S, 32, VALUED, IDX64, RED>(a, st);
+        case 64: return launch_slab<V, S, 64, VALUED, IDX64, RED>(a, st);
     }
     return hipErrorInvalidValue;
 }
 
-template <bool VALUED, bool IDX64>
+template <bool VALUED, bool IDX64, int RED>
 static hipError_t slab_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
     if (g.strips == 2) {
-        if (g.vec == 4) return slab_w<4, 2, VALUED, IDX64>(a, g.group, st);
+        if (g.vec == 4) return slab_w<4, 2, VALUED, IDX64, RED>(a, g.group, st);
         return hipErrorInvalidValue;
     }
     switch (g.vec) {
-        case 1: return slab_w<1, 1, VALUED, IDX64>(a, g.group, st);
-        case 2: return slab_w<2, 1, VALUED, IDX64>(a, g.group, st);
-        case 4: return slab_w<4, 1, VALUED, IDX64>(a, g.group, st);
+        case 1: return slab_w<1, 1, VALUED, IDX64, RED>(a, g.group, st);
+        case 2: return slab_w<2, 1, VALUED, IDX64, RED>(a, g.group, st);
+        case 4: return slab_w<4, 1, VALUED, IDX64, RED>(a, g.group, st);
     }
     return hipErrorInvalidValue;
 }
@@ -1526,7 +1526,7 @@ size_t slabblocked_workspace_bytes(int64_t M, const Geometry& geo) {
 
 hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, void* ext_ws, size_t ext_bytes,
                                    hipStream_t st) {
-    if (geo.reduce != kReduceSum) return hipErrorInvalidValue;
+    if (geo.reduce == kReduceMax && a0.val != nullptr) return hipErrorInvalidValue;
     const int M = a0.M;
     const int nslab = (int)(((int64_t)geo.K + geo.slab_rows - 1) / geo.slab_rows);
     if (nslab < 1 || M <= 0) return hipErrorInvalidValue;
@@ -1546,8 +1546,12 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a0, const Geometry& geo, void
         a.row_begin = split + (size_t)sl * M;
         a.row_end = split + (size_t)(sl + 1) * M;
         a.accumulate = sl > 0 ? 1 : 0;
-        if (valued) e = geo.idx64 ? slab_vs<true, true>(a, geo, st) : slab_vs<true, false>(a, geo, st);
-        else e = geo.idx64 ? slab_vs<false, true>(a, geo, st) : slab_vs<false, false>(a, geo, st);
+        if (geo.reduce == kReduceMax)
+            e = geo.idx64 ? slab_vs<false, true, kReduceMax>(a, geo, st) : slab_vs<false, false, kReduceMax>(a, geo, st);
+        else if (valued)
+            e = geo.idx64 ? slab_vs<true, true, kReduceSum>(a, geo, st) : slab_vs<true, false, kReduceSum>(a, geo, st);
+        else
+            e = geo.idx64 ? slab_vs<false, true, kReduceSum>(a, geo, st) : slab_vs<false, false, kReduceSum>(a, geo, st);
     }
     const hipError_t ef = own ? workspace_free(split, st) : hipSuccess;
     return e != hipSuccess ? e : ef;
