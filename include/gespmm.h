@@ -191,8 +191,10 @@ int gespmm_describe_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, int var
  * binary_reduce_max.cu:182-207 XTopoCsrmmmax<float>) with their argument list — (m, n, indptr,
  * indices, B, C) plus the stream DGL keeps in its RuntimeConfig: C[m x n] = sum / max over the
  * row's neighbours of B[neighbour, :], A == 1 on the CSR pattern. DGL passes neither the number
- * of source nodes nor nnz at that point: 64-bit offsets into B are used and every row keeps the
- * strict CSR-order chain. Rows without neighbours give 0 (sum) or -10000 (max: the patch's
+ * of source nodes nor nnz at that point: 64-bit offsets into B are used; for graphs of 32768 rows
+ * or more nnz is read back from indptr[m] (a stream synchronisation, as the patch does after its
+ * kernel) so that dense graphs and hub rows get their dedicated paths, smaller graphs keep the
+ * strict CSR-order chain for every row. Rows without neighbours give 0 (sum) or -10000 (max: the patch's
  * max_init, binary_reduce_max.cu:22-24). Returns 0 or an error code as above (the patch returns
  * its cudaError the same way).
  */

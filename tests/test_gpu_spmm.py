@@ -277,6 +277,25 @@ def test_dgl_entry_points(pkg, oracle, bundled):
             assert rc == 0
             torch.cuda.synchronize()
             assert_bits_equal(out.cpu().numpy(), oracle.spmm_max(G["rowptr"], G["colind"], B), "dgl max")
+    # a large dense graph: the entry point reads nnz back and takes the cache-blocked path (K taken as m)
+    from gespmm_amd import spmm
+
+    rng = np.random.RandomState(4)
+    M, N = 60000, 128
+    deg = rng.randint(64, 100, size=M)
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    rp = torch.from_numpy(rowptr).cuda()
+    ci = torch.from_numpy(rng.randint(0, M + 5000, size=int(rowptr[-1])).astype(np.int32)).cuda()  # K > m
+    Bd = torch.rand(M + 5000, N, device="cuda") - 0.5
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert _lib.lib.gespmm_dgl_csrmm_sum_f32(M, N, rp.data_ptr(), ci.data_ptr(), Bd.data_ptr(), out.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, spmm.csr_spmm_no_edge_value(rp, ci, Bd, cfg={"flags": _lib.FLAG_NO_SLAB_BLOCKED}))
+    assert _lib.lib.gespmm_dgl_csrmm_max_f32(M, N, rp.data_ptr(), ci.data_ptr(), Bd.data_ptr(), out.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, spmm.csr_spmm_max(rp, ci, Bd))
 
 
 def test_stream_semantics(pkg, oracle, bundled):
