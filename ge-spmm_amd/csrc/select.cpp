@@ -84,7 +84,7 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // N = 32..512 (profiles/r01/rows_per_wave_sweep.log): the best task size is ~12 KB of B
     // gathered per wavefront task — 96 CSR entries at N = 32, 24 at N = 128 — never fewer
     // than 16 entries; larger tasks lose 5-17 % (coarser dynamic balance over the CUs).
-    // Keep >= ~4 wavefronts per wave slot of the chip (256 CUs x 32 slots) in the grid.
+    // (grid depth: see below)
     const int rows_in_flight = 64 / g.group;
     const bool b_resident = (uint64_t)K * (uint64_t)N * 4ull <= (8ull << 20);
     {
@@ -99,7 +99,8 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         if (b_resident) target = 128;
         int rpw = kMaxRowsPerWave;
         while (rpw > rows_in_flight && (int64_t)rpw * avg > target) rpw >>= 1;
-        while (rpw > rows_in_flight && M / rpw < 4 * 8192) rpw >>= 1;
+        // ... but never fewer wavefronts than the chip has slots (256 CUs x 32): one full round
+        while (rpw > rows_in_flight && M / rpw < 8192) rpw >>= 1;
         if (rpw < rows_in_flight) rpw = rows_in_flight;
         g.rows_per_wave = rpw;
     }
@@ -135,7 +136,10 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
             *nslab_out = nslab;
             // measured on reddit-like (profiles/r01/slab_blocking.log): 1.5-1.7x for N >= 64 with 4-6 MB
             // slabs, a loss at N = 32 (128-byte row slices)
-            return nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 4 * nslab &&
+            // ... and only when a row keeps >= ~20 of its entries per slab: with fewer, the per-slab read-modify-write
+            // of C outweighs the L2 hits (M = 200 k, degree 150, 17 slabs: 2.58 ms blocked vs 2.04 ms streaming,
+            // profiles/r01/heuristic_audit.log; reddit-like has 26 per slab)
+            return nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 20 * nslab &&
                    avg_deg >= 64;
         };
         int64_t slab_rows = 0, nslab = 0;
@@ -147,16 +151,22 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
         // (N = 256: 9.96 -> 8.79 ms, N = 512: 19.2 -> 17.4 on reddit-like,
         // profiles/r01/slab_size_sweep_v2.log).
         const bool forced = (flags & kFlagSlabBlocked) != 0;
-        if ((dense || forced) && (flags & kFlagNoSlabBlocked) == 0 && g.vec == 4 && cfg_strips == 0 && cfg_group == 0 &&
+        if ((flags & kFlagNoSlabBlocked) == 0 && g.vec == 4 && cfg_strips == 0 && cfg_group == 0 &&
             (int64_t)g.group * g.strips > 32) {
             const int64_t ntile1 = (N + 127) / 128;
             int64_t sr1 = 0, ns1 = 0;
-            if ((ntile1 == 2 || ntile1 == 4 || ntile1 == 8) && (plan(512, &sr1, &ns1) || forced)) {
-                g.group = 32;
-                g.strips = 1;
-                slab_rows = sr1;
-                nslab = ns1;
-                dense = true;
+            if (ntile1 == 2 || ntile1 == 4 || ntile1 == 8) {
+                if (plan(512, &sr1, &ns1) || forced) {
+                    g.group = 32;
+                    g.strips = 1;
+                    slab_rows = sr1;
+                    nslab = ns1;
+                    dense = true;
+                } else {
+                    // the narrow-tile form is the better of the two whenever it applies: if it is not worth it,
+                    // neither is blocking with 1-KB tiles (M = 20 k, degree 150, N = 256: 380 vs 330 us streaming)
+                    dense = false;
+                }
             }
         }
         g.slab_rows = (int)slab_rows;

@@ -195,12 +195,15 @@ def test_describe_launch_pins_the_selection_rules(pkg):
     assert describe(amazon[0], amazon[1], 128, amazon[3]) == \
         "variant=3 kernel=batch-stream V=4 S=1 W=32 rows_per_wave=4 idx32"
     assert describe(amazon[0], amazon[1], 32, amazon[3]) == \
-        "variant=1 kernel=batch-stream V=1 S=1 W=32 rows_per_wave=8 idx32"
+        "variant=1 kernel=batch-stream V=1 S=1 W=32 rows_per_wave=16 idx32"
     reddit = (232965, 232965, None, 114615892)
     for N in (128, 256, 512):  # 512-byte column tiles bound to XCDs, 6 MB slabs
         assert describe(reddit[0], reddit[1], N, reddit[3]) == \
             "variant=3 kernel=slab-blocked V=4 S=1 W=32 slab_rows=12288 slabs=19 idx32"
     assert "kernel=batch-stream" in describe(reddit[0], reddit[1], 128, reddit[3], flags=_lib.FLAG_NO_SLAB_BLOCKED)
+    # blocking needs >= ~20 entries of a row per slab: degree 150 over 17 slabs streams instead
+    assert "kernel=batch-stream" in describe(200000, 200000, 128, 30000000)
+    assert "kernel=batch-stream" in describe(20000, 20000, 256, 3000000)
     assert describe(1 << 22, 1 << 22, 128, 1 << 26).endswith("rows_per_wave=2 idx32 long_rows>2048 chunk=2048")
     assert "long_rows" not in describe(1 << 22, 1 << 22, 128, 1 << 26, flags=_lib.FLAG_STRICT_ORDER)
     assert describe(1 << 26, 1 << 26, 256, 1 << 30).startswith("variant=3 kernel=batch-stream V=4 S=1 W=64")

@@ -168,7 +168,7 @@ def test_spmm_plan_reuses_split_points(pkg, oracle):
 
     rng = np.random.RandomState(9)
     M = 60000
-    deg = rng.randint(64, 100, size=M)
+    deg = rng.randint(110, 160, size=M)  # >= 20 entries of a row per 6 MB slab: the cache-blocked path
     rowptr = np.zeros(M + 1, dtype=np.int32)
     rowptr[1:] = np.cumsum(deg)
     colind = rng.randint(0, M, size=int(rowptr[-1])).astype(np.int32)

@@ -282,7 +282,7 @@ def test_dgl_entry_points(pkg, oracle, bundled):
 
     rng = np.random.RandomState(4)
     M, N = 60000, 128
-    deg = rng.randint(64, 100, size=M)
+    deg = rng.randint(110, 160, size=M)  # >= 20 entries of a row per 6 MB slab: the cache-blocked path
     rowptr = np.zeros(M + 1, dtype=np.int32)
     rowptr[1:] = np.cumsum(deg)
     rp = torch.from_numpy(rowptr).cuda()
