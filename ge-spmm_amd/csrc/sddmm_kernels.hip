@@ -166,7 +166,10 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // long rows: the wavefront's 64 edges usually lie inside ONE row — no per-edge search then
+        const bool single_row = s_rp[wave][1] >= e1;
         auto row_of = [&](int e) {
+            if (single_row) return r0;
             // largest i in [0, EPW+1] with s_rp[i] <= e   (s_rp[0] = rowptr[r0] <= e0 <= e)
             int lo = 0, hi = EPW + 1;
             if (s_rp[wave][hi] <= e) {  // more than EPW empty rows in the window: fall back
@@ -411,7 +414,7 @@ hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, co
     while (W < 64 && (int64_t)W * V * per_lane < N) W <<= 1;
     const int m = (int)M, z = (int)nnz, n = (int)N;
     if (csr && M > 0 && (flags & kSddmmNoSlab) == 0) {
-        // Dense pattern (mean degree >= 64 and >= 2 entries of a row per slab): cache-blocked form, ~6 MB
+        // Dense pattern (mean degree >= 64 and >= 10 entries of a row per slab): cache-blocked form, ~6 MB
         // slabs of D2. The number of D2 rows is not part of the call: the pattern is taken as square for
         // the slab count (columns past M land in the last slab — fewer hits, same result). Needs a
         // stream-ordered temporary for the split points, so not on a stream under capture.
@@ -421,7 +424,9 @@ hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, co
         const int64_t nslab = (M + slab_rows - 1) / slab_rows;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
-        if (!capturing && N * 4 >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 64 && avg_deg >= 2 * nslab) {
+        // (>= ~10 edges of a row per slab: with fewer the per-row overhead of 'nslab' launches outweighs the L2 hits —
+        // profiles/r01/sddmm_heuristic_audit.log; M = 10^6, degree 100, 41 slabs was 4.5x slower than streaming)
+        if (!capturing && N * 4 >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 64 && avg_deg >= 10 * nslab) {
             int32_t* split = nullptr;
             hipError_t e = workspace_alloc(reinterpret_cast<void**>(&split), (size_t)(nslab + 1) * (size_t)M * 4, st);
             if (e != hipSuccess) return e;
