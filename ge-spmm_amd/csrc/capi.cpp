@@ -95,6 +95,10 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.flags = flags;
     a.empty = empty;
     a.long_row = 0;
+    a.lr_hdr = nullptr;
+    a.lr_rows = nullptr;
+    a.lr_chunks = nullptr;
+    a.lr_chunk = a.lr_max_rows = a.lr_max_chunks = 0;
     a.row_begin = nullptr;
     a.row_end = nullptr;
     a.accumulate = 0;
@@ -117,8 +121,10 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
         else {
             a.rpw = sel.geo.rows_per_wave;
             a.long_row = sel.geo.split_long_rows ? sel.geo.long_row_threshold : 0;
-            e = gespmm::launch_spmm_stream(a, sel.geo, st);
-            if (e == hipSuccess && sel.geo.split_long_rows) e = gespmm::launch_spmm_longrows(a, sel.geo, nnz, ws, (size_t)(ws_bytes > 0 ? ws_bytes : 0), st);
+            if (sel.geo.split_long_rows)
+                e = gespmm::launch_spmm_stream_with_longrows(a, sel.geo, nnz, ws, (size_t)(ws_bytes > 0 ? ws_bytes : 0), st);
+            else
+                e = gespmm::launch_spmm_stream(a, sel.geo, st);
         }
     }
     return (int)e;

@@ -175,7 +175,12 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
                          variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
     }
     // (needs nnz to size its workspace: callers that pass nnz = -1 keep the strict chain)
-    g.split_long_rows = nnz > 0 && ((flags & kFlagSplitLongRows) != 0 || nnz >= kLongRowMinNnz) && (flags & kFlagStrictOrder) == 0 &&
+    // The pass costs ~6.5 us of extra launches when there is no long row (profiles/r01/longrow_threshold_audit.log),
+    // and the host cannot see the degrees. Always on from 2^23 entries; from 2^20 when the mean degree is >= 8
+    // (RMAT-16..18: 1.8-5x faster with it; com-Amazon-shaped graphs, mean degree 5.5 and no hubs, keep their 150 us).
+    // Smaller or sparser matrices with hub rows: GESPMM_FLAG_SPLIT_LONG_ROWS.
+    const bool auto_split = nnz >= kLongRowMinNnz || (nnz >= (1 << 20) && M > 0 && nnz / M >= 8);
+    g.split_long_rows = nnz > 0 && ((flags & kFlagSplitLongRows) != 0 || auto_split) && (flags & kFlagStrictOrder) == 0 &&
                         variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE;
     // A row is "long" when it dwarfs the average wavefront's work: 32x the mean degree,
     // at least kLongRowThreshold entries (reddit-like graphs, mean degree ~500, keep

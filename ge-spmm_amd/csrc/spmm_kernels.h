@@ -49,6 +49,11 @@ struct SpmmArgs {
     const int32_t* row_end;
     int32_t accumulate;        // slab-blocked path: 0 = first slab (C = ...), 1 = C += ...
     int32_t long_row;  // > 0: rows with more entries are skipped by the main kernel (long-row kernel does them)
+    // long-row pass workspace (device): the main kernel appends the rows it skips to these lists
+    int32_t* lr_hdr;     // {nchunks, nrows, -, -}
+    int32_t* lr_rows;    // int4 per long row: {row, first chunk slot, #chunks, -}
+    int32_t* lr_chunks;  // int2 per chunk: {row, chunk index}
+    int32_t lr_chunk, lr_max_rows, lr_max_chunks;
     float empty;    // max reducer: value of rows without non-zeros / initial accumulator
 };
 
@@ -75,8 +80,8 @@ hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStre
 // The two paths below need a temporary: the caller's (ext_ws, 16-byte aligned, >= *_workspace_bytes) or,
 // when that is absent or too small, a stream-ordered block from the library's pool (workspace.h).
 size_t longrows_workspace_bytes(int64_t nnz, int64_t N, int long_row);
-hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, void* ext_ws, size_t ext_bytes,
-                                hipStream_t st);
+hipError_t launch_spmm_stream_with_longrows(SpmmArgs a, const Geometry& geo, int64_t nnz, void* ext_ws, size_t ext_bytes,
+                                            hipStream_t st);
 size_t slabblocked_workspace_bytes(int64_t M, const Geometry& geo);
 hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void* ext_ws, size_t ext_bytes,
                                    hipStream_t st);

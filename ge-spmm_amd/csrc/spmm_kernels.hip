@@ -313,7 +313,17 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         if (rowok) {
             lb = s_ptr[wave][r];
             hb = s_ptr[wave][r + 1];
-            if (a.long_row > 0 && hb - lb > a.long_row) {  // left to spmm_longrow_kernel
+            if (a.long_row > 0 && hb - lb > a.long_row) {  // left to the long-row pass
+                if (l == 0 && tile == 0 && a.lr_hdr) {  // one lane registers the row: chunk slots + list entry
+                    const int nch = (hb - lb + a.lr_chunk - 1) / a.lr_chunk;
+                    const int base = atomicAdd(a.lr_hdr + 0, nch);
+                    const int j = atomicAdd(a.lr_hdr + 1, 1);
+                    if (j < a.lr_max_rows && base + nch <= a.lr_max_chunks) {
+                        reinterpret_cast<int4*>(a.lr_rows)[j] = make_int4(row_first + r, base, nch, 0);
+                        for (int c = 0; c < nch; ++c)
+                            reinterpret_cast<int2*>(a.lr_chunks)[base + c] = make_int2(row_first + r, c);
+                    }
+                }
                 hb = lb;
                 rowok2 = false;
             }
@@ -622,24 +632,6 @@ struct LongRowHeader {
     int nrows;
     int pad[2];
 };
-
-__global__ __launch_bounds__(kThreads) void spmm_longrow_list_kernel(const int32_t* __restrict__ rowptr, int M,
-                                                                      int long_row, int chunk, int max_chunks,
-                                                                      int max_rows, LongRowHeader* hdr,
-                                                                      int4* __restrict__ rowlist,
-                                                                      int2* __restrict__ chunklist) {
-    const int r = blockIdx.x * kThreads + threadIdx.x;
-    if (r >= M) return;
-    const int lb = rowptr[r];
-    const int len = rowptr[r + 1] - lb;
-    if (len <= long_row) return;
-    const int nch = (len + chunk - 1) / chunk;
-    const int base = atomicAdd(&hdr->nchunks, nch);
-    const int j = atomicAdd(&hdr->nrows, 1);
-    if (j >= max_rows || base + nch > max_chunks) return;  // cannot happen: bounds are nnz/long_row, nnz/chunk + rows
-    rowlist[j] = make_int4(r, base, nch, 0);
-    for (int c = 0; c < nch; ++c) chunklist[base + c] = make_int2(r, c);
-}
 
 template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
 __global__ __launch_bounds__(kThreads) void spmm_longrow_chunk_kernel(SpmmArgs a, int chunk, int max_chunks,
@@ -1411,12 +1403,15 @@ size_t longrows_workspace_bytes(int64_t nnz, int64_t N, int long_row) {
     return off + (size_t)max_chunks * (size_t)N * sizeof(float);
 }
 
-hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t nnz, void* ext_ws, size_t ext_bytes,
-                                hipStream_t st) {
-    const bool valued = a.val != nullptr;
-    if (geo.reduce == kReduceMax && valued) return hipErrorInvalidValue;
+// Long-row pass around the main kernel: `begin` sizes and zeroes the workspace and points the main
+// kernel's arguments at it (the main kernel registers every row it skips: chunk slots from one atomic
+// counter, one list entry); `finish` runs the chunk and combine kernels and releases the workspace.
+hipError_t longrows_begin(SpmmArgs& a, int64_t nnz, void* ext_ws, size_t ext_bytes, LongRowWs& ws, bool& own,
+                          hipStream_t st) {
+    a.lr_hdr = nullptr;
+    own = false;
+    ws.hdr = nullptr;
     if (a.long_row <= 0 || nnz <= a.long_row) return hipSuccess;  // no row can be long
-    LongRowWs ws;
     ws.chunk = kLongRowChunk;
     const int64_t max_rows = nnz / a.long_row + 1;
     const int64_t max_chunks = nnz / ws.chunk + max_rows;
@@ -1430,7 +1425,7 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
     const size_t bytes = off_partial + (size_t)max_chunks * (size_t)a.N * sizeof(float);
     char* base = nullptr;
     hipError_t e = hipSuccess;
-    const bool own = !(ext_ws && ext_bytes >= bytes && (reinterpret_cast<uintptr_t>(ext_ws) & 15) == 0);
+    own = !(ext_ws && ext_bytes >= bytes && (reinterpret_cast<uintptr_t>(ext_ws) & 15) == 0);
     if (own) e = workspace_alloc(reinterpret_cast<void**>(&base), bytes, st);
     else base = static_cast<char*>(ext_ws);
     if (e != hipSuccess) return e;
@@ -1439,12 +1434,20 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
     ws.chunklist = reinterpret_cast<int2*>(base + off_chunks);
     ws.partial = reinterpret_cast<float*>(base + off_partial);
     e = hipMemsetAsync(base, 0, sizeof(LongRowHeader), st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(spmm_longrow_list_kernel, dim3((unsigned)((a.M + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                           st, a.rowptr, a.M, a.long_row, ws.chunk, ws.max_chunks, ws.max_rows, ws.hdr, ws.rowlist,
-                           ws.chunklist);
-        e = hipGetLastError();
-    }
+    a.lr_hdr = reinterpret_cast<int32_t*>(ws.hdr);
+    a.lr_rows = reinterpret_cast<int32_t*>(ws.rowlist);
+    a.lr_chunks = reinterpret_cast<int32_t*>(ws.chunklist);
+    a.lr_chunk = ws.chunk;
+    a.lr_max_rows = ws.max_rows;
+    a.lr_max_chunks = ws.max_chunks;
+    return e;
+}
+
+hipError_t longrows_finish(const SpmmArgs& a, const Geometry& geo, const LongRowWs& ws, bool own, hipError_t e,
+                           hipStream_t st) {
+    if (!ws.hdr) return e;
+    const bool valued = a.val != nullptr;
+    if (e == hipSuccess && geo.reduce == kReduceMax && valued) e = hipErrorInvalidValue;
     if (e == hipSuccess) {
         if (geo.reduce == kReduceMax)
             e = geo.idx64 ? longrow_vs<false, true, kReduceMax>(a, ws, geo, st) : longrow_vs<false, false, kReduceMax>(a, ws, geo, st);
@@ -1454,7 +1457,7 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
             e = geo.idx64 ? longrow_vs<false, true, kReduceSum>(a, ws, geo, st) : longrow_vs<false, false, kReduceSum>(a, ws, geo, st);
     }
     if (e == hipSuccess) {
-        const int blocks = ws.max_rows < 1024 ? ws.max_rows : 1024;
+        const int blocks = ws.max_rows < 256 ? ws.max_rows : 256;
         if (geo.reduce == kReduceMax)
             hipLaunchKernelGGL(spmm_longrow_combine_kernel<kReduceMax>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a.C,
                                a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
@@ -1463,8 +1466,18 @@ hipError_t launch_spmm_longrows(const SpmmArgs& a, const Geometry& geo, int64_t 
                                a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
         e = hipGetLastError();
     }
-    const hipError_t ef = own ? workspace_free(base, st) : hipSuccess;
+    const hipError_t ef = own ? workspace_free(ws.hdr, st) : hipSuccess;
     return e != hipSuccess ? e : ef;
+}
+
+// main streaming kernel + long-row pass
+hipError_t launch_spmm_stream_with_longrows(SpmmArgs a, const Geometry& geo, int64_t nnz, void* ext_ws, size_t ext_bytes,
+                                            hipStream_t st) {
+    LongRowWs ws;
+    bool own = false;
+    hipError_t e = longrows_begin(a, nnz, ext_ws, ext_bytes, ws, own, st);
+    if (e == hipSuccess) e = launch_spmm_stream(a, geo, st);
+    return longrows_finish(a, geo, ws, own, e, st);
 }
 
 

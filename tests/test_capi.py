@@ -206,6 +206,9 @@ def test_describe_launch_pins_the_selection_rules(pkg):
     assert "kernel=batch-stream" in describe(20000, 20000, 256, 3000000)
     assert describe(1 << 22, 1 << 22, 128, 1 << 26).endswith("rows_per_wave=2 idx32 long_rows>2048 chunk=2048")
     assert "long_rows" not in describe(1 << 22, 1 << 22, 128, 1 << 26, flags=_lib.FLAG_STRICT_ORDER)
+    assert "long_rows" in describe(1 << 16, 1 << 16, 128, 1 << 20)          # 2^20 entries at mean degree 16: on
+    assert "long_rows" not in describe(1 << 16, 1 << 16, 128, (1 << 20) - 1)  # below 2^20: off
+    assert "long_rows" not in describe(amazon[0], amazon[1], 128, amazon[3])  # mean degree 5.5: off below 2^23
     assert describe(1 << 26, 1 << 26, 256, 1 << 30).startswith("variant=3 kernel=batch-stream V=4 S=1 W=64")
     assert "idx64" in describe(1 << 26, 1 << 26, 256, 1 << 30)
     assert "kernel=segmented-stream" in describe(2048, 2048, 128, 10000)      # short rows, B resident in L2
