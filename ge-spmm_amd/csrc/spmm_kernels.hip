@@ -36,7 +36,7 @@
 //                          small tasks (~12 KB of gathered B per wavefront)
 //   spmm_segstream_kernel  segmented-stream: one continuous gather stream per lane group
 //                          (short rows with B resident in L2; otherwise opt-in)
-//   spmm_longrow_{list,chunk,combine}_kernel   hub rows of skewed graphs in 2048-entry chunks
+//   spmm_longrow_{chunk,combine}_kernel   hub rows of skewed graphs in 2048-entry chunks
 //                          spread over the chip, ordered combine (deterministic)
 //   spmm_slabplan_kernel / spmm_slab_kernel   cache blocking for dense graphs
 //   spmm_parreduce_kernel  variant 5: lanes over nnz, reduce-scatter + xor butterfly
@@ -608,9 +608,9 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
 // gathers in flight: tens of GB/s). Rows longer than `long_row` entries are therefore
 // skipped by the main kernel and done here in CHUNKS of kLongRowChunk entries:
 //
-//   1. spmm_longrow_list_kernel   one thread per row; a long row reserves ceil(len/chunk)
-//                                 consecutive chunk slots (atomic counter) and one entry of
-//                                 the long-row list {row, first slot, #chunks};
+//   1. (in the main kernel)       the lane group that meets a long row skips it and registers it:
+//                                 ceil(len/chunk) consecutive chunk slots (one atomic counter) and one
+//                                 entry of the long-row list {row, first slot, #chunks};
 //   2. spmm_longrow_chunk_kernel  workgroups walk the chunk list grid-stride; the NG = 4*G
 //                                 lane groups of a workgroup take the chunk's 64-entry tiles
 //                                 round-robin (group q: tiles q, q+NG, ...), each keeps ONE
