@@ -83,8 +83,9 @@ def _make_cfg(cfg):
 class SpmmPlan:
     """Scratch kept across calls for ONE sparse matrix at one feature width — the "analysis" stage of
     the vendor libraries. For dense graphs (cache-blocked path) it holds the per-row split points, which
-    are computed on the first call and reused afterwards (0.2 ms per call on a reddit-sized graph); for
-    every other path it only saves the per-call allocation. The caller vouches that ``rowptr`` /
+    are computed on the first call and reused afterwards (0.2 ms per call on a reddit-sized graph). Creating
+    a plan also looks at the longest row (one synchronisation) and switches the long-row pass on or off
+    accordingly — rows that pass re-associates are within the 1e-4 tolerance, not bit-exact. The caller vouches that ``rowptr`` /
     ``colind`` do not change while the plan is in use and uses a plan on one stream at a time.
 
         plan = SpmmPlan(rowptr, colind, K, N)
@@ -96,8 +97,17 @@ class SpmmPlan:
         _need(colind, "colind", torch.int32, 1)
         self.shape = (rowptr.numel() - 1, int(K), int(N), colind.numel(), int(variant))
         self.graph = (rowptr.data_ptr(), colind.data_ptr())
+        # Analysis the plain entry points cannot afford (it synchronises): the longest row decides whether the
+        # long-row pass is worth its launches — the library's own rule has to guess from nnz and the mean degree.
+        M, nnz = self.shape[0], self.shape[3]
+        self.flags = 0
+        if M > 0 and nnz > 0:
+            max_deg = int((rowptr[1:] - rowptr[:-1]).max().item())
+            threshold = max(2048, 32 * ((nnz + M - 1) // M))
+            self.flags = _lib.FLAG_SPLIT_LONG_ROWS if max_deg > threshold else _lib.FLAG_STRICT_ORDER
+        self._cfg = LaunchCfg(0, 0, 0, 0, 0, self.flags)
         nbytes = lib.gespmm_csr_spmm_workspace_bytes(self.shape[0], self.shape[1], self.shape[2], self.shape[3],
-                                                     int(variant), None)
+                                                     int(variant), ctypes.byref(self._cfg))
         if nbytes < 0:
             check(int(nbytes), "gespmm_csr_spmm_workspace_bytes")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=rowptr.device) if nbytes > 0 else None
@@ -108,7 +118,7 @@ class SpmmPlan:
         if (rowptr.numel() - 1, dense.shape[0], dense.shape[1], colind.numel(), int(variant)) != (M, K, N, nnz, var) or \
                 (rowptr.data_ptr(), colind.data_ptr()) != self.graph:
             raise ValueError("SpmmPlan was made for a different matrix, width or variant")
-        return _lib.FLAG_REUSE_SPLIT if (self.ready and self.workspace is not None) else 0
+        return self.flags | (_lib.FLAG_REUSE_SPLIT if (self.ready and self.workspace is not None) else 0)
 
 
 def _spmm(rowptr, colind, values, dense, variant, cfg, out, plan=None):
