@@ -20,7 +20,6 @@ static int pow2_ceil(int64_t x) {
 }
 
 int auto_variant(int64_t M, int64_t nnz, int64_t N) {
-    (void)M;
     (void)nnz;
     // Up to 64 columns one lane per column already spans a whole wavefront-wide group;
     // coarsening would only shrink the group and put more rows on one wavefront, and a
@@ -28,6 +27,10 @@ int auto_variant(int64_t M, int64_t nnz, int64_t N) {
     // narrow_n_kernel_choice.log): V=1 is equal or faster for every graph at N <= 64,
     // by 30-58 % on the denser ones (products-like N=32, reddit-like N<=32).
     if (N <= 64) return GESPMM_VARIANT_CRC;
+    // Just above one 256-column tile the second tile would be mostly empty yet walk every row again:
+    // two strips per lane (one 512-column tile) instead — 24 % faster at N = 260, 3 % at 384 on a
+    // 335 k-row graph; small graphs prefer the extra workgroups of two tiles (profiles/r01/width_audit.log).
+    if (N % 4 == 0 && N > 256 && N <= 384 && M >= (1 << 17)) return GESPMM_VARIANT_CRC_CWM8;
     if (N % 4 == 0) return GESPMM_VARIANT_CRC_CWM4;
     if (N % 2 == 0) return GESPMM_VARIANT_CRC_CWM2;
     return GESPMM_VARIANT_CRC;

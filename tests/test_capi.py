@@ -215,6 +215,8 @@ def test_describe_launch_pins_the_selection_rules(pkg):
     assert describe(reddit[0], reddit[1], 4, reddit[3], variant=5) == "variant=5 kernel=parallel-reduction W=64 idx32"
     assert "kernel=parallel-reduction" in describe(reddit[0], reddit[1], 8, reddit[3], flags=_lib.FLAG_ALLOW_REASSOCIATION)
     assert "kernel=parallel-reduction" not in describe(reddit[0], reddit[1], 8, reddit[3])
+    assert describe(amazon[0], amazon[1], 260, amazon[3]).startswith("variant=4 kernel=batch-stream V=4 S=2 W=64")  # one 512-col tile
+    assert describe(27770, 27770, 260, 352807).startswith("variant=3 ")         # small graph: two tiles
     assert describe(100, 100, 41, 1000).startswith("variant=1 ")               # odd N: one column per lane
     assert describe(100, 100, 130, 1000).startswith("variant=2 ") and " V=2 " in describe(100, 100, 130, 1000)
     buf = C.create_string_buffer(8)
