@@ -128,7 +128,7 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     const int64_t avg_deg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 8;
     // Cache blocking for dense graphs (one launch per ~6 MB column slab of B, see
     // spmm_kernels.hip): worth it when B per column tile is much larger than an L2 and a
-    // row still finds several of its entries in every slab.
+    // row still carries enough work in every slab.
     {
         auto plan = [&](int64_t row_bytes, int64_t* slab_rows_out, int64_t* nslab_out) {
             int64_t slab_rows = cfg_slab_rows > 0 ? cfg_slab_rows : (6 << 20) / row_bytes;
@@ -137,40 +137,34 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
             const int64_t nslab = (K + slab_rows - 1) / slab_rows;
             *slab_rows_out = slab_rows;
             *nslab_out = nslab;
-            // measured on reddit-like (profiles/r01/slab_blocking.log): 1.5-1.7x for N >= 64 with 4-6 MB
-            // slabs, a loss at N = 32 (128-byte row slices)
-            // ... and only when a row keeps >= ~20 of its entries per slab: with fewer, the per-slab read-modify-write
-            // of C outweighs the L2 hits (M = 200 k, degree 150, 17 slabs: 2.58 ms blocked vs 2.04 ms streaming,
-            // profiles/r01/heuristic_audit.log; reddit-like has 26 per slab)
-            return nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 20 * nslab &&
-                   avg_deg >= 64;
+            // Measured (profiles/r01/slab_blocking.log, heuristic_audit.log, dense_width_audit.log): blocking wins
+            // when the part of a row that falls into one slab still gathers >= ~10 KB (reddit-like: 13 KB at every
+            // width; a 200 k-row degree-150 matrix: 4.5 KB, 27 % slower blocked) — with 6 MB slabs that is a matrix
+            // density of ~0.16 %. Below it the per-slab read-modify-write of C outweighs the L2 hits. Also: B at
+            // least 4 slabs, mean degree >= 64, row slices >= 256 B (a loss at N = 32).
+            return nnz > 0 && M > 0 && row_bytes >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 64 &&
+                   avg_deg * row_bytes >= 10240 * nslab;
         };
         int64_t slab_rows = 0, nslab = 0;
-        bool dense = plan((int64_t)g.group * g.vec * g.strips * 4, &slab_rows, &nslab);
-        // Column tiles are dealt to workgroups round-robin (tile = id mod ntile) and workgroup ids to
-        // XCDs round-robin (id mod 8): with 2, 4 or 8 tiles an XCD only ever sees ONE tile, so its L2
-        // holds slab_rows x (tile bytes) of B. 512-byte tiles (W = 32, V = 4, one strip) instead of 1-KB
-        // ones let the slab be twice as tall for the same footprint and halve the number of slabs
-        // (N = 256: 9.96 -> 8.79 ms, N = 512: 19.2 -> 17.4 on reddit-like,
-        // profiles/r01/slab_size_sweep_v2.log).
+        bool dense;
         const bool forced = (flags & kFlagSlabBlocked) != 0;
-        if ((flags & kFlagNoSlabBlocked) == 0 && g.vec == 4 && cfg_strips == 0 && cfg_group == 0 &&
-            (int64_t)g.group * g.strips > 32) {
-            const int64_t ntile1 = (N + 127) / 128;
-            int64_t sr1 = 0, ns1 = 0;
-            if (ntile1 == 2 || ntile1 == 4 || ntile1 == 8) {
-                if (plan(512, &sr1, &ns1) || forced) {
-                    g.group = 32;
-                    g.strips = 1;
-                    slab_rows = sr1;
-                    nslab = ns1;
-                    dense = true;
-                } else {
-                    // the narrow-tile form is the better of the two whenever it applies: if it is not worth it,
-                    // neither is blocking with 1-KB tiles (M = 20 k, degree 150, N = 256: 380 vs 330 us streaming)
-                    dense = false;
-                }
+        if (g.vec == 4 && N > 128 && cfg_strips == 0 && cfg_group == 0) {
+            // The blocked path picks its own column tiling (a tile with few live columns costs as much as a full
+            // one: every tile walks every entry). Column tiles are dealt to workgroups round-robin (tile = id mod
+            // ntile) and workgroup ids to XCDs round-robin (id mod 8), so with 2, 4 or 8 FULL 128-column tiles
+            // an XCD only ever sees one tile and its L2 holds slab_rows x 512 B: N = 256 / 512 / 1024 use
+            // 512-byte tiles (N = 256: 9.96 -> 8.79 ms on reddit-like, slab_size_sweep_v2.log). Every other
+            // width takes ceil(N / 256) tiles of 1 KB (N = 132: 8.9 -> 6.6 ms, N = 384: 23.8 -> 17.1,
+            // N = 516: 43 -> 30, dense_width_audit.log).
+            const int64_t ntile128 = (N + 127) / 128;
+            const bool xcd_tiles = (N % 128 == 0) && (ntile128 == 2 || ntile128 == 4 || ntile128 == 8);
+            dense = plan(xcd_tiles ? 512 : 1024, &slab_rows, &nslab);
+            if (dense || forced) {
+                g.group = xcd_tiles ? 32 : 64;
+                g.strips = 1;
             }
+        } else {
+            dense = plan((int64_t)g.group * g.vec * g.strips * 4, &slab_rows, &nslab);
         }
         g.slab_rows = (int)slab_rows;
         g.K = K;

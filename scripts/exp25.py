@@ -22,9 +22,11 @@ g = graphs.synthetic_graph(name, device=dev)
 rp, ci, M, K = g["rowptr"], g["colind"], g["M"], g["K"]
 val = torch.rand(ci.numel(), device=dev)
 prev = None
-for N in (1, 2, 3, 4, 6, 8, 12, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 66, 68, 96, 100, 127, 128, 129, 130, 132, 160, 192, 200, 255, 256, 257, 260, 320, 384, 500, 512, 513, 516, 768, 1024):
+NS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
+IT = 3 if ci.numel() > 2e7 else 100
+for N in NS or (1, 2, 3, 4, 6, 8, 12, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 66, 68, 96, 100, 127, 128, 129, 130, 132, 160, 192, 200, 255, 256, 257, 260, 320, 384, 500, 512, 513, 516, 768, 1024):
     B = torch.rand(K, N, device=dev); C = torch.empty(M, N, device=dev)
-    us = time_fn(lambda: spmm.csr_spmm(rp, ci, val, B, out=C))
+    us = time_fn(lambda: spmm.csr_spmm(rp, ci, val, B, out=C), IT, 1 if IT < 10 else 10)
     per = us / N
     note = ""
     if prev is not None and per > 1.35 * prev[1] and N > 8:
