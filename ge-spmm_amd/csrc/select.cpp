@@ -162,6 +162,7 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
             if (dense || forced) {
                 g.group = xcd_tiles ? 32 : 64;
                 g.strips = 1;
+                if (variant == GESPMM_VARIANT_CRC_CWM8) variant = GESPMM_VARIANT_CRC_CWM4;  // report what runs
             }
         } else {
             dense = plan((int64_t)g.group * g.vec * g.strips * 4, &slab_rows, &nslab);
