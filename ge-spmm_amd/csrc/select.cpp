@@ -70,6 +70,14 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // Degrade to what alignment and N allow; results do not depend on V/S/W.
     if (g.vec > max_vec) g.vec = max_vec;
     if (g.strips == 2 && g.vec != 4) g.strips = 1;
+    // Widths with no dwordx4 access (odd N, N = 2 mod 4, or unaligned operands) beyond one 64-lane tile: two
+    // strips per lane halve the number of column tiles — each tile walks every entry of every row again
+    // (reddit-like N = 65: 5.3 -> 3.9 ms; bench graph N = 513: 719 -> 647 us; no gain where scalar gathers are issue-bound, N = 127; profiles/r01/width_audit.log). Batch-stream, blocked and
+    // long-row kernels only; W = 64.
+    const bool wide_narrow_vec = g.vec < 4 && cfg_strips == 0 && cfg_group == 0 && N > 64 * g.vec &&
+                                 variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE &&
+                                 (flags & kFlagSegStream) == 0;
+    if (wide_narrow_vec) g.strips = 2;
 
     if (variant == GESPMM_VARIANT_PARREDUCE) {
         const int64_t avg = (nnz > 0 && M > 0) ? (nnz + M - 1) / M : 16;
@@ -194,7 +202,7 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // split. The segmented kernel keeps the short-row, L2-resident-B corner (58 vs 68 us,
     // kernel_generations_cache_regimes.log) and is otherwise opt-in (GESPMM_FLAG_SEG_STREAM).
     g.segmented = ((flags & kFlagSegStream) != 0 || (b_resident && g.group >= 32 && avg_deg <= 12)) &&
-                  !g.split_long_rows;
+                  !g.split_long_rows && !(g.strips == 2 && g.vec < 4);
     out->variant = variant;
     out->geo = g;
     return 0;

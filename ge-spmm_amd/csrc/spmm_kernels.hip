@@ -1259,7 +1259,10 @@ template <bool VALUED, bool IDX64, int RED>
 static hipError_t stream_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
     if (g.strips == 2) {
         if (g.vec == 4) return stream_w<4, 2, VALUED, IDX64, RED>(a, g.group, g.rows_per_wave, st);
-        return hipErrorInvalidValue;
+        // widths that allow no dwordx4 (odd N, N = 2 mod 4) beyond one 64-lane tile: two strips, W = 64 only
+        if (g.group != 64) return hipErrorInvalidValue;
+        if (g.vec == 2) return launch_stream<2, 2, 64, VALUED, IDX64, RED>(a, g.rows_per_wave, st);
+        return launch_stream<1, 2, 64, VALUED, IDX64, RED>(a, g.rows_per_wave, st);
     }
     switch (g.vec) {
         case 1: return stream_w<1, 1, VALUED, IDX64, RED>(a, g.group, g.rows_per_wave, st);
@@ -1384,7 +1387,9 @@ template <bool VALUED, bool IDX64, int RED>
 static hipError_t longrow_vs(const SpmmArgs& a, const LongRowWs& ws, const Geometry& g, hipStream_t st) {
     if (g.strips == 2) {
         if (g.vec == 4) return longrow_w<4, 2, VALUED, IDX64, RED>(a, ws, g.group, st);
-        return hipErrorInvalidValue;
+        if (g.group != 64) return hipErrorInvalidValue;
+        if (g.vec == 2) return launch_longrow<2, 2, 64, VALUED, IDX64, RED>(a, ws, st);
+        return launch_longrow<1, 2, 64, VALUED, IDX64, RED>(a, ws, st);
     }
     switch (g.vec) {
         case 1: return longrow_w<1, 1, VALUED, IDX64, RED>(a, ws, g.group, st);
@@ -1515,7 +1520,9 @@ template <bool VALUED, bool IDX64, int RED>
 static hipError_t slab_vs(const SpmmArgs& a, const Geometry& g, hipStream_t st) {
     if (g.strips == 2) {
         if (g.vec == 4) return slab_w<4, 2, VALUED, IDX64, RED>(a, g.group, st);
-        return hipErrorInvalidValue;
+        if (g.group != 64) return hipErrorInvalidValue;
+        if (g.vec == 2) return launch_slab<2, 2, 64, VALUED, IDX64, RED>(a, st);
+        return launch_slab<1, 2, 64, VALUED, IDX64, RED>(a, st);
     }
     switch (g.vec) {
         case 1: return slab_w<1, 1, VALUED, IDX64, RED>(a, g.group, st);
