@@ -42,9 +42,9 @@ def test_random_shapes_and_knobs(pkg, oracle):
              _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_SHALLOW_UNROLL, _lib.FLAG_SLAB_BLOCKED, _lib.FLAG_SPLIT_LONG_ROWS,
              _lib.FLAG_SPLIT_LONG_ROWS | _lib.FLAG_STRICT_ORDER, _lib.FLAG_SLAB_BLOCKED | _lib.FLAG_FORCE_IDX64]
     rng = np.random.RandomState(20260928)
-    for case in range(400):
+    for case in range(600):
         G, law = random_csr(rng)
-        N = int(rng.choice([1, 2, 3, 4, 7, 16, 31, 32, 33, 64, 100, 128, 200, 256, 384, 512]))
+        N = int(rng.choice([1, 2, 3, 4, 7, 16, 31, 32, 33, 64, 65, 100, 127, 128, 129, 130, 200, 256, 258, 260, 384, 512, 513]))
         variant = int(rng.choice([-1, 0, 1, 2, 3, 4]))
         flags = int(knobs[rng.randint(len(knobs))])
         cfg = {"flags": flags, "rows_per_wave": int(rng.choice([0, 0, 1, 2, 8, 32])),

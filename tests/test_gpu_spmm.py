@@ -15,7 +15,7 @@ from helpers import GOLDEN, bits, edge_case_csr
 pytestmark = pytest.mark.gpu
 
 EXACT_VARIANTS = (-1, 0, 1, 2, 3, 4)
-N_SWEEP = (1, 2, 3, 4, 5, 8, 16, 31, 32, 33, 41, 64, 100, 128, 192, 256, 512)
+N_SWEEP = (1, 2, 3, 4, 5, 8, 16, 31, 32, 33, 41, 64, 65, 100, 127, 128, 130, 192, 256, 258, 512)
 
 
 def dev_csr(G, dev="cuda"):
