@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
     constexpr int G = 64 / W;
     constexpr int EPW = 64;  // edges per wavefront (CSR form): G edges at a time, EPW/G rounds
     constexpr int UE = 4;    // edges per lane group per step (COO form)
-    constexpr int IT = (V == 4) ? 2 : 8;  // vectors per lane that cover a row under launch_sddmm's width rule
+    constexpr int IT = (V == 4) ? 2 : (V == 2) ? 4 : 8;  // vectors per lane that cover a row under launch_sddmm's width rule
     using T = typename SdVec<V>::type;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_slab_kernel(const int32_t* __r
                                                                const float* __restrict__ D2, float* __restrict__ out,
                                                                int M, int N, int rows_per_wave) {
     constexpr int G = 64 / W;
-    constexpr int IT = (V == 4) ? 2 : 8;  // vectors per lane that cover a row (launch_sddmm's width rule)
+    constexpr int IT = (V == 4) ? 2 : (V == 2) ? 4 : 8;  // vectors per lane that cover a row (launch_sddmm's width rule)
     constexpr int UE = 4;                 // edges per lane group in flight
     using T = typename SdVec<V>::type;
     __shared__ int s_col[kWaves][64];
@@ -409,12 +409,12 @@ hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, co
     // Measured against "just enough lanes to cover N" (profiles/r01/sddmm_group_width.log):
     // N=41 2.4-2.8x, N=64 1.35x, N=128 1.2x faster on reddit-like, equal or better on com-Amazon-like.
     // Both forms use the same width, so COO and CSR results agree bit for bit.
-    const int64_t per_lane = (V == 4) ? 2 : 8;
+    const int64_t per_lane = (V == 4) ? 2 : (V == 2) ? 4 : 8;
     int W = 4;
     while (W < 64 && (int64_t)W * V * per_lane < N) W <<= 1;
     const int m = (int)M, z = (int)nnz, n = (int)N;
     if (csr && M > 0 && (flags & kSddmmNoSlab) == 0) {
-        // Dense pattern (mean degree >= 64 and >= 10 entries of a row per slab): cache-blocked form, ~6 MB
+        // Dense pattern (mean degree >= 64, >= 4.5 KB gathered per row and slab): cache-blocked form, ~6 MB
         // slabs of D2. The number of D2 rows is not part of the call: the pattern is taken as square for
         // the slab count (columns past M land in the last slab — fewer hits, same result). Needs a
         // stream-ordered temporary for the split points, so not on a stream under capture.
@@ -424,9 +424,11 @@ hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, co
         const int64_t nslab = (M + slab_rows - 1) / slab_rows;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
-        // (>= ~10 edges of a row per slab: with fewer the per-row overhead of 'nslab' launches outweighs the L2 hits —
+        // (the edges of a row that fall into one slab must still gather >= ~4.5 KB of D2: with less the per-row
+        // overhead of 'nslab' launches outweighs the L2 hits —
         // profiles/r01/sddmm_heuristic_audit.log; M = 10^6, degree 100, 41 slabs was 4.5x slower than streaming)
-        if (!capturing && N * 4 >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 64 && avg_deg >= 10 * nslab) {
+        if (!capturing && N * 4 >= 256 && nslab >= 4 && nslab <= 4096 && avg_deg >= 64 &&
+            avg_deg * N * 4 >= 4608 * nslab) {
             int32_t* split = nullptr;
             hipError_t e = workspace_alloc(reinterpret_cast<void**>(&split), (size_t)(nslab + 1) * (size_t)M * 4, st);
             if (e != hipSuccess) return e;
