@@ -353,6 +353,11 @@ __global__ __launch_bounds__(kThreads) void sddmm_slab_kernel(const int32_t* __r
     }
 }
 
+// Row-walking (one wavefront per row) is skew-sensitive — a hub row is walked by one wavefront — and only pays
+// for long rows: parity with the edge-parallel form at degree 32-48, up to 2x at degree >= 64 on patterns too
+// small to block (profiles/r01/sddmm_heuristic_audit.log).
+constexpr int64_t kSddmmRowWalkMinDegree = 64;
+
 template <int V>
 static hipError_t sddmm_slab_w(int W, const int32_t* rb, const int32_t* re, const int32_t* colind, const float* D1,
                                const float* D2, float* out, int M, int N, hipStream_t st) {
@@ -444,6 +449,14 @@ hipError_t launch_sddmm(const int32_t* rows, bool csr, const int32_t* colind, co
             return e != hipSuccess ? e : ef;
         }
         (void)hipGetLastError();
+        // Long rows but not worth blocking: the same row-walking kernel over the whole row ([rowptr[r], rowptr[r+1])
+        // is "one slab") — D1 slice in registers, four edges in flight, no per-edge row search. The edge-parallel
+        // form below stays for short rows, where a row per wavefront would leave lanes idle.
+        if (avg_deg >= kSddmmRowWalkMinDegree) {
+            if (V == 4) return sddmm_slab_w<4>(W, rows, rows + 1, colind, D1, D2, out, m, n, st);
+            if (V == 2) return sddmm_slab_w<2>(W, rows, rows + 1, colind, D1, D2, out, m, n, st);
+            return sddmm_slab_w<1>(W, rows, rows + 1, colind, D1, D2, out, m, n, st);
+        }
     }
     if (csr) {
         if (V == 4) return sddmm_w<4, true>(W, rows, colind, D1, D2, out, m, z, n, st);
