@@ -11,8 +11,9 @@
 // to four edges per group are in flight, their slices requested before the first FMA, and
 // the W partial dot products meet in an xor butterfly (cross-lane ds_bpermute / DPP
 // moves). Edges of a wavefront are consecutive, so the out[] stores and the index loads
-// coalesce. Dense patterns in CSR form take a cache-blocked kernel (one launch per column
-// slab of D2, sddmm_slab_kernel). Summation order is not sequential (neither is the
+// coalesce. In CSR form, long rows (mean degree >= 64) are walked a row per wavefront with the D1
+// slice in registers (sddmm_slab_kernel), one launch per ~6 MB column slab of D2 when the pattern
+// is dense enough for cache blocking, one launch otherwise. Summation order is not sequential (neither is the
 // reference's shuffle tree): parity for SDDMM is tolerance-based; COO, CSR and the
 // cache-blocked form agree with each other bit for bit.
 
