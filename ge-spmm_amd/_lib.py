@@ -55,6 +55,7 @@ EXPORTS = [
     "gespmm_mtx_free",
     "gespmm_coo_to_csr",
     "gespmm_row_partition",
+    "gespmm_baseline_atomic_scatter_f32",
 ]
 
 
@@ -120,6 +121,8 @@ def _load():
     lib.gespmm_mtx_free.argtypes = [POINTER(Coo)]
     lib.gespmm_coo_to_csr.restype = c_int
     lib.gespmm_coo_to_csr.argtypes = [c_int32, c_int32, c_int64, p, p, p, p, p, p]
+    lib.gespmm_baseline_atomic_scatter_f32.restype = c_int
+    lib.gespmm_baseline_atomic_scatter_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, p]
     lib.gespmm_row_partition.restype = c_int
     lib.gespmm_row_partition.argtypes = [p, c_int64, c_int32, p]
     return lib

@@ -305,6 +305,16 @@ int gespmm_sddmm_csr_f32(const int32_t* rowptr, const int32_t* colind, const flo
                                      reinterpret_cast<hipStream_t>(stream));
 }
 
+int gespmm_baseline_atomic_scatter_f32(const int32_t* rowptr, const int32_t* colind, const float* in, float* out,
+                                       int64_t M, int64_t K, int64_t N, int64_t nnz, void* stream) {
+    if (M < 0 || K < 0 || N < 0 || nnz < 0) return GESPMM_EINVAL;
+    if (M > 0x7fffffffLL - 1 || K > 0x7fffffffLL || N > 0x7fffffffLL / 4 || nnz > 0x7fffffffLL) return GESPMM_ERANGE;
+    if (K == 0 || N == 0) return 0;
+    if (!out || (nnz > 0 && (!rowptr || !colind || !in))) return GESPMM_EINVAL;
+    return (int)gespmm::launch_atomic_scatter(rowptr, colind, in, out, M, K, N, nnz,
+                                              reinterpret_cast<hipStream_t>(stream));
+}
+
 int64_t gespmm_csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
     if (M < 0 || K < 0 || nnz < 0) return GESPMM_EINVAL;
     return gespmm::csr2csc_workspace_bytes(M, K, nnz);

@@ -96,6 +96,10 @@ hipError_t launch_sddmm(const int32_t* rowind_or_rowptr, bool csr, const int32_t
 hipError_t launch_slabplan(const int32_t* rowptr, const int32_t* colind, int32_t* split, int M, int nslab,
                            int slab_rows, hipStream_t st);
 
+// baseline_kernels.hip — Gunrock-style edge-parallel atomicAdd scatter (comparison column only)
+hipError_t launch_atomic_scatter(const int32_t* rowptr, const int32_t* colind, const float* in, float* out, int64_t M,
+                                 int64_t K, int64_t N, int64_t nnz, hipStream_t st);
+
 // csr2csc.hip
 int64_t csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
 hipError_t launch_csr2csc(const int32_t* rowptr, const int32_t* colind, const float* csr_val,

@@ -25,11 +25,15 @@
 //   --iters n       timed launches per width          (default 200; spmm_test.cu:714)
 //   --seed s        srand seed for B                  (default time(0); spmm_test.cu:587)
 //   --use-values    keep the file's values            (default: all ones; spmm_test.cu:574)
-//   --validate      run every variant at N=max_ncols against an in-driver CPU loop and
-//                   print "kernel<m> WA: ..." on |diff| > 1e-2 (the reference's
-//                   `#define VALIDATE` block, spmm_test.cu:595-605, 671-698). The CPU
-//                   loop only CHECKS device output; it never produces results.
-//   --cpu-baseline  time that CPU loop (1 thread) and print its GFLOP/s
+//   --validate      run every variant (and the library's own pick when --method -1 is given) against an
+//                   in-driver CPU loop and print "kernel<m> WA: ..." on |diff| > 1e-2 (the reference's
+//                   `#define VALIDATE` block, spmm_test.cu:595-605, 671-698) — at every width of --ncols,
+//                   or at N = max_ncols like the reference when no widths are given. The CPU loop only
+//                   CHECKS device output; it never produces results.
+//   --cpu-baseline  time that CPU loop (1 thread) at the same widths and print its GFLOP/s
+//   --atomic-baseline  also time the Gunrock app's edge-parallel atomicAdd scatter
+//                   (gunrock-test/app/spmm/spmm_enactor.cuh:92-105) per width, printed on stdout (the CSV keeps
+//                   the reference's two columns); with --validate it is checked against a CPU scatter loop
 //   --out path      CSV side file                     (default spmm_test_out.out)
 //   --no-vendor     skip the rocSPARSE comparison column
 //   --describe      print what the library launches for each N (gespmm_describe_launch)
@@ -203,6 +207,7 @@ int main(int argc, char** argv) {
     int method = GESPMM_VARIANT_CRC_CWM2;
     int iters = 200;
     bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true, describe = false;
+    bool atomic_baseline = false;
     unsigned seed = 0;
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
@@ -228,13 +233,14 @@ int main(int argc, char** argv) {
         else if (a == "--use-values") use_values = true;
         else if (a == "--no-vendor") vendor = false;
         else if (a == "--describe") describe = true;
+        else if (a == "--atomic-baseline") atomic_baseline = true;
         else if (a == "--cache") cache_dir = next("--cache");
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
     if (!mtx_path) {
         fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
-                        "[--use-values] [--validate] [--cpu-baseline] [--no-vendor] [--describe] [--out path]\n", argv[0]);
+                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--no-vendor] [--describe] [--out path]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (iters < 1) iters = 1;
@@ -296,14 +302,6 @@ int main(int argc, char** argv) {
     srand(seed);
     for (size_t i = 0; i < (size_t)max_ncols * (size_t)K; i++) g.B[i] = float(rand() % 100 - 50) / 100;
 
-    double cpu_gflops = 0.0;
-    if (validate || cpu_baseline) {
-        const auto t0 = std::chrono::steady_clock::now();
-        cpu_check_loop(M, max_ncols, g.indptr, g.indices, g.data, g.B, g.golden);
-        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        cpu_gflops = 2.0 * nnz * max_ncols / s / 1e9;
-    }
-
     CHECK_HIP(hipSetDevice(dev_id));
     for (;;) {
         hipError_t s1 = hipMalloc((void**)&g.indptr_dev, ((size_t)M + 1) * sizeof(int32_t));
@@ -336,40 +334,71 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(warmup, dim3(1), dim3(1), 0, 0);
     CHECK_HIP(hipDeviceSynchronize());
 
-    if (validate) {
-        const int N = max_ncols;
-        for (int m = 0; m < GESPMM_NUM_VARIANTS; m++) {
-            CHECK_HIP(hipMemset(g.C_dev, 0, (size_t)M * N * sizeof(float)));
-            CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, m,
-                                         nullptr));
-            CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
-            for (int i = 0; i < M; i++)
-                for (int j = 0; j < N; j++)
-                    if (fabs(g.C[(size_t)i * N + j] - g.golden[(size_t)i * N + j]) > 1e-2) {
-                        printf("kernel%d WA: C[%d, %d] = %f, golden = %f\n", m, i, j, g.C[(size_t)i * N + j],
-                               g.golden[(size_t)i * N + j]);
-                        break;
-                    }
-        }
-        if (vendor) {  // reference: csrmm2 checked against golden too (spmm_test.cu:671-679)
-            VendorSpmm vs;
-            if (vs.setup(M, K, N, nnz, g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev) && vs.run()) {
-                CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
+    // Validation / CPU timing happen AFTER the allocation loop: max_ncols is final here, so the CPU result and
+    // the device result always share one leading dimension.
+    if (validate || cpu_baseline) {
+        std::vector<int> widths;
+        for (int n : ncols_list)
+            if (n >= 1 && n <= max_ncols) widths.push_back(n);
+        if (widths.empty()) widths.push_back(max_ncols);  // the reference validates at max_ncols only
+        for (int N : widths) {
+            const auto t0 = std::chrono::steady_clock::now();
+            cpu_check_loop(M, N, g.indptr, g.indices, g.data, g.B, g.golden);
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (cpu_baseline)
+                printf("cpu golden loop: %f GFLOP/s (1 thread, N=%d)\n", 2.0 * nnz * N / secs / 1e9, N);
+            if (!validate) continue;
+            auto compare = [&](const char* who) {
                 for (int i = 0; i < M; i++)
                     for (int j = 0; j < N; j++)
-                        if (fabs(g.C[(size_t)i * N + j] - g.golden[(size_t)i * N + j]) > 1e-2) {
-                            printf("rocsparse WA: C[%d, %d] = %f, golden = %f\n", i, j, g.C[(size_t)i * N + j],
+                        if (!(fabs(g.C[(size_t)i * N + j] - g.golden[(size_t)i * N + j]) <= 1e-2)) {
+                            printf("%s WA: C[%d, %d] = %f, golden = %f\n", who, i, j, g.C[(size_t)i * N + j],
                                    g.golden[(size_t)i * N + j]);
-                            break;
+                            return false;  // first mismatch per variant is enough
                         }
-            } else {
-                printf("rocsparse spmm unavailable\n");
+                return true;
+            };
+            int checked = 0;
+            std::vector<int> methods;
+            for (int m = 0; m < GESPMM_NUM_VARIANTS; m++) methods.push_back(m);
+            if (method == GESPMM_VARIANT_AUTO) methods.push_back(GESPMM_VARIANT_AUTO);
+            for (int m : methods) {
+                CHECK_HIP(hipMemset(g.C_dev, 0xff, (size_t)M * N * sizeof(float)));  // NaNs: every element must be written
+                CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, m,
+                                             nullptr));
+                CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
+                char who[32];
+                snprintf(who, sizeof who, "kernel%d", m);
+                compare(who);
+                checked++;
             }
-            vs.teardown();
+            if (vendor) {  // reference: csrmm2 checked against golden too (spmm_test.cu:671-679)
+                VendorSpmm vs;
+                if (vs.setup(M, K, N, nnz, g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev) && vs.run()) {
+                    CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
+                    compare("rocsparse");
+                } else {
+                    printf("rocsparse spmm unavailable\n");
+                }
+                vs.teardown();
+            }
+            if (atomic_baseline && M == K) {
+                // scatter form out[dest] += in[src] on the pattern (gunrock CPU_Reference, spmm_test.cuh): CPU loop as checker
+                float* out_dev = nullptr;
+                CHECK_HIP(hipMalloc((void**)&out_dev, (size_t)K * N * sizeof(float)));
+                CHECK_GE(gespmm_baseline_atomic_scatter_f32(g.indptr_dev, g.indices_dev, g.B_dev, out_dev, M, K, N, nnz,
+                                                            nullptr));
+                CHECK_HIP(hipMemcpy(g.C, out_dev, (size_t)K * N * sizeof(float), hipMemcpyDeviceToHost));
+                CHECK_HIP(hipFree(out_dev));
+                for (size_t i = 0; i < (size_t)K * N; i++) g.golden[i] = 0.0f;
+                for (int i = 0; i < M; i++)
+                    for (int p2 = g.indptr[i]; p2 < g.indptr[i + 1]; p2++)
+                        for (int j = 0; j < N; j++) g.golden[(size_t)g.indices[p2] * N + j] += g.B[(size_t)i * N + j];
+                compare("atomic-baseline");
+            }
+            printf("validate done (%d variants, N=%d)\n", checked, N);
         }
-        printf("validate done (%d variants, N=%d)\n", GESPMM_NUM_VARIANTS, N);
     }
-    if (cpu_baseline) printf("cpu golden loop: %f GFLOP/s (1 thread, N=%d)\n", cpu_gflops, max_ncols);
 
     CHECK_HIP(hipEventCreate(&g.start));
     CHECK_HIP(hipEventCreate(&g.stop));
@@ -414,6 +443,22 @@ int main(int argc, char** argv) {
         if (g.fpo) fprintf(g.fpo, "%f,", gflop / (rt / iters));
         printf("N=%d method=%d: %f ms/iter, %f GFLOP/s (rocsparse %f GFLOP/s)\n", N, method, rt / iters,
                gflop / (rt / iters), vendor_gflops);
+        if (atomic_baseline) {
+            // out = A^T * B[0:M] by one atomicAdd per edge and feature; reuses C_dev when it is large enough (M == K)
+            float* out_dev = g.C_dev;
+            if (K != M) CHECK_HIP(hipMalloc((void**)&out_dev, (size_t)K * N * sizeof(float)));
+            const int ait = iters < 20 ? iters : 20;
+            CHECK_GE(gespmm_baseline_atomic_scatter_f32(g.indptr_dev, g.indices_dev, g.B_dev, out_dev, M, K, N, nnz, nullptr));
+            CHECK_HIP(hipEventRecord(g.start, 0));
+            for (int i = 0; i < ait; i++)
+                CHECK_GE(gespmm_baseline_atomic_scatter_f32(g.indptr_dev, g.indices_dev, g.B_dev, out_dev, M, K, N, nnz,
+                                                            nullptr));
+            CHECK_HIP(hipEventRecord(g.stop, 0));
+            CHECK_HIP(hipEventSynchronize(g.stop));
+            CHECK_HIP(hipEventElapsedTime(&rt, g.start, g.stop));
+            printf("N=%d atomic-baseline: %f ms/iter, %f GFLOP/s\n", N, rt / ait, gflop / (rt / ait));
+            if (K != M) CHECK_HIP(hipFree(out_dev));
+        }
     }
 
     g.release();

@@ -11,6 +11,7 @@ Synthetic side (torch, runs on whatever device the generator is given — the bi
 graphs are built on the GPU). Every generator is a pure function of (name, seed):
     synthetic_graph("com-amazon-like" | "cit-hepth-like" | "reddit-like" |
                     "products-like" | "pubmed-selfloop-like", ...)
+    synthetic_graph("com-amazon-sbm" | "products-sbm", ...)   planted communities, vertex ids SHUFFLED
 Node ids carry NO locality by default (ids are scrambled by an affine bijection):
 the reference's own spreadsheet numbers for com-Amazon/pubmed are consistent with
 every B-row gather missing a 2.75 MB L2 (DESIGN.md "Synthetic graphs"), so the
@@ -190,9 +191,127 @@ def synthetic_csr(M, nnz, symmetric=True, gamma=1.5, seed=42, device="cpu", loca
     return rowptr.to(torch.int32), c.to(torch.int32)
 
 
+
+def community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share=0.6, size_skew=1.5, gamma=1.55, seed=42,
+                  device="cpu", shuffle=True):
+    """Symmetric graph with EXACTLY ``nnz`` stored entries and PLANTED two-level community structure whose
+    vertex ids are then shuffled by a seeded random permutation — so any locality has to be found by the
+    consumer (row clustering), it is not inherited from the generator.
+
+      level 1   ``n_comm`` communities with skewed sizes (size of community c ~ c^(1/size_skew - 1), largest a few
+                hundred vertices at com-Amazon's size, smallest 2-3): every pair inside a community of s vertices is
+                an edge with probability min(1, intra_deg / (s - 1)) — small communities are near-cliques, which is
+                what gives co-purchase networks their high clustering coefficient;
+      level 2   communities are dealt at random to ``n_groups`` groups of ~M / n_groups vertices; of the remaining
+                edges a share ``group_share`` joins a popularity-drawn vertex to a uniformly drawn member of its
+                own group;
+      global    the rest joins two popularity-drawn vertices anywhere (power-law-ish tail, exponent ``gamma``,
+                as in synthetic_csr).
+
+    Returns (rowptr int32[M+1], colind int32[nnz], planted int64[M]) — ``planted[v]`` orders the vertices by
+    (group, community), i.e. argsort(planted) is the order a perfect community detector would produce.
+    """
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    if nnz % 2:
+        raise ValueError("symmetric graphs need an even nnz")
+    target = nnz // 2
+    u = torch.rand(M, generator=gen, device=device, dtype=torch.float64)
+    c1 = torch.clamp((u.pow(size_skew) * n_comm).to(torch.int64), max=n_comm - 1)
+    c1, _ = torch.sort(c1)
+    _, c1 = torch.unique(c1, return_inverse=True)  # compact labels, still ascending with the planted id
+    nc1 = int(c1.max()) + 1
+    size1 = torch.bincount(c1, minlength=nc1)
+    off1 = torch.zeros(nc1 + 1, dtype=torch.int64, device=device)
+    off1[1:] = torch.cumsum(size1, 0)
+    ids = torch.arange(M, device=device)
+    # level 1: every pair (i < j) of a community, kept with probability q(s)
+    pos = ids - off1[c1]
+    s_of = size1[c1]
+    cnt = s_of - 1 - pos
+    src = torch.repeat_interleave(ids, cnt)
+    start = torch.cumsum(cnt, 0) - cnt
+    dst = src + 1 + (torch.arange(src.numel(), device=device) - torch.repeat_interleave(start, cnt))
+    q = torch.clamp(float(intra_deg) / torch.clamp(s_of[src] - 1, min=1).to(torch.float64), max=1.0)
+    keep = torch.rand(src.numel(), generator=gen, device=device, dtype=torch.float64) < q
+    keys = torch.unique(src[keep] * M + dst[keep])
+    del src, dst, keep, q, start
+    if keys.numel() > target:
+        raise ValueError("intra-community edges alone exceed nnz/2: lower intra_deg")
+    # level 2: communities dealt to groups at random
+    perm_c = torch.randperm(nc1, generator=gen, device=device)
+    cum = torch.cumsum(size1[perm_c], 0)
+    g_of_c = torch.empty(nc1, dtype=torch.int64, device=device)
+    g_of_c[perm_c] = torch.clamp((cum - 1) * n_groups // M, max=n_groups - 1)
+    c2 = g_of_c[c1]
+    members2 = torch.argsort(c2, stable=True)
+    off2 = torch.zeros(n_groups + 1, dtype=torch.int64, device=device)
+    off2[1:] = torch.cumsum(torch.bincount(c2, minlength=n_groups), 0)
+    want = target - keys.numel()
+    rounds = 0
+    while want > 0:
+        rounds += 1
+        n = int(want * 1.2) + 1024
+        a = _scramble(_endpoints(n, M, gamma, gen, device), M, seed)
+        t = torch.rand(n, generator=gen, device=device)
+        r = torch.rand(n, generator=gen, device=device, dtype=torch.float64)
+        ga = c2[a]
+        v_group = members2[off2[ga] + (r * (off2[ga + 1] - off2[ga]).to(torch.float64)).to(torch.int64)]
+        v_glob = _scramble(torch.clamp((r.pow(gamma) * M).to(torch.int64), max=M - 1), M, seed)
+        b = torch.where(t < group_share, v_group, v_glob)
+        lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+        k = torch.unique((lo * M + hi)[lo != hi])
+        k = k[~torch.isin(k, keys)]
+        if k.numel() > want:
+            k = k[torch.randperm(k.numel(), generator=gen, device=device)[:want]]
+        keys = torch.cat([keys, k])
+        want = target - keys.numel()
+        if rounds > 64:
+            raise RuntimeError("community_csr did not converge")
+    r = keys // M
+    c = keys % M
+    planted = c2 * nc1 + c1
+    if shuffle:
+        P = torch.randperm(M, generator=gen, device=device)
+        r, c = P[r], P[c]
+        pl = torch.empty_like(planted)
+        pl[P] = planted
+        planted = pl
+    r, c = torch.cat([r, c]), torch.cat([c, r])
+    order = torch.argsort(r * M + c)
+    r, c = r[order], c[order]
+    rowptr = torch.zeros(M + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=M), 0)
+    return rowptr.to(torch.int32), c.to(torch.int32), planted
+
+
+# Structured stand-ins (same M and nnz as the structureless ones above). com-Amazon: SNAP lists 334 863 nodes,
+# 925 872 edges, 75 149 ground-truth communities, average clustering coefficient 0.3967; ogbn-products (also an
+# Amazon co-purchase graph): 2 449 029 nodes, 61 859 140 edges, average clustering coefficient 0.411 (OGB).
+# (n_comm, n_groups, intra_deg, group_share) are set so that the generated graph reproduces the clustering
+# coefficient (measured: scripts/reorder_study.py --stats); the group level is an assumption (product categories).
+COMMUNITY_SPECS = {
+    "com-amazon-sbm": ("com-amazon-like", 75149, 1024, 5.0, 0.6),
+    "products-sbm": ("products-like", 51000, 2048, 34.0, 0.6),
+}
+
 def synthetic_graph(name, seed=42, device="cpu", locality=0.0, band=2000, scale=1.0):
     """One of the named stand-ins. ``scale`` < 1 shrinks M and nnz
     proportionally (CPU-sized tests); scale == 1 reproduces the exact M / nnz."""
+    if name in COMMUNITY_SPECS:
+        base, n_comm, n_groups, intra_deg, group_share = COMMUNITY_SPECS[name]
+        M, nnz, _, gamma = SPECS[base]
+        if scale != 1.0:
+            M = max(int(M * scale), 64)
+            nnz = max(int(nnz * scale), 64)
+            nnz -= nnz % 2
+            n_comm = max(int(n_comm * scale), 4)
+            n_groups = max(int(n_groups * scale), 2)
+        rowptr, colind, planted = community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share, 1.5, gamma, seed,
+                                                device)
+        return {"name": name, "M": M, "K": M, "nnz": int(colind.numel()), "rowptr": rowptr, "colind": colind,
+                "truth": planted}
     if name == "pubmed-selfloop-like":
         M, nnz, sym, gamma = SPECS["pubmed-like"]
     else:

@@ -22,6 +22,7 @@
  *   gespmm_mtx_read[_cached] / _free  <- readMtx<float>()     util/util.hpp:286-333 (+ mmio.hpp:215,308)
  *   gespmm_coo_to_csr        <- inline COO->CSR               spmm_test.cu:557-581
  *   gespmm_row_partition     <- (new; north_star multi-GPU)   no reference counterpart
+ *   gespmm_baseline_atomic_scatter_f32 <- Gunrock app's edge map  gunrock-test/app/spmm/spmm_enactor.cuh:92-105
  *
  * Conventions (all device entry points):
  *   - every pointer is a DEVICE pointer owned by the caller, except where a
@@ -226,6 +227,16 @@ int gespmm_csr2csc_f32(const int32_t* rowptr, const int32_t* colind, const float
                        int32_t* colptr, int32_t* rowind, float* csc_val,
                        int64_t M, int64_t K, int64_t nnz,
                        void* workspace, void* stream);
+
+/*
+ * Comparison column, not a product path: the Gunrock app's edge map
+ * (gunrock-test/app/spmm/spmm_enactor.cuh:92-105) — for every edge (src -> dest) of the CSR pattern
+ * and every feature j, atomicAdd(out + dest*N + j, in[src*N + j]): out[K x N] = A^T * in with A == 1,
+ * `out` zeroed by the call. `in` is M x N. The order of the additions is not fixed (atomics), so
+ * results are tolerance-checked. spmm_test --atomic-baseline times it next to the row-product kernels.
+ */
+int gespmm_baseline_atomic_scatter_f32(const int32_t* rowptr, const int32_t* colind, const float* in, float* out,
+                                       int64_t M, int64_t K, int64_t N, int64_t nnz, void* stream);
 
 /* ------------------------------------------------------------------ host side */
 

@@ -44,10 +44,23 @@ def test_validate_all_variants_and_flags(tmp_path):
                         str(tmp_path / "o.csv")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "WA" not in r.stdout, r.stdout
-    assert "validate done (6 variants, N=512)" in r.stdout
-    assert re.search(r"cpu golden loop: [0-9.]+ GFLOP/s", r.stdout)
+    # --validate honours --ncols (and adds the library's pick when --method is -1)
+    assert "validate done (7 variants, N=32)" in r.stdout and "validate done (7 variants, N=100)" in r.stdout
+    assert re.search(r"cpu golden loop: [0-9.]+ GFLOP/s \(1 thread, N=32\)", r.stdout)
+    assert re.search(r"cpu golden loop: [0-9.]+ GFLOP/s \(1 thread, N=100\)", r.stdout)
     assert re.search(r"N=32 method=-1", r.stdout) and re.search(r"N=100 method=-1", r.stdout)
     assert len((tmp_path / "o.csv").read_text().rstrip(",").split(",")) == 4
+
+
+def test_validate_defaults_follow_the_reference(tmp_path):
+    """No --ncols: validation runs once at N = max_ncols = 512 with methods 0..5, as spmm_test.cu:671-698 does."""
+    r = subprocess.run([DRIVER, os.path.join(GOLDEN, "cora.mtx"), "--validate", "--atomic-baseline", "--iters", "3",
+                        "--seed", "3", "--out", str(tmp_path / "o.csv")], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "WA" not in r.stdout, r.stdout
+    assert "validate done (6 variants, N=512)" in r.stdout
+    assert len(re.findall(r"atomic-baseline: [0-9.]+ ms/iter", r.stdout)) == 3  # N = 128, 256, 512
 
 
 def test_error_exits(tmp_path):
