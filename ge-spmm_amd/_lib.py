@@ -56,12 +56,29 @@ EXPORTS = [
     "gespmm_coo_to_csr",
     "gespmm_row_partition",
     "gespmm_baseline_atomic_scatter_f32",
+    "gespmm_plan_create",
+    "gespmm_plan_spmm_f32",
+    "gespmm_plan_spmm_max_f32",
+    "gespmm_plan_set_values",
+    "gespmm_plan_get_order",
+    "gespmm_plan_describe",
+    "gespmm_plan_destroy",
+    "gespmm_cluster_rows",
+    "gespmm_simulate_l2_hits",
 ]
+
+PLAN_REORDER_AUTO = 0
+PLAN_REORDER = 1
+PLAN_NO_REORDER = 2
 
 
 class LaunchCfg(Structure):
     _fields_ = [("vec", c_int32), ("strips", c_int32), ("group", c_int32), ("rows_per_wave", c_int32),
                 ("slab_rows", c_int32), ("flags", c_int32)]
+
+
+class PlanOptions(Structure):
+    _fields_ = [("reorder", c_int32), ("task_entries", c_int32), ("threads", c_int32), ("flags", c_int32)]
 
 
 class Coo(Structure):
@@ -123,6 +140,25 @@ def _load():
     lib.gespmm_coo_to_csr.argtypes = [c_int32, c_int32, c_int64, p, p, p, p, p, p]
     lib.gespmm_baseline_atomic_scatter_f32.restype = c_int
     lib.gespmm_baseline_atomic_scatter_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, p]
+    lib.gespmm_plan_create.restype = c_int
+    lib.gespmm_plan_create.argtypes = [POINTER(c_void_p), p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                       POINTER(PlanOptions), p]
+    lib.gespmm_plan_spmm_f32.restype = c_int
+    lib.gespmm_plan_spmm_f32.argtypes = [p, p, p, c_int64, p]
+    lib.gespmm_plan_spmm_max_f32.restype = c_int
+    lib.gespmm_plan_spmm_max_f32.argtypes = [p, p, p, c_int64, c_float, p]
+    lib.gespmm_plan_set_values.restype = c_int
+    lib.gespmm_plan_set_values.argtypes = [p, p, p]
+    lib.gespmm_plan_get_order.restype = c_int
+    lib.gespmm_plan_get_order.argtypes = [p, p]
+    lib.gespmm_plan_describe.restype = c_int
+    lib.gespmm_plan_describe.argtypes = [p, c_char_p, c_int64]
+    lib.gespmm_plan_destroy.restype = None
+    lib.gespmm_plan_destroy.argtypes = [p]
+    lib.gespmm_cluster_rows.restype = c_int
+    lib.gespmm_cluster_rows.argtypes = [p, p, c_int64, c_int64, c_int32, p, p, p]
+    lib.gespmm_simulate_l2_hits.restype = ctypes.c_double
+    lib.gespmm_simulate_l2_hits.argtypes = [p, p, c_int64, c_int64, p, c_int32, c_int64]
     lib.gespmm_row_partition.restype = c_int
     lib.gespmm_row_partition.argtypes = [p, c_int64, c_int32, p]
     return lib

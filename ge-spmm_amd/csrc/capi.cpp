@@ -13,6 +13,7 @@
 
 #include "../../include/gespmm.h"
 #include "select.h"
+#include "plan.h"
 #include "spmm_kernels.h"
 
 namespace {
@@ -37,9 +38,14 @@ int check_common(const int32_t* rowptr, const int32_t* colind, const float* val,
     return 0;
 }
 
+}  // namespace
+
+namespace gespmm {
+
+// The one place every SpMM entry point ends up in (plan.cpp included: `pl` carries the plan's task table).
 int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
              int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
-             void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
+             void* stream, void* ws, int64_t ws_bytes, const PlanLaunch* pl) {
     const int rc = check_common(rowptr, colind, val, B, C, M, K, N, nnz);
     if (rc != 0) return rc;
     if (M == 0 || N == 0) return 0;
@@ -76,11 +82,16 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
             (void)hipGetLastError();
         }
     }
+    if (pl) {  // task tables exist for the batch-stream kernel only
+        flags |= gespmm::kFlagBatchStream | gespmm::kFlagNoSlabBlocked;
+        flags &= ~(gespmm::kFlagSlabBlocked | gespmm::kFlagSegStream);
+    }
     const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
                                              cfg ? cfg->strips : 0, cfg ? cfg->group : 0,
                                              cfg ? cfg->rows_per_wave : 0, cfg ? cfg->slab_rows : 0, flags, &sel);
     if (src != 0) return src;
     sel.geo.reduce = reduce;
+    if (pl && (sel.variant == GESPMM_VARIANT_NAIVE || sel.variant == GESPMM_VARIANT_PARREDUCE)) return GESPMM_EINVAL;
 
     SpmmArgs a;
     a.rowptr = rowptr;
@@ -102,6 +113,9 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.row_begin = nullptr;
     a.row_end = nullptr;
     a.accumulate = 0;
+    a.tasks = pl ? pl->tasks : nullptr;
+    a.perm = pl ? pl->perm : nullptr;
+    a.ntasks = pl ? pl->ntasks : 0;
 
     hipError_t e;
     a.rpw = sel.geo.rows_per_group;
@@ -130,6 +144,15 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     return (int)e;
 }
 
+}  // namespace gespmm
+
+namespace {
+int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
+             int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
+             void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
+    return gespmm::run_spmm(rowptr, colind, val, B, C, M, K, N, nnz, variant, cfg, reduce, empty, stream, ws, ws_bytes,
+                            nullptr);
+}
 }  // namespace
 
 extern "C" {

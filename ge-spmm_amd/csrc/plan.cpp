@@ -1,0 +1,401 @@
+// plan.cpp — gespmm_plan: the "analysis" stage in front of repeated SpMM calls on ONE sparse matrix.
+//
+// The reference launches its kernels straight on the caller's CSR (spmmWrapper, spmm_test.cu:456-492;
+// spmm_cuda, pytorch-custom/spmm_kernel.cu:425-458) and has no such stage; vendor libraries do
+// (rocsparse_spmm_stage_preprocess). A plan looks at the matrix ONCE — on the host, one synchronisation —
+// and keeps what every later launch can reuse:
+//
+//   * the longest row (decides the long-row pass exactly instead of guessing from nnz and the mean degree);
+//   * for dense graphs: the workspace with the per-row split points of the cache-blocked path;
+//   * for sparse graphs whose B exceeds the L2s: a ROW-CLUSTERED copy of the matrix (reorder.cpp) and a task
+//     table with an equal non-zero budget per wavefront. Rows that share neighbours are processed next to
+//     each other, so the B rows they share are gathered from the XCD's L2 instead of crossing the fabric
+//     again. Only the processing order changes: every row is still summed by one lane group in its own CSR
+//     order and written to its own C row (through perm[]), so the result has the same bits as the plain call.
+//
+// The plan owns its device memory (permuted rowptr / colind / val, perm, tasks, workspace) and refers to the
+// caller's arrays only while it is created (and in gespmm_plan_set_values).
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/gespmm.h"
+#include "plan.h"
+#include "reorder.h"
+#include "select.h"
+#include "spmm_kernels.h"
+
+struct gespmm_plan {
+    int64_t M = 0, K = 0, nnz = 0, N = 0;
+    int variant = GESPMM_VARIANT_AUTO;
+    int launch_flags = 0;
+    int device = 0;
+    const int32_t* rowptr = nullptr;  // caller's arrays (used only when the plan keeps the storage order)
+    const int32_t* colind = nullptr;
+    const float* val = nullptr;
+    bool valued = false;
+    int32_t max_degree = 0;
+    bool reordered = false;
+    int32_t* d_rowptr = nullptr;
+    int32_t* d_colind = nullptr;
+    float* d_val = nullptr;
+    int32_t* d_perm = nullptr;
+    int32_t* d_src_begin = nullptr;
+    int32_t* d_tasks = nullptr;
+    int32_t ntasks = 0;
+    int32_t task_entries = 0;
+    std::vector<int32_t> perm_host;
+    void* ws = nullptr;
+    int64_t ws_bytes = 0;
+    bool split_ready = false;
+    gespmm::ClusterStats stats;
+    double analysis_seconds = 0.0, cluster_seconds = 0.0;
+    double hits_before = -1.0, hits_after = -1.0;
+};
+
+namespace {
+
+__global__ void permute_values_kernel(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ src_begin,
+                                      const float* __restrict__ val, float* __restrict__ val_p, int M, int nnz) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int lo = 0, hi = M;  // rowptr_p[lo] <= p < rowptr_p[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr_p[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    val_p[p] = val[src_begin[lo] + (p - rowptr_p[lo])];
+}
+
+void free_device(gespmm_plan* p) {
+    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = nullptr;
+    p->d_val = nullptr;
+    p->ws = nullptr;
+}
+
+template <typename T>
+hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), bytes);
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    return e;
+}
+
+// Non-zeros per wavefront task. Storage-order launches take ~12 KB of gathered B per task (select.cpp);
+// with clustered rows part of the gathers hit L2 and the per-task prologue weighs more: twice that
+// (profiles/r02/plan_task_size.log).
+int default_task_entries(int64_t N) {
+    const int64_t row_bytes = 4 * (N < 256 ? N : 256);
+    int64_t t = (24 << 10) / (row_bytes > 0 ? row_bytes : 4);
+    if (t < 32) t = 32;
+    if (t > 192) t = 192;
+    return (int)t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int32_t threads,
+                        int32_t* perm_out, int32_t* levels_out, int32_t* clusters_out /* [16] */) {
+    if (M < 0 || K < 0 || (M > 0 && (!rowptr || !perm_out))) return GESPMM_EINVAL;
+    gespmm::ClusterOptions opt;
+    opt.threads = threads;
+    gespmm::ClusterStats st;
+    try {
+        if (gespmm::cluster_rows(M, K, rowptr, colind, opt, perm_out, &st) != 0) return GESPMM_EINVAL;
+    } catch (const std::bad_alloc&) {
+        return GESPMM_ENOMEM;
+    }
+    if (levels_out) *levels_out = st.levels;
+    if (clusters_out)
+        for (int i = 0; i < 16; ++i) clusters_out[i] = st.clusters[i];
+    return 0;
+}
+
+double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
+                               int32_t slices, int64_t window_rows) {
+    if (M <= 0 || K <= 0 || !rowptr || slices < 1 || window_rows < 1) return 0.0;
+    try {
+        return gespmm::simulate_l2_hits(M, K, rowptr, colind, perm, slices, window_rows);
+    } catch (const std::bad_alloc&) {
+        return -1.0;
+    }
+}
+
+int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
+                       int64_t K, int64_t nnz, int64_t N, int variant, const gespmm_plan_options* opt, void* stream) {
+    if (!out) return GESPMM_EINVAL;
+    *out = nullptr;
+    if (M < 0 || K < 0 || N < 0 || nnz < 0) return GESPMM_EINVAL;
+    if (M > 0x7fffffffLL - 64 || K > 0x7fffffffLL || N > 0x7fffffffLL / 4 || nnz > 0x7fffffffLL - 4096) return GESPMM_ERANGE;
+    if (variant < GESPMM_VARIANT_AUTO || variant >= GESPMM_NUM_VARIANTS) return GESPMM_EINVAL;
+    if (M > 0 && !rowptr) return GESPMM_EINVAL;
+    if (nnz > 0 && !colind) return GESPMM_EINVAL;
+    const int reorder_mode = opt ? opt->reorder : GESPMM_PLAN_REORDER_AUTO;
+    if (reorder_mode < 0 || reorder_mode > 2) return GESPMM_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const auto t_start = std::chrono::steady_clock::now();
+
+    gespmm_plan* p = new (std::nothrow) gespmm_plan;
+    if (!p) return GESPMM_ENOMEM;
+    p->M = M;
+    p->K = K;
+    p->nnz = nnz;
+    p->N = N;
+    p->variant = variant;
+    p->rowptr = rowptr;
+    p->colind = colind;
+    p->val = val;
+    p->valued = val != nullptr;
+    hipError_t e = hipGetDevice(&p->device);
+    if (e != hipSuccess) {
+        delete p;
+        return (int)e;
+    }
+    int user_flags = opt ? opt->flags : 0;
+
+    try {
+        // ---- the matrix comes to the host once
+        std::vector<int32_t> h_rowptr((size_t)M + 1, 0), h_colind((size_t)nnz);
+        if (M > 0) e = hipMemcpyAsync(h_rowptr.data(), rowptr, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(h_colind.data(), colind, (size_t)nnz * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            delete p;
+            return (int)e;
+        }
+        if (M > 0 && (h_rowptr[0] != 0 || h_rowptr[M] != nnz)) {
+            delete p;
+            return GESPMM_EINVAL;  // rowptr does not describe nnz entries
+        }
+        int32_t max_deg = 0;
+        for (int64_t r = 0; r < M; ++r) {
+            const int32_t d = h_rowptr[r + 1] - h_rowptr[r];
+            if (d < 0) {
+                delete p;
+                return GESPMM_EINVAL;
+            }
+            if (d > max_deg) max_deg = d;
+        }
+        p->max_degree = max_deg;
+        // long-row pass: decided by the longest row (the plain entry points have to guess)
+        const int64_t mean = (M > 0) ? (nnz + M - 1) / M : 0;
+        int64_t threshold = 32 * mean;
+        if (threshold < gespmm::kLongRowThreshold) threshold = gespmm::kLongRowThreshold;
+        if (!(user_flags & (GESPMM_FLAG_STRICT_ORDER | GESPMM_FLAG_SPLIT_LONG_ROWS)))
+            user_flags |= (max_deg > threshold) ? GESPMM_FLAG_SPLIT_LONG_ROWS : GESPMM_FLAG_STRICT_ORDER;
+        p->launch_flags = user_flags;
+
+        // ---- what would a plain call launch? (the cache-blocked path keeps the storage order)
+        gespmm::Selection sel;
+        int max_vec = 4;
+        while (max_vec > 1 && (N % max_vec) != 0) max_vec >>= 1;
+        if (gespmm::resolve_geometry(M, K, N > 0 ? N : 1, nnz, variant, max_vec, 0, 0, 0, 0, 0, user_flags, &sel) != 0) {
+            delete p;
+            return GESPMM_EINVAL;
+        }
+        const bool stream_family = sel.variant >= GESPMM_VARIANT_CRC && sel.variant <= GESPMM_VARIANT_CRC_CWM8 &&
+                                   !sel.geo.slab_blocked;
+        const int64_t tile_cols = (int64_t)sel.geo.group * sel.geo.vec * sel.geo.strips;
+        const int64_t b_bytes = K * 4 * (N < tile_cols ? N : tile_cols);
+        bool reorder = false;
+        if (reorder_mode == GESPMM_PLAN_REORDER) reorder = stream_family && M > 1 && nnz > 0;
+        else if (reorder_mode == GESPMM_PLAN_REORDER_AUTO)
+            // B beyond the L2s (below that every order hits), enough rows to cluster, not so many entries that
+            // the host analysis takes minutes
+            reorder = stream_family && M >= (1 << 14) && nnz >= M && b_bytes > (8ll << 20) && mean <= 96 &&
+                      nnz <= (1ll << 28);
+
+        if (reorder) {
+            const auto tc = std::chrono::steady_clock::now();
+            p->perm_host.resize((size_t)M);
+            gespmm::ClusterOptions copt;
+            copt.threads = opt ? opt->threads : 0;
+            if (gespmm::cluster_rows(M, K, h_rowptr.data(), h_colind.data(), copt, p->perm_host.data(), &p->stats) != 0) {
+                delete p;
+                return GESPMM_EINVAL;
+            }
+            p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+            // A model of the XCD L2s says whether the new order is worth having (graphs whose storage order is
+            // already local, or that have no structure to find, keep their order and pay nothing per launch).
+            if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && nnz <= (1ll << 25)) {
+                const int64_t window = (3ll << 20) / (4 * (N < tile_cols ? N : tile_cols) > 0 ? 4 * (N < tile_cols ? N : tile_cols) : 4);
+                p->hits_before = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), nullptr, 8, window);
+                p->hits_after = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), p->perm_host.data(), 8, window);
+                if (p->hits_after < p->hits_before + 0.03) reorder = false;
+            }
+        }
+        if (reorder) {
+            // ---- row-permuted copy + task table
+            std::vector<int32_t> rp((size_t)M + 1), ci((size_t)nnz), src((size_t)M);
+            rp[0] = 0;
+            for (int64_t i = 0; i < M; ++i) {
+                const int32_t r = p->perm_host[i];
+                const int32_t b = h_rowptr[r], d = h_rowptr[r + 1] - b;
+                src[i] = b;
+                std::memcpy(ci.data() + rp[i], h_colind.data() + b, (size_t)d * 4);
+                rp[i + 1] = rp[i] + d;
+            }
+            const int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
+            p->task_entries = budget;
+            std::vector<int32_t> tasks;
+            tasks.reserve((size_t)(nnz / budget + M / gespmm::kMaxRowsPerWave + 16) * 4);
+            int64_t i = 0;
+            while (i < M) {
+                const int64_t first = i;
+                int64_t acc = rp[i + 1] - rp[i];
+                ++i;
+                while (i < M && i - first < gespmm::kMaxRowsPerWave && acc + (rp[i + 1] - rp[i]) <= budget) {
+                    acc += rp[i + 1] - rp[i];
+                    ++i;
+                }
+                tasks.push_back((int32_t)first);
+                tasks.push_back((int32_t)(i - first));
+                tasks.push_back(rp[first]);
+                tasks.push_back(rp[i]);
+            }
+            p->ntasks = (int32_t)(tasks.size() / 4);
+            e = upload(&p->d_rowptr, rp, st);
+            if (e == hipSuccess) e = upload(&p->d_colind, ci, st);
+            if (e == hipSuccess) e = upload(&p->d_perm, p->perm_host, st);
+            if (e == hipSuccess) e = upload(&p->d_src_begin, src, st);
+            if (e == hipSuccess) e = upload(&p->d_tasks, tasks, st);
+            if (e == hipSuccess && p->valued) e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(nnz > 0 ? nnz : 1) * 4);
+            if (e == hipSuccess && p->valued && nnz > 0) {
+                hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
+                                   p->d_src_begin, val, p->d_val, (int)M, (int)nnz);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors go out of scope
+            if (e != hipSuccess) {
+                free_device(p);
+                delete p;
+                return (int)e;
+            }
+            p->reordered = true;
+        } else {
+            p->perm_host.clear();
+        }
+        // ---- scratch of the launches (split points / long-row partials), owned by the plan
+        gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags};
+        const int64_t need = gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, variant, &cfg);
+        if (need > 0) {
+            e = hipMalloc(&p->ws, (size_t)need);
+            if (e != hipSuccess) {
+                free_device(p);
+                delete p;
+                return (int)e;
+            }
+            p->ws_bytes = need;
+        }
+    } catch (const std::bad_alloc&) {
+        free_device(p);
+        delete p;
+        return GESPMM_ENOMEM;
+    }
+    p->analysis_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    *out = p;
+    return 0;
+}
+
+static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream) {
+    if (!p || N < 0) return GESPMM_EINVAL;
+    if (reduce == gespmm::kReduceMax && p->valued) return GESPMM_EINVAL;
+    gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags};
+    void* ws = (N == p->N) ? p->ws : nullptr;  // another width: the library's pool serves the scratch
+    const int64_t ws_bytes = (N == p->N) ? p->ws_bytes : 0;
+    if (ws && p->split_ready) cfg.flags |= GESPMM_FLAG_REUSE_SPLIT;
+    int rc;
+    if (p->reordered) {
+        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm};
+        rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
+                              p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
+    } else {
+        rc = gespmm::run_spmm(p->rowptr, p->colind, p->valued ? p->val : nullptr, B, C, p->M, p->K, N, p->nnz, p->variant,
+                              &cfg, reduce, empty, stream, ws, ws_bytes, nullptr);
+    }
+    if (rc == 0 && ws) p->split_ready = true;
+    return rc;
+}
+
+int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, void* stream) {
+    return plan_run(plan, B, C, N, gespmm::kReduceSum, 0.0f, stream);
+}
+
+int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, float empty_value, void* stream) {
+    return plan_run(plan, B, C, N, gespmm::kReduceMax, empty_value, stream);
+}
+
+int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
+    if (!p) return GESPMM_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!p->reordered) {
+        p->val = val;
+        p->valued = val != nullptr;
+        return 0;
+    }
+    if (!val) {
+        p->valued = false;
+        return 0;
+    }
+    if (!p->d_val) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(p->nnz > 0 ? p->nnz : 1) * 4);
+        if (e != hipSuccess) return (int)e;
+    }
+    p->valued = true;
+    if (p->nnz == 0) return 0;
+    hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
+                       p->d_src_begin, val, p->d_val, (int)p->M, (int)p->nnz);
+    return (int)hipGetLastError();
+}
+
+int gespmm_plan_get_order(const gespmm_plan* p, int32_t* perm_host) {
+    if (!p || (p->M > 0 && !perm_host)) return GESPMM_EINVAL;
+    if (p->reordered) std::memcpy(perm_host, p->perm_host.data(), (size_t)p->M * 4);
+    else
+        for (int64_t i = 0; i < p->M; ++i) perm_host[i] = (int32_t)i;
+    return p->reordered ? 1 : 0;
+}
+
+int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
+    if (!p || !out || capacity <= 0) return GESPMM_EINVAL;
+    char what[256] = "";
+    gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags | (p->reordered ? (GESPMM_FLAG_BATCH_STREAM | GESPMM_FLAG_NO_SLAB_BLOCKED) : 0)};
+    gespmm_describe_launch(p->M, p->K, p->N, p->nnz, p->variant, &cfg, what, sizeof what);
+    int n;
+    if (p->reordered) {
+        char lv[128] = "";
+        int off = 0;
+        for (int i = 0; i < p->stats.levels && i < 16 && off < 100; ++i)
+            off += snprintf(lv + off, sizeof lv - (size_t)off, "%s%d", i ? ">" : "", p->stats.clusters[i]);
+        n = snprintf(out, (size_t)capacity,
+                     "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d max_degree=%d l2_model=%.3f->%.3f "
+                     "analysis=%.3fs (clustering %.3fs) | %s",
+                     p->stats.levels, lv, p->ntasks, p->task_entries, p->max_degree, p->hits_before, p->hits_after,
+                     p->analysis_seconds, p->cluster_seconds, what);
+    } else {
+        n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.3fs | %s",
+                     p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, what);
+    }
+    if (n < 0) return GESPMM_EINVAL;
+    return n < capacity ? n : (int)capacity - 1;
+}
+
+void gespmm_plan_destroy(gespmm_plan* p) {
+    if (!p) return;
+    free_device(p);
+    delete p;
+}
+
+}  // extern "C"

@@ -1,0 +1,19 @@
+// plan.h — internal interface between the C ABI (capi.cpp) and the plan object (plan.cpp).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/gespmm.h"
+
+namespace gespmm {
+
+struct PlanLaunch {
+    const int32_t* tasks;  // int4 per task (device)
+    int32_t ntasks;
+    const int32_t* perm;   // permuted row -> original row (device)
+};
+
+int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
+             int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
+             void* stream, void* ws, int64_t ws_bytes, const PlanLaunch* pl);
+
+}  // namespace gespmm

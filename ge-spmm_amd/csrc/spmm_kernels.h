@@ -55,6 +55,12 @@ struct SpmmArgs {
     int32_t* lr_chunks;  // int2 per chunk: {row, chunk index}
     int32_t lr_chunk, lr_max_rows, lr_max_chunks;
     float empty;    // max reducer: value of rows without non-zeros / initial accumulator
+    // plan mode (plan.cpp): rowptr/colind/val are the plan's row-permuted copy of the matrix, wavefront w works on
+    // task w = int4 {first permuted row, #rows (<= kMaxRowsPerWave), CSR begin, CSR end}, and row i of the
+    // permuted matrix is written to C row perm[i]
+    const int32_t* tasks;
+    const int32_t* perm;
+    int32_t ntasks;
 };
 
 // Launch geometry resolved by the host-side selector (select.cpp).

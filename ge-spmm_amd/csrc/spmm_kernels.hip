@@ -248,6 +248,7 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
     __shared__ off_t s_off[kWaves][kTile];
     __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? kTile : 1];
     __shared__ int s_ptr[kWaves][kMaxRowsPerWave + 1];
+    __shared__ int s_perm[kWaves][kMaxRowsPerWave];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -261,16 +262,32 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         tile = item % a.ntile;
         rb = item / a.ntile;
     }
-    const int rpw = a.rpw;
-    const int row_first = (rb * kWaves + wave) * rpw;
-    if (row_first >= a.M) return;  // whole wavefront leaves together
-    const int nrows = (a.M - row_first < rpw) ? a.M - row_first : rpw;  // wave-uniform
-
-    // Row pointers of this wavefront's rows -> LDS (one coalesced load, rpw <= 32).
-    const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
-    if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
-    const int wb = __builtin_amdgcn_readfirstlane(rp);
-    const int we = __builtin_amdgcn_readlane(rp, nrows);
+    int row_first, nrows, wb, we;  // wave-uniform
+    const bool planned = a.tasks != nullptr;
+    if (planned) {
+        // Plan mode: the task table names the rows and the CSR range, so the first CSR tile, the row
+        // pointers and the C-row indices are three independent loads instead of a dependent chain.
+        const int wid = rb * kWaves + wave;
+        if (wid >= a.ntasks) return;
+        const int4 t = reinterpret_cast<const int4*>(a.tasks)[wid];
+        row_first = __builtin_amdgcn_readfirstlane(t.x);
+        nrows = __builtin_amdgcn_readfirstlane(t.y);
+        wb = __builtin_amdgcn_readfirstlane(t.z);
+        we = __builtin_amdgcn_readfirstlane(t.w);
+        const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
+        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
+        if (lane < kMaxRowsPerWave) s_perm[wave][lane] = a.perm[row_first + (lane < nrows ? lane : nrows - 1)];
+    } else {
+        const int rpw = a.rpw;
+        row_first = (rb * kWaves + wave) * rpw;
+        if (row_first >= a.M) return;  // whole wavefront leaves together
+        nrows = (a.M - row_first < rpw) ? a.M - row_first : rpw;
+        // Row pointers of this wavefront's rows -> LDS (one coalesced load, rpw <= 32).
+        const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
+        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
+        wb = __builtin_amdgcn_readfirstlane(rp);
+        we = __builtin_amdgcn_readlane(rp, nrows);
+    }
 
     const int col0 = tile * (W * V * S) + l * V;
     bool colok[S];
@@ -411,7 +428,8 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         }
 
         if (rowok2) {
-            float* Crow = a.C + (size_t)(row_first + r) * (size_t)a.N + col0;
+            const int crow = planned ? s_perm[wave][r] : row_first + r;
+            float* Crow = a.C + (size_t)crow * (size_t)a.N + col0;
             const bool nts = (a.flags & kFlagNtStore) != 0;
 #pragma unroll
             for (int s = 0; s < S; ++s)
@@ -767,13 +785,14 @@ template <int RED>
 __global__ __launch_bounds__(kThreads) void spmm_longrow_combine_kernel(float* __restrict__ C, int N, int max_rows,
                                                                          const LongRowHeader* __restrict__ hdr,
                                                                          const int4* __restrict__ rowlist,
-                                                                         const float* __restrict__ partial) {
+                                                                         const float* __restrict__ partial,
+                                                                         const int32_t* __restrict__ perm) {
     int nrows = hdr->nrows;
     if (nrows > max_rows) nrows = max_rows;
     for (int j = blockIdx.x; j < nrows; j += gridDim.x) {
         const int4 e = rowlist[j];  // {row, first slot, #chunks}
         const float* src = partial + (size_t)e.y * (size_t)N;
-        float* dst = C + (size_t)e.x * (size_t)N;
+        float* dst = C + (size_t)(perm ? perm[e.x] : e.x) * (size_t)N;  // plan mode: e.x is a permuted row id
         for (int col = threadIdx.x; col < N; col += kThreads) {
             float acc = src[col];
             for (int c = 1; c < e.z; ++c) {
@@ -1224,6 +1243,7 @@ static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {
         rpw *= 2;
     args.rpw = rpw;
     args.nblk = (int)(((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw));
+    if (a.tasks) args.nblk = (a.ntasks + kWaves - 1) / kWaves;  // plan mode: one wavefront per task
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;
     if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
@@ -1465,10 +1485,10 @@ hipError_t longrows_finish(const SpmmArgs& a, const Geometry& geo, const LongRow
         const int blocks = ws.max_rows < 256 ? ws.max_rows : 256;
         if (geo.reduce == kReduceMax)
             hipLaunchKernelGGL(spmm_longrow_combine_kernel<kReduceMax>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a.C,
-                               a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
+                               a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial, a.perm);
         else
             hipLaunchKernelGGL(spmm_longrow_combine_kernel<kReduceSum>, dim3((unsigned)blocks), dim3(kThreads), 0, st, a.C,
-                               a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial);
+                               a.N, ws.max_rows, ws.hdr, ws.rowlist, ws.partial, a.perm);
         e = hipGetLastError();
     }
     const hipError_t ef = own ? workspace_free(ws.hdr, st) : hipSuccess;

@@ -81,44 +81,102 @@ def _make_cfg(cfg):
 
 
 class SpmmPlan:
-    """Scratch kept across calls for ONE sparse matrix at one feature width — the "analysis" stage of
-    the vendor libraries. For dense graphs (cache-blocked path) it holds the per-row split points, which
-    are computed on the first call and reused afterwards (0.2 ms per call on a reddit-sized graph). Creating
-    a plan also looks at the longest row (one synchronisation) and switches the long-row pass on or off
-    accordingly — rows that pass re-associates are within the 1e-4 tolerance, not bit-exact. The caller vouches that ``rowptr`` /
-    ``colind`` do not change while the plan is in use and uses a plan on one stream at a time.
+    """The analysis stage for ONE sparse matrix at one feature width (``gespmm_plan_*`` of the C ABI — what the
+    vendor libraries call preprocess; the reference has none). Creating a plan reads the matrix on the host once
+    (one synchronisation) and keeps what every later launch reuses: the long-row decision from the longest row it
+    saw, the split points of the cache-blocked path (dense graphs), and — for sparse graphs whose B exceeds the
+    L2s — a row-CLUSTERED copy of the matrix with an nnz-balanced task table, so rows that share neighbours run
+    next to each other and find the shared B rows in L2. Only the processing order changes: the result has the
+    same bits as the plain call.
 
-        plan = SpmmPlan(rowptr, colind, K, N)
-        out = csr_spmm(rowptr, colind, values, dense, plan=plan)
+        plan = SpmmPlan(rowptr, colind, K, N, values=val)      # reorder="auto" | True | False
+        out = csr_spmm(rowptr, colind, val, dense, plan=plan)
+
+    The plan keeps references to ``rowptr`` / ``colind`` (and the values it last saw) and notices in-place edits
+    through the tensors' version counters: new VALUES are re-permuted automatically, a changed PATTERN raises —
+    make a new plan. One plan serves one stream at a time.
     """
 
-    def __init__(self, rowptr, colind, K, N, variant=_lib.VARIANT_AUTO):
+    def __init__(self, rowptr, colind, K, N, variant=_lib.VARIANT_AUTO, values=None, reorder="auto", task_entries=0,
+                 threads=0, flags=0):
         _need(rowptr, "rowptr", torch.int32, 1)
         _need(colind, "colind", torch.int32, 1)
+        if values is not None:
+            _need(values, "values", torch.float32, 1)
+            if values.numel() != colind.numel():
+                raise ValueError("values and colind must have the same length")
+        dev = _same_device(rowptr, colind) if values is None else _same_device(rowptr, colind, values)
         self.shape = (rowptr.numel() - 1, int(K), int(N), colind.numel(), int(variant))
-        self.graph = (rowptr.data_ptr(), colind.data_ptr())
-        # Analysis the plain entry points cannot afford (it synchronises): the longest row decides whether the
-        # long-row pass is worth its launches — the library's own rule has to guess from nnz and the mean degree.
-        M, nnz = self.shape[0], self.shape[3]
-        self.flags = 0
-        if M > 0 and nnz > 0:
-            max_deg = int((rowptr[1:] - rowptr[:-1]).max().item())
-            threshold = max(2048, 32 * ((nnz + M - 1) // M))
-            self.flags = _lib.FLAG_SPLIT_LONG_ROWS if max_deg > threshold else _lib.FLAG_STRICT_ORDER
-        self._cfg = LaunchCfg(0, 0, 0, 0, 0, self.flags)
-        nbytes = lib.gespmm_csr_spmm_workspace_bytes(self.shape[0], self.shape[1], self.shape[2], self.shape[3],
-                                                     int(variant), ctypes.byref(self._cfg))
-        if nbytes < 0:
-            check(int(nbytes), "gespmm_csr_spmm_workspace_bytes")
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=rowptr.device) if nbytes > 0 else None
-        self.ready = False  # True once a call has written the split points
+        self._rowptr, self._colind = rowptr, colind  # strong references: the plan may point at them
+        self._pattern_version = (rowptr._version, colind._version)
+        self._values = values
+        self._values_version = values._version if values is not None else None
+        self.device = dev
+        mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
+        opt = _lib.PlanOptions(mode, int(task_entries), int(threads), int(flags))
+        self._handle = ctypes.c_void_p()
+        M, K_, N_, nnz, var = self.shape
+        with _on_device(dev):
+            rc = lib.gespmm_plan_create(ctypes.byref(self._handle), _ptr(rowptr), _ptr(colind),
+                                        _ptr(values) if values is not None else None, M, K_, N_, nnz, var,
+                                        ctypes.byref(opt), _stream(dev))
+        check(rc, "gespmm_plan_create")
 
-    def _flags_for(self, rowptr, colind, dense, variant):
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            lib.gespmm_plan_destroy(h)
+            self._handle = ctypes.c_void_p()
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(1024)
+        n = lib.gespmm_plan_describe(self._handle, buf, 1024)
+        if n < 0:
+            check(int(n), "gespmm_plan_describe")
+        return buf.value.decode()
+
+    @property
+    def clustered(self):
+        return self.describe().startswith("order=clustered")
+
+    def order(self):
+        """perm[i] = row processed at position i (torch int32 on the CPU)."""
+        perm = torch.empty(self.shape[0], dtype=torch.int32)
+        rc = lib.gespmm_plan_get_order(self._handle, ctypes.c_void_p(perm.data_ptr()))
+        if rc < 0:
+            check(rc, "gespmm_plan_get_order")
+        return perm
+
+    def _sync_inputs(self, rowptr, colind, values, dense, variant):
         M, K, N, nnz, var = self.shape
-        if (rowptr.numel() - 1, dense.shape[0], dense.shape[1], colind.numel(), int(variant)) != (M, K, N, nnz, var) or \
-                (rowptr.data_ptr(), colind.data_ptr()) != self.graph:
-            raise ValueError("SpmmPlan was made for a different matrix, width or variant")
-        return self.flags | (_lib.FLAG_REUSE_SPLIT if (self.ready and self.workspace is not None) else 0)
+        if (rowptr.numel() - 1, dense.shape[0], colind.numel(), int(variant)) != (M, K, nnz, var) or \
+                rowptr.data_ptr() != self._rowptr.data_ptr() or colind.data_ptr() != self._colind.data_ptr():
+            raise ValueError("SpmmPlan was made for a different matrix or variant")
+        if (self._rowptr._version, self._colind._version) != self._pattern_version:
+            raise ValueError("rowptr/colind were modified in place after the plan was made: create a new SpmmPlan")
+        if values is None:
+            if self._values is not None:
+                check(lib.gespmm_plan_set_values(self._handle, None, _stream(self.device)), "gespmm_plan_set_values")
+                self._values, self._values_version = None, None
+        elif self._values is None or values.data_ptr() != self._values.data_ptr() or \
+                values._version != self._values_version:
+            check(lib.gespmm_plan_set_values(self._handle, _ptr(values), _stream(self.device)), "gespmm_plan_set_values")
+            self._values, self._values_version = values, values._version
+
+    def run(self, values, dense, out=None, reduce_max=None):
+        _need(dense, "dense", torch.float32, 2)
+        M, K, _, _, _ = self.shape
+        N = dense.shape[1]
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        with _on_device(self.device):
+            if reduce_max is None:
+                rc = lib.gespmm_plan_spmm_f32(self._handle, _ptr(dense), _ptr(out), N, _stream(self.device))
+            else:
+                rc = lib.gespmm_plan_spmm_max_f32(self._handle, _ptr(dense), _ptr(out), N, float(reduce_max),
+                                                  _stream(self.device))
+        check(rc, "gespmm_plan_spmm_f32")
+        return out
 
 
 def _spmm(rowptr, colind, values, dense, variant, cfg, out, plan=None):
@@ -147,24 +205,19 @@ def _spmm(rowptr, colind, values, dense, variant, cfg, out, plan=None):
     if plan is not None:
         if c is not None:
             raise ValueError("a plan fixes the launch configuration: pass either cfg or plan")
-        c = LaunchCfg(0, 0, 0, 0, 0, plan._flags_for(rowptr, colind, dense, variant))
+        plan._sync_inputs(rowptr, colind, values, dense, variant)
+        return plan.run(values, dense, out)
     cref = ctypes.byref(c) if c is not None else None
     # scratch for the cache-blocked / long-row paths from torch's allocator (see torch_binding.cpp)
-    if plan is not None:
-        ws = plan.workspace
-        ws_bytes = ws.numel() if ws is not None else 0
-    else:
-        ws_bytes = lib.gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, int(variant), cref)
-        if ws_bytes < 0:
-            check(int(ws_bytes), "gespmm_csr_spmm_workspace_bytes")
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
+    ws_bytes = lib.gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, int(variant), cref)
+    if ws_bytes < 0:
+        check(int(ws_bytes), "gespmm_csr_spmm_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
     with _on_device(dev):
         rc = lib.gespmm_csr_spmm_f32_ws(_ptr(rowptr), _ptr(colind), _ptr(values) if values is not None else None,
                                         _ptr(dense), _ptr(out), M, K, N, nnz, int(variant), cref,
                                         _ptr(ws) if ws is not None else None, ws_bytes, _stream(dev))
     check(rc, "gespmm_csr_spmm_f32")
-    if plan is not None:
-        plan.ready = True
     return out
 
 
@@ -172,25 +225,15 @@ def csr_spmm(rowptr, colind, values, dense, variant=_lib.VARIANT_AUTO, cfg=None,
     """C = A @ dense with A = CSR(rowptr, colind, values). Mirrors spmm.cpp:24-43."""
     if values is None:
         raise TypeError("csr_spmm needs edge values; use csr_spmm_no_edge_value for A == 1")
-    if _ext is not None and cfg is None and out is None:
-        if plan is None:
-            return _ext.csr_spmm(rowptr, colind, values, dense, int(variant))
-        res = _ext.csr_spmm(rowptr, colind, values, dense, int(variant), plan.workspace,
-                            plan._flags_for(rowptr, colind, dense, variant))
-        plan.ready = True
-        return res
+    if _ext is not None and cfg is None and out is None and plan is None:
+        return _ext.csr_spmm(rowptr, colind, values, dense, int(variant))
     return _spmm(rowptr, colind, values, dense, variant, cfg, out, plan)
 
 
 def csr_spmm_no_edge_value(rowptr, colind, dense, variant=_lib.VARIANT_AUTO, cfg=None, out=None, plan=None):
     """C = A @ dense with A == 1 on its pattern. Mirrors spmm.cpp:45-60."""
-    if _ext is not None and cfg is None and out is None:
-        if plan is None:
-            return _ext.csr_spmm_no_edge_value(rowptr, colind, dense, int(variant))
-        res = _ext.csr_spmm_no_edge_value(rowptr, colind, dense, int(variant), plan.workspace,
-                                          plan._flags_for(rowptr, colind, dense, variant))
-        plan.ready = True
-        return res
+    if _ext is not None and cfg is None and out is None and plan is None:
+        return _ext.csr_spmm_no_edge_value(rowptr, colind, dense, int(variant))
     return _spmm(rowptr, colind, None, dense, variant, cfg, out, plan)
 
 

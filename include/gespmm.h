@@ -22,6 +22,8 @@
  *   gespmm_mtx_read[_cached] / _free  <- readMtx<float>()     util/util.hpp:286-333 (+ mmio.hpp:215,308)
  *   gespmm_coo_to_csr        <- inline COO->CSR               spmm_test.cu:557-581
  *   gespmm_row_partition     <- (new; north_star multi-GPU)   no reference counterpart
+ *   gespmm_plan_*            <- (new) analysis stage in front of repeated launches; no reference counterpart
+ *   gespmm_cluster_rows / gespmm_simulate_l2_hits <- (new) the plan's host-side row clustering and its L2 model
  *   gespmm_baseline_atomic_scatter_f32 <- Gunrock app's edge map  gunrock-test/app/spmm/spmm_enactor.cuh:92-105
  *
  * Conventions (all device entry points):
@@ -71,12 +73,14 @@ extern "C" {
  * reference's device kernels perform); they are bit-identical to each other.
  * Variant 5 changes the summation order and is tolerance-checked.
  *
- * Load balance: in matrices with >= 2^23 non-zeros, rows longer than
- * max(2048, 32 x mean degree) entries (RMAT hubs) are computed by a whole workgroup as 64-entry tiles dealt
- * round-robin to its lane groups, with the partial rows added in a fixed order —
- * bit-reproducible from run to run, but a re-association of the strict chain
- * (within the 1e-4 tolerance, not bit-for-bit). GESPMM_FLAG_STRICT_ORDER (through
- * gespmm_csr_spmm_f32_cfg) keeps every row a strict chain.
+ * Load balance: in matrices with >= 2^23 non-zeros (or >= 2^20 at mean degree >= 8), rows longer than
+ * max(2048, 32 x mean degree) entries (RMAT hubs) are skipped by the main kernel and computed in
+ * 2048-entry CHUNKS spread over the whole chip: a workgroup sums one chunk (its lane groups take the
+ * chunk's 64-entry tiles round-robin, partial rows added in fixed group order), a combine kernel adds
+ * a row's chunk partials in chunk order — bit-reproducible from run to run, but a re-association of
+ * the strict chain (within the 1e-4 tolerance, not bit-for-bit). GESPMM_FLAG_STRICT_ORDER (through
+ * gespmm_csr_spmm_f32_cfg) keeps every row a strict chain. A gespmm_plan decides from the longest row
+ * it actually saw instead of these size rules.
  */
 #define GESPMM_VARIANT_AUTO       (-1)
 #define GESPMM_VARIANT_NAIVE        0
@@ -227,6 +231,70 @@ int gespmm_csr2csc_f32(const int32_t* rowptr, const int32_t* colind, const float
                        int32_t* colptr, int32_t* rowind, float* csc_val,
                        int64_t M, int64_t K, int64_t nnz,
                        void* workspace, void* stream);
+
+/*
+ * ------------------------------------------------------------------ plans (analysis stage)
+ *
+ * Repeated products with ONE sparse matrix (200 timed launches in spmm_test.cu:754-762; every layer of every
+ * epoch in gcn_custom.py:118-143) can be prepared once. The reference has no such stage — its kernels walk the
+ * rows in storage order on every launch; vendor SpMMs have one (rocsparse_spmm_stage_preprocess). A plan
+ *   - reads the matrix on the HOST once (gespmm_plan_create synchronises `stream`),
+ *   - decides the long-row pass from the longest row it actually saw,
+ *   - keeps the scratch of the cache-blocked path (dense graphs) so its split scan runs once,
+ *   - and, for sparse graphs whose B exceeds the L2s, keeps a ROW-CLUSTERED copy of the matrix plus a task
+ *     table with an equal non-zero budget per wavefront: rows that share neighbours are processed next to each
+ *     other, so the B rows they share come from the XCD's L2 instead of crossing the fabric again.
+ * The order in which rows are PROCESSED is the only thing a plan changes: each row is still one fp32 chain in
+ * its own CSR order written to its own row of C, so gespmm_plan_spmm_f32 returns the same bits as
+ * gespmm_csr_spmm_f32 (with the same long-row decision; see GESPMM_FLAG_STRICT_ORDER).
+ *
+ * rowptr / colind / val are DEVICE pointers. A plan that keeps the storage order (small or dense matrices, or
+ * reorder = GESPMM_PLAN_NO_REORDER) keeps referring to them, so they must outlive the plan; a clustered plan owns
+ * copies. After changing the VALUES call gespmm_plan_set_values; a changed pattern needs a new plan.
+ * One plan serves one stream at a time.
+ */
+typedef struct gespmm_plan gespmm_plan;
+
+#define GESPMM_PLAN_REORDER_AUTO 0  /* cluster when B exceeds the L2s and the model of the L2s predicts a gain */
+#define GESPMM_PLAN_REORDER      1  /* always cluster (streaming-kernel family only) */
+#define GESPMM_PLAN_NO_REORDER   2  /* keep the storage order */
+
+typedef struct gespmm_plan_options {
+    int32_t reorder;       /* GESPMM_PLAN_REORDER_* */
+    int32_t task_entries;  /* non-zeros per wavefront task of a clustered plan, 0 = default for N */
+    int32_t threads;       /* host threads for the clustering, 0 = all (the result does not depend on it) */
+    int32_t flags;         /* GESPMM_FLAG_* applied to every launch (e.g. GESPMM_FLAG_STRICT_ORDER) */
+} gespmm_plan_options;
+
+int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,
+                       int64_t M, int64_t K, int64_t nnz, int64_t N /* width the plan is tuned for */, int variant,
+                       const gespmm_plan_options* opt /* may be NULL */, void* stream);
+/* C[M x N] = A * B through the plan; any N is legal (scratch and task size are tuned for the plan's N). */
+int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, void* stream);
+/* max reducer (unweighted plans only), see gespmm_csr_spmm_max_f32 */
+int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, float empty_value, void* stream);
+/* New values on the unchanged pattern (val in the caller's CSR order, device memory; NULL = A == 1). */
+int gespmm_plan_set_values(gespmm_plan* plan, const float* val, void* stream);
+/* perm_host[i] = row processed at position i (HOST memory, M entries). Returns 1 if clustered, 0 if storage order. */
+int gespmm_plan_get_order(const gespmm_plan* plan, int32_t* perm_host);
+/* One line of text: order, cluster hierarchy, tasks, modelled L2 hit rate before -> after, analysis time, launch. */
+int gespmm_plan_describe(const gespmm_plan* plan, char* out, int64_t capacity);
+void gespmm_plan_destroy(gespmm_plan* plan);
+
+/*
+ * The clustering by itself, HOST pointers (what gespmm_plan_create runs on its host copy): multi-level label
+ * propagation on the bipartite row/column graph; perm_out[i] = row at position i. Deterministic, independent of
+ * `threads`. levels_out / clusters_out[16] (row clusters after each level) may be NULL.
+ */
+int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int32_t threads,
+                        int32_t* perm_out, int32_t* levels_out, int32_t* clusters_out);
+/*
+ * Model of the per-XCD L2 used to judge an order (HOST pointers): rows processed in `perm` order (NULL = storage
+ * order) in `slices` contiguous parts of equal non-zero count, each with an LRU of `window_rows` B rows; returns
+ * the share of non-zeros whose B row is resident when gathered.
+ */
+double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
+                               int32_t slices, int64_t window_rows);
 
 /*
  * Comparison column, not a product path: the Gunrock app's edge map

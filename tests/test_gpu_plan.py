@@ -1,0 +1,150 @@
+"""gespmm_plan (row-clustered copy + nnz-balanced task table): the processing order is the ONLY thing a plan
+changes, so every result must have the same bits as the plain call and as the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import bits, edge_case_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("graph", ("cora", "pubmed"))
+def test_clustered_plan_bits_equal_oracle(pkg, oracle, bundled, graph):
+    from gespmm_amd import spmm
+
+    g = bundled[graph]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=7)
+    val = _dev(val_h)
+    for N in (3, 32, 100, 128, 260, 512):
+        plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True)
+        assert plan.clustered, plan.describe()
+        order = plan.order().numpy()
+        assert np.array_equal(np.sort(order), np.arange(g["M"]))
+        B_h = oracle.hash_B(g["K"], N, seed=N)
+        B = _dev(B_h)
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()
+        ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
+        assert np.array_equal(bits(got), bits(ref)), (graph, N)
+        # the same plan without values = the unweighted kernels, against the golden loop
+        got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan).cpu().numpy()
+        ref_u = oracle.spmm(g["rowptr"], g["colind"], None, B_h, "golden")
+        assert np.array_equal(bits(got_u), bits(ref_u)), (graph, N)
+        # and with values again (re-permuted on the device)
+        val2_h = oracle.hash_val(g["nnz"], seed=8)
+        val2 = _dev(val2_h)
+        got2 = spmm.csr_spmm(rp, ci, val2, B, plan=plan).cpu().numpy()
+        assert np.array_equal(bits(got2), bits(oracle.spmm(g["rowptr"], g["colind"], val2_h, B_h, "fma")))
+        del plan
+
+
+def test_values_edited_in_place_are_picked_up(pkg, oracle, bundled):
+    from gespmm_amd import spmm
+
+    g = bundled["citeseer"]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val = _dev(oracle.hash_val(g["nnz"], seed=1))
+    B = _dev(oracle.hash_B(g["K"], 64, seed=2))
+    plan = spmm.SpmmPlan(rp, ci, g["K"], 64, values=val, reorder=True)
+    a = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    assert torch.equal(a, spmm.csr_spmm(rp, ci, val, B))
+    val.mul_(-2.0)  # same tensor, new contents
+    b = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    assert torch.equal(b, spmm.csr_spmm(rp, ci, val, B)) and not torch.equal(a, b)
+    rp[1:3] = rp[1:3]  # an in-place write to the pattern (even a no-op) invalidates the plan
+    with pytest.raises(ValueError):
+        spmm.csr_spmm(rp, ci, val, B, plan=plan)
+
+
+def test_edge_shapes_rectangular_empty_rows_duplicates(pkg, oracle):
+    from gespmm_amd import spmm
+
+    g = edge_case_csr(seed=4)
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=3)
+    for N in (1, 7, 64, 130):
+        B_h = oracle.hash_B(g["K"], N, seed=N + 1)
+        for te in (0, 8, 1000):  # tiny budgets: every row its own task; huge: 32-row tasks
+            plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=_dev(val_h), reorder=True, task_entries=te)
+            got = plan.run(None, _dev(B_h)).cpu().numpy()
+            ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
+            assert np.array_equal(bits(got), bits(ref)), (N, te)
+            mx = spmm.SpmmPlan(rp, ci, g["K"], N, reorder=True, task_entries=te).run(None, _dev(B_h), reduce_max=-10000.0)
+            assert np.array_equal(bits(mx.cpu().numpy()), bits(oracle.spmm_max(g["rowptr"], g["colind"], B_h)))
+
+
+def test_fuzz_plans_against_plain_calls(pkg):
+    from gespmm_amd import spmm
+
+    rng = np.random.RandomState(5)
+    for case in range(40):
+        M = int(rng.randint(1, 3000))
+        K = int(rng.randint(1, 3000))
+        deg = rng.geometric(0.2, size=M) - 1
+        if case % 5 == 0:
+            deg[rng.randint(0, M)] = rng.randint(100, 5000)
+        rowptr = np.zeros(M + 1, dtype=np.int32)
+        rowptr[1:] = np.cumsum(deg)
+        colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)
+        N = int(rng.choice([1, 2, 5, 16, 31, 32, 33, 64, 96, 128, 129, 256, 300]))
+        rp, ci = _dev(rowptr), _dev(colind)
+        val = torch.rand(colind.size, device="cuda") - 0.5
+        B = torch.rand(K, N, device="cuda") - 0.5
+        plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=int(rng.choice([0, 16, 64])))
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+        ref = spmm.csr_spmm(rp, ci, val, B)
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (case, M, K, N)
+
+
+def test_full_size_community_graph_auto_plan(pkg, oracle):
+    """com-Amazon-sized planted-community graph with shuffled ids: AUTO clusters it (the L2 model predicts the
+    gain), bits equal the plain call on the whole matrix and the oracle on sampled rows."""
+    from gespmm_amd import graphs, spmm
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    assert g["M"] == 334863 and g["nnz"] == 1851744
+    rp, ci, M = g["rowptr"], g["colind"], g["M"]
+    val = torch.rand(g["nnz"], device="cuda") - 0.5
+    plan = spmm.SpmmPlan(rp, ci, M, 128, values=val)
+    d = plan.describe()
+    assert d.startswith("order=clustered"), d
+    B = (torch.randint(0, 100, (M, 128), device="cuda", dtype=torch.int32) - 50).float() / 100
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    ref = spmm.csr_spmm(rp, ci, val, B)
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    # structureless stand-in: whatever AUTO decides, the bits stay
+    g2 = graphs.synthetic_graph("com-amazon-like", seed=42, device="cuda")
+    plan2 = spmm.SpmmPlan(g2["rowptr"], g2["colind"], M, 128, values=val)
+    got2 = spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B, plan=plan2)
+    assert torch.equal(got2.view(torch.int32), spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B).view(torch.int32))
+    # N = 32 and 512 through plans of their own
+    for N in (32, 512):
+        Bn = (torch.randint(0, 100, (M, N), device="cuda", dtype=torch.int32) - 50).float() / 100
+        pn = spmm.SpmmPlan(rp, ci, M, N, values=val, reorder=True)
+        assert torch.equal(spmm.csr_spmm(rp, ci, val, Bn, plan=pn).view(torch.int32),
+                           spmm.csr_spmm(rp, ci, val, Bn).view(torch.int32)), N
+
+
+def test_hub_rows_through_a_clustered_plan(pkg):
+    """RMAT scale 18 (hub rows of 10^4+ entries): the plan sees the longest row and switches the long-row pass on;
+    a plain call with the same decision gives the same bits (chunk sums do not depend on the processing order)."""
+    from gespmm_amd import _lib, graphs, spmm
+
+    g = graphs.rmat_shard(18, 16, 0, 1, seed=42, device="cuda")
+    rp, ci, M, K = g["rowptr"], g["colind"], g["M"], g["K"]
+    assert int((rp[1:] - rp[:-1]).max()) > 4096
+    val = torch.rand(g["nnz"], device="cuda") - 0.5
+    B = torch.rand(K, 64, device="cuda") - 0.5
+    plan = spmm.SpmmPlan(rp, ci, K, 64, values=val, reorder=True)
+    assert "long_rows>" in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    ref = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_SPLIT_LONG_ROWS})
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    strict = spmm.SpmmPlan(rp, ci, K, 64, values=val, reorder=True, flags=_lib.FLAG_STRICT_ORDER)
+    ref_s = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_STRICT_ORDER})
+    assert torch.equal(spmm.csr_spmm(rp, ci, val, B, plan=strict).view(torch.int32), ref_s.view(torch.int32))
