@@ -65,11 +65,15 @@ EXPORTS = [
     "gespmm_plan_destroy",
     "gespmm_cluster_rows",
     "gespmm_simulate_l2_hits",
+    "gespmm_debug_build_records",
 ]
 
 PLAN_REORDER_AUTO = 0
 PLAN_REORDER = 1
 PLAN_NO_REORDER = 2
+PLAN_KERNEL_AUTO = 0
+PLAN_KERNEL_STREAM = 1
+PLAN_KERNEL_LDS_ROWS = 2
 
 
 class LaunchCfg(Structure):
@@ -78,7 +82,8 @@ class LaunchCfg(Structure):
 
 
 class PlanOptions(Structure):
-    _fields_ = [("reorder", c_int32), ("task_entries", c_int32), ("threads", c_int32), ("flags", c_int32)]
+    _fields_ = [("reorder", c_int32), ("task_entries", c_int32), ("row_floor", c_int32), ("threads", c_int32),
+                ("flags", c_int32), ("kernel", c_int32)]
 
 
 class Coo(Structure):

@@ -20,6 +20,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -49,6 +50,12 @@ struct gespmm_plan {
     int32_t* d_tasks = nullptr;
     int32_t ntasks = 0;
     int32_t task_entries = 0;
+    // LDS-staged-rows kernel (spmm_ldsrow.hip): one 640-byte record per task
+    int32_t* d_recs = nullptr;
+    int32_t* d_rec_src = nullptr;  // per record entry: position of its value in the CALLER's val array (-1: none)
+    int32_t nrec = 0;
+    double rec_dup = 0.0;          // non-zeros per distinct B row, averaged over the records
+    int kernel_choice = 0;         // GESPMM_PLAN_KERNEL_*
     std::vector<int32_t> perm_host;
     void* ws = nullptr;
     int64_t ws_bytes = 0;
@@ -74,12 +81,144 @@ __global__ void permute_values_kernel(const int32_t* __restrict__ rowptr_p, cons
 }
 
 void free_device(gespmm_plan* p) {
-    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws};
+    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
-    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = nullptr;
+    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = nullptr;
     p->d_val = nullptr;
     p->ws = nullptr;
+}
+
+
+__global__ void scatter_record_values_kernel(const int32_t* __restrict__ rec_src, const float* __restrict__ val,
+                                             int32_t* __restrict__ recs, int64_t nslots) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const int32_t src = rec_src[i];
+    if (src < 0) return;
+    const int64_t rec = i / gespmm::kRecEntries, k = i % gespmm::kRecEntries;
+    reinterpret_cast<float*>(recs)[rec * gespmm::kRecWords + gespmm::kRecOffVal + k] = val[src];
+}
+
+// Cut the row-permuted matrix into the records of spmm_ldsrow.hip: consecutive rows are packed while they fit
+// (<= 32 rows, <= `target` (<= 64) entries, <= 32 DISTINCT columns); a row that does not fit a record by itself
+// becomes a chain of records over consecutive pieces of its entries.
+struct RecordBuilder {
+    std::vector<int32_t> recs, src;
+    int64_t entries = 0, distinct = 0;
+    int32_t nrec() const { return (int32_t)(recs.size() / gespmm::kRecWords); }
+    int32_t* open() {
+        recs.resize(recs.size() + gespmm::kRecWords, 0);
+        src.resize(src.size() + gespmm::kRecEntries, -1);
+        return recs.data() + recs.size() - gespmm::kRecWords;
+    }
+};
+
+void build_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci,
+                   const std::vector<int32_t>& src_begin, const std::vector<int32_t>& perm, int target, RecordBuilder& rb) {
+    using namespace gespmm;
+    if (target <= 0 || target > kRecEntries) target = kRecEntries;
+    std::vector<int32_t> stamp((size_t)K, -1), slot_of((size_t)K, 0), seen((size_t)K, -1), seen_alone((size_t)K, -1);
+    int32_t stamp_id = 0;
+    auto set_byte = [](int32_t* rec, int byte_off, int value) {
+        reinterpret_cast<uint8_t*>(rec)[byte_off] = (uint8_t)value;
+    };
+    int64_t i = 0;
+    while (i < M) {
+        // distinct columns of row i alone
+        auto row_distinct = [&](int64_t r) {
+            int d = 0;
+            for (int32_t p = rp[r]; p < rp[r + 1]; ++p)
+                if (seen_alone[ci[p]] != (int32_t)r) {
+                    seen_alone[ci[p]] = (int32_t)r;
+                    ++d;
+                }
+            return d;
+        };
+        const int32_t deg = rp[i + 1] - rp[i];
+        if (deg > kRecEntries || (deg > kRecDistinct && row_distinct(i) > kRecDistinct)) {
+            // ---- long row: chain of records
+            const size_t first_word = rb.recs.size();
+            int nseg = 0;
+            int32_t p = rp[i];
+            while (p < rp[i + 1]) {
+                int32_t* rec = rb.open();
+                const size_t src_base = rb.src.size() - kRecEntries;
+                ++stamp_id;
+                int nent = 0, ndist = 0;
+                while (p < rp[i + 1] && nent < kRecEntries) {
+                    const int32_t c = ci[p];
+                    if (stamp[c] != stamp_id) {
+                        if (ndist == kRecDistinct) break;
+                        stamp[c] = stamp_id;
+                        slot_of[c] = ndist;
+                        rec[kRecOffDcol + ndist] = c;
+                        ++ndist;
+                    }
+                    set_byte(rec, kRecOffSlotBytes + nent, slot_of[c]);
+                    rb.src[src_base + nent] = src_begin[i] + (p - rp[i]);
+                    ++nent;
+                    ++p;
+                }
+                rec[0] = 1;
+                rec[1] = nent;
+                rec[2] = ndist;
+                rec[3] = -1;
+                rec[kRecOffCrow] = perm[i];
+                set_byte(rec, kRecOffRpBytes + 0, 0);
+                set_byte(rec, kRecOffRpBytes + 1, nent);
+                rb.entries += nent;
+                rb.distinct += ndist;
+                ++nseg;
+            }
+            rb.recs[first_word + 3] = nseg > 1 ? nseg : 0;
+            ++i;
+            continue;
+        }
+        // ---- ordinary record: pack consecutive rows
+        int32_t* rec = rb.open();
+        const size_t src_base = rb.src.size() - kRecEntries;
+        ++stamp_id;
+        int nrows = 0, nent = 0, ndist = 0;
+        while (i < M && nrows < kRecRows) {
+            const int32_t d = rp[i + 1] - rp[i];
+            if (nrows > 0 && nent + d > target) break;
+            if (d > kRecEntries) break;
+            // new distinct columns this row would add (row-local duplicates counted once)
+            int add = 0;
+            for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+                const int32_t c = ci[p];
+                if (stamp[c] != stamp_id && seen[c] != (int32_t)i) {
+                    seen[c] = (int32_t)i;
+                    ++add;
+                }
+            }
+            if (ndist + add > kRecDistinct) break;  // (never the record's first row: that one was checked to fit alone)
+            set_byte(rec, kRecOffRpBytes + nrows, nent);
+            rec[kRecOffCrow + nrows] = perm[i];
+            for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+                const int32_t c = ci[p];
+                if (stamp[c] != stamp_id) {
+                    stamp[c] = stamp_id;
+                    slot_of[c] = ndist;
+                    rec[kRecOffDcol + ndist] = c;
+                    ++ndist;
+                }
+                set_byte(rec, kRecOffSlotBytes + nent, slot_of[c]);
+                rb.src[src_base + nent] = src_begin[i] + (p - rp[i]);
+                ++nent;
+            }
+            ++nrows;
+            ++i;
+        }
+        set_byte(rec, kRecOffRpBytes + nrows, nent);
+        rec[0] = nrows;
+        rec[1] = nent;
+        rec[2] = ndist;
+        rec[3] = 0;
+        rb.entries += nent;
+        rb.distinct += ndist;
+    }
 }
 
 template <typename T>
@@ -131,6 +270,36 @@ double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int
     } catch (const std::bad_alloc&) {
         return -1.0;
     }
+}
+
+// Test hook (HOST pointers): the records build_records() cuts from a matrix in the given processing order, so the
+// CPU test-suite can interpret them and compare with the oracle. *recs_out is malloc'ed; free() it.
+int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
+                               int32_t target, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out) {
+    if (!rowptr || !perm || !recs_out || !nrec_out || M < 0 || K <= 0) return GESPMM_EINVAL;
+    try {
+        std::vector<int32_t> rp((size_t)M + 1, 0), src((size_t)M, 0), pv(perm, perm + M);
+        for (int64_t i = 0; i < M; ++i) rp[i + 1] = rp[i] + (rowptr[perm[i] + 1] - rowptr[perm[i]]);
+        std::vector<int32_t> ci((size_t)rp[M]);
+        for (int64_t i = 0; i < M; ++i) {
+            src[i] = rowptr[perm[i]];
+            std::memcpy(ci.data() + rp[i], colind + src[i], (size_t)(rp[i + 1] - rp[i]) * 4);
+        }
+        RecordBuilder rb;
+        build_records(M, K, rp, ci, src, pv, target, rb);
+        *nrec_out = rb.nrec();
+        *recs_out = (int32_t*)malloc(rb.recs.size() * 4 + 4);
+        if (!*recs_out) return GESPMM_ENOMEM;
+        std::memcpy(*recs_out, rb.recs.data(), rb.recs.size() * 4);
+        if (src_out) {
+            *src_out = (int32_t*)malloc(rb.src.size() * 4 + 4);
+            if (!*src_out) return GESPMM_ENOMEM;
+            std::memcpy(*src_out, rb.src.data(), rb.src.size() * 4);
+        }
+    } catch (const std::bad_alloc&) {
+        return GESPMM_ENOMEM;
+    }
+    return 0;
 }
 
 int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
@@ -248,16 +417,19 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 rp[i + 1] = rp[i] + d;
             }
             const int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
+            const int floor_opt = opt ? opt->row_floor : 0;
+            const int64_t row_floor = floor_opt < 0 ? 0 : (floor_opt > 0 ? floor_opt : 8);
             p->task_entries = budget;
+            auto cost = [&](int64_t i2) { const int64_t d = rp[i2 + 1] - rp[i2]; return d > row_floor ? d : row_floor; };
             std::vector<int32_t> tasks;
             tasks.reserve((size_t)(nnz / budget + M / gespmm::kMaxRowsPerWave + 16) * 4);
             int64_t i = 0;
             while (i < M) {
                 const int64_t first = i;
-                int64_t acc = rp[i + 1] - rp[i];
+                int64_t acc = cost(i);
                 ++i;
-                while (i < M && i - first < gespmm::kMaxRowsPerWave && acc + (rp[i + 1] - rp[i]) <= budget) {
-                    acc += rp[i + 1] - rp[i];
+                while (i < M && i - first < gespmm::kMaxRowsPerWave && acc + cost(i) <= budget) {
+                    acc += cost(i);
                     ++i;
                 }
                 tasks.push_back((int32_t)first);
@@ -276,6 +448,23 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
                                    p->d_src_begin, val, p->d_val, (int)M, (int)nnz);
                 e = hipGetLastError();
+            }
+            // ---- records of the LDS-staged-rows kernel (not for matrices that need the long-row pass)
+            p->kernel_choice = opt ? opt->kernel : GESPMM_PLAN_KERNEL_AUTO;
+            RecordBuilder rb;
+            if (e == hipSuccess && p->kernel_choice != GESPMM_PLAN_KERNEL_STREAM && !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) &&
+                K > 0) {
+                build_records(M, K, rp, ci, src, p->perm_host, (opt && opt->task_entries > 0) ? opt->task_entries : 0, rb);
+                p->nrec = rb.nrec();
+                p->rec_dup = rb.distinct > 0 ? (double)rb.entries / (double)rb.distinct : 0.0;
+                e = upload(&p->d_recs, rb.recs, st);
+                if (e == hipSuccess) e = upload(&p->d_rec_src, rb.src, st);
+                if (e == hipSuccess && p->valued && p->nrec > 0) {
+                    const int64_t nslots = (int64_t)p->nrec * gespmm::kRecEntries;
+                    hipLaunchKernelGGL(scatter_record_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
+                                       p->d_rec_src, val, p->d_recs, nslots);
+                    e = hipGetLastError();
+                }
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors go out of scope
             if (e != hipSuccess) {
@@ -317,7 +506,26 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     const int64_t ws_bytes = (N == p->N) ? p->ws_bytes : 0;
     if (ws && p->split_ready) cfg.flags |= GESPMM_FLAG_REUSE_SPLIT;
     int rc;
-    if (p->reordered) {
+    const bool variant_v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 ||
+                            p->variant == GESPMM_VARIANT_CRC_CWM8;
+    bool lds_rows = p->reordered && p->d_recs && p->nrec > 0 && gespmm::ldsrow_group_width(N) > 0 && variant_v4 &&
+                    (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    // AUTO: staging pays when a record's rows really share B rows (>= 1.25 non-zeros per distinct row) and a row is
+    // at least 64 bytes wide; GESPMM_PLAN_KERNEL_LDS_ROWS forces it wherever it is defined
+    if (lds_rows && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO) lds_rows = p->rec_dup >= 1.25 && N >= 16;
+    if (lds_rows) {
+        if (!B || !C) return GESPMM_EINVAL;
+        gespmm::LdsRowArgs la;
+        la.recs = p->d_recs;
+        la.B = B;
+        la.C = C;
+        la.nrec = p->nrec;
+        la.N = (int32_t)N;
+        la.ntile = la.nblk = 0;
+        la.empty = empty;
+        const bool idx64 = (uint64_t)p->K * (uint64_t)N * 4ull >= (1ull << 32);
+        rc = (int)gespmm::launch_spmm_ldsrow(la, p->valued, idx64, reduce, reinterpret_cast<hipStream_t>(stream));
+    } else if (p->reordered) {
         gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
                               p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
@@ -357,6 +565,11 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     if (p->nnz == 0) return 0;
     hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
                        p->d_src_begin, val, p->d_val, (int)p->M, (int)p->nnz);
+    if (p->d_recs && p->nrec > 0) {
+        const int64_t nslots = (int64_t)p->nrec * gespmm::kRecEntries;
+        hipLaunchKernelGGL(scatter_record_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
+                           p->d_rec_src, val, p->d_recs, nslots);
+    }
     return (int)hipGetLastError();
 }
 
@@ -379,11 +592,18 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         int off = 0;
         for (int i = 0; i < p->stats.levels && i < 16 && off < 100; ++i)
             off += snprintf(lv + off, sizeof lv - (size_t)off, "%s%d", i ? ">" : "", p->stats.clusters[i]);
+        char kern[160];
+        const int W = gespmm::ldsrow_group_width(p->N);
+        const bool lds = p->d_recs && p->nrec > 0 && W > 0 &&
+                         (p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS || (p->rec_dup >= 1.25 && p->N >= 16)) &&
+                         (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
+        if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
+        else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d max_degree=%d l2_model=%.3f->%.3f "
                      "analysis=%.3fs (clustering %.3fs) | %s",
                      p->stats.levels, lv, p->ntasks, p->task_entries, p->max_degree, p->hits_before, p->hits_after,
-                     p->analysis_seconds, p->cluster_seconds, what);
+                     p->analysis_seconds, p->cluster_seconds, kern);
     } else {
         n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.3fs | %s",
                      p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, what);

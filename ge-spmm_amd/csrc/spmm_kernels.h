@@ -31,6 +31,8 @@ constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force 
 constexpr int kFlagNoSlabBlocked = 0x800; // == GESPMM_FLAG_NO_SLAB_BLOCKED
 constexpr int kFlagReuseSplit = 0x2000;   // == GESPMM_FLAG_REUSE_SPLIT
 constexpr int kFlagAllowReassoc = 0x1000; // == GESPMM_FLAG_ALLOW_REASSOCIATION
+constexpr int kFlagDebugIdentityStore = 0x4000;  // experiments only: plan mode writes C in processing order (WRONG rows)
+constexpr int kFlagSc1Store = 0x8000;     // == GESPMM_FLAG_SC1_STORE: C stores do not stay in the XCD's L2
 constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
 
 struct SpmmArgs {
@@ -92,6 +94,36 @@ size_t slabblocked_workspace_bytes(int64_t M, const Geometry& geo);
 hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void* ext_ws, size_t ext_bytes,
                                    hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+
+// spmm_ldsrow.hip — the plan's kernel for clustered matrices. A task is one fixed-size RECORD (plan.cpp writes them):
+//   words 0-3    nrows, nent, ndist, kind (0: single record; k > 0: first of a k-record chain = one long row; -1: continuation)
+//   words 4-35   C row of each of the (<= 32) rows
+//   words 36-67  the (<= 32) distinct column ids
+//   words 68-131 value of each of the (<= 64) entries (fp32)
+//   bytes 528-591  LDS slot (index into the distinct columns) of each entry
+//   bytes 592-624  first entry of each row (nrows + 1 values)
+constexpr int kRecEntries = 64;
+constexpr int kRecDistinct = 32;
+constexpr int kRecRows = 32;
+constexpr int kRecWords = 160;
+constexpr int kRecOffCrow = 4;
+constexpr int kRecOffDcol = 36;
+constexpr int kRecOffVal = 68;
+constexpr int kRecOffSlotBytes = 132 * 4;
+constexpr int kRecOffRpBytes = 148 * 4;
+
+struct LdsRowArgs {
+    const int32_t* recs;
+    const float* B;
+    float* C;
+    int32_t nrec;
+    int32_t N;
+    int32_t ntile;  // filled in by the launcher
+    int32_t nblk;
+    float empty;
+};
+int ldsrow_group_width(int64_t N);  // lanes per row (4..32), 0 if N is not served (N % 4 != 0)
+hipError_t launch_spmm_ldsrow(const LdsRowArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
 
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form

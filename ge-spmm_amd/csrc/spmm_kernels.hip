@@ -97,6 +97,23 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[V]) {
     else *reinterpret_cast<T*>(p) = v;
 }
 
+// Store that does not leave the line in the XCD's L2 (`sc1`: MI355X_MICROARCH.md, stores of each flavour): C is
+// written once and never read by this launch, and every C line kept in L2 evicts a B row somebody may reuse.
+template <int V>
+__device__ __forceinline__ void store_vec_sc1(float* p, const float (&src)[V]) {
+    using T = typename VecT<V>::type;
+    T v;
+    if constexpr (V == 1) {
+        v = src[0];
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = src[i];
+        if constexpr (V == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
 // Workgroup id -> work item id such that XCD x (which receives ids == x mod 8)
 // gets a contiguous slice of the item range. Bijective for every n.
 __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
@@ -428,13 +445,15 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         }
 
         if (rowok2) {
-            const int crow = planned ? s_perm[wave][r] : row_first + r;
+            const int crow = (planned && !(a.flags & kFlagDebugIdentityStore)) ? s_perm[wave][r] : row_first + r;
             float* Crow = a.C + (size_t)crow * (size_t)a.N + col0;
             const bool nts = (a.flags & kFlagNtStore) != 0;
+            const bool sc1 = (a.flags & kFlagSc1Store) != 0;
 #pragma unroll
             for (int s = 0; s < S; ++s)
                 if (colok[s]) {
-                    if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                    if (sc1) store_vec_sc1<V>(Crow + s * (W * V), acc[s]);
+                    else if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
                     else store_vec<V, false>(Crow + s * (W * V), acc[s]);
                 }
         }

@@ -98,7 +98,7 @@ class SpmmPlan:
     """
 
     def __init__(self, rowptr, colind, K, N, variant=_lib.VARIANT_AUTO, values=None, reorder="auto", task_entries=0,
-                 threads=0, flags=0):
+                 threads=0, flags=0, row_floor=0, kernel="auto"):
         _need(rowptr, "rowptr", torch.int32, 1)
         _need(colind, "colind", torch.int32, 1)
         if values is not None:
@@ -113,18 +113,19 @@ class SpmmPlan:
         self._values_version = values._version if values is not None else None
         self.device = dev
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
-        opt = _lib.PlanOptions(mode, int(task_entries), int(threads), int(flags))
+        kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "lds-rows": _lib.PLAN_KERNEL_LDS_ROWS}[kernel]
+        opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern)
         self._handle = ctypes.c_void_p()
         M, K_, N_, nnz, var = self.shape
         with _on_device(dev):
             rc = lib.gespmm_plan_create(ctypes.byref(self._handle), _ptr(rowptr), _ptr(colind),
-                                        _ptr(values) if values is not None else None, M, K_, N_, nnz, var,
+                                        _ptr(values) if values is not None else None, M, K_, nnz, N_, var,
                                         ctypes.byref(opt), _stream(dev))
         check(rc, "gespmm_plan_create")
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h is not None and h.value:
+        if h is not None and h.value and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib.gespmm_plan_destroy(h)
             self._handle = ctypes.c_void_p()
 

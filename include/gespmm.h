@@ -261,10 +261,17 @@ typedef struct gespmm_plan gespmm_plan;
 
 typedef struct gespmm_plan_options {
     int32_t reorder;       /* GESPMM_PLAN_REORDER_* */
-    int32_t task_entries;  /* non-zeros per wavefront task of a clustered plan, 0 = default for N */
+    int32_t task_entries;  /* work per wavefront task of a clustered plan in non-zeros, 0 = default for N */
+    int32_t row_floor;     /* a row counts as at least this many non-zeros when tasks are cut (the kernel spends one
+                              memory round trip per row pair however short the rows are), 0 = default, -1 = none */
     int32_t threads;       /* host threads for the clustering, 0 = all (the result does not depend on it) */
     int32_t flags;         /* GESPMM_FLAG_* applied to every launch (e.g. GESPMM_FLAG_STRICT_ORDER) */
+    int32_t kernel;        /* GESPMM_PLAN_KERNEL_*: which kernel a clustered plan launches */
 } gespmm_plan_options;
+
+#define GESPMM_PLAN_KERNEL_AUTO     0  /* LDS-staged rows when the tasks' rows share B rows, else the streaming kernel */
+#define GESPMM_PLAN_KERNEL_STREAM   1  /* batch-stream kernel on the task table */
+#define GESPMM_PLAN_KERNEL_LDS_ROWS 2  /* distinct B rows of a task fetched once into LDS (N % 4 == 0, no long-row pass) */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,
                        int64_t M, int64_t K, int64_t nnz, int64_t N /* width the plan is tuned for */, int variant,
@@ -295,6 +302,15 @@ int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M,
  */
 double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                int32_t slices, int64_t window_rows);
+
+/*
+ * Test hook (HOST pointers, no device): the task records a clustered plan cuts for its LDS-staged-rows kernel
+ * (layout: csrc/spmm_kernels.h) from a matrix processed in `perm` order, so a CPU test can interpret them against the
+ * oracle. *recs_out (nrec x 160 int32) and *src_out (nrec x 64: position of each record entry's value in the caller's
+ * value array, -1 = unused) are malloc'ed; free() them.
+ */
+int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
+                               int32_t task_entries, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out);
 
 /*
  * Comparison column, not a product path: the Gunrock app's edge map

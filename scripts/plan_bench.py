@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--ncols", default="128")
     ap.add_argument("--entries", default="0,16,24,32,48,64,96,128")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--kernel", default="auto")
     ap.add_argument("--only-plan", action="store_true", help="one clustered plan per graph at the default task size (for rocprofv3)")
     args = ap.parse_args()
     import torch
@@ -49,7 +50,7 @@ def main():
             C = torch.empty((M, N), device=dev)
             abytes = 4 * (M + 1) + 8 * nnz + 4 * K * N + 4 * M * N
             if args.only_plan:
-                plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True)
+                plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=args.kernel)
                 us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
                 print("%s N=%d clustered plan %.1f us  frac %.3f | %s" % (name, N, us, abytes / us / 8e6, plan.describe()), flush=True)
                 continue
@@ -59,15 +60,21 @@ def main():
             plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=False)
             us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
             print("%s N=%d storage-order plan    %8.1f us  frac %.3f" % (name, N, us, abytes / us / 8e6), flush=True)
-            for te in [int(x) for x in args.entries.split(",")]:
-                t0 = time.time()
-                plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=te)
-                dt = time.time() - t0
-                us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
-                ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
-                print("%s N=%d clustered entries=%-4d %8.1f us  frac %.3f  bits_equal=%s  create %.2fs" %
-                      (name, N, te, us, abytes / us / 8e6, ok, dt), flush=True)
-            print("   ", plan.describe(), flush=True)
+            for kernel in ("stream", "lds-rows"):
+                if kernel == "lds-rows" and N % 4:
+                    continue
+                for te in [int(x) for x in args.entries.split(",")]:
+                    if kernel == "lds-rows" and te > 64:
+                        continue
+                    t0 = time.time()
+                    plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=te, kernel=kernel)
+                    dt = time.time() - t0
+                    C.zero_()
+                    us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
+                    ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
+                    print("%s N=%d clustered %-8s entries=%-4d %8.1f us  frac %.3f  bits_equal=%s  create %.2fs" %
+                          (name, N, kernel, te, us, abytes / us / 8e6, ok, dt), flush=True)
+                print("   ", plan.describe(), flush=True)
             auto = spmm.SpmmPlan(rp, ci, K, N, values=val)
             us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=auto))
             print("%s N=%d AUTO plan             %8.1f us  | %s" % (name, N, us, auto.describe()), flush=True)

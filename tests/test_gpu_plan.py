@@ -21,9 +21,12 @@ def test_clustered_plan_bits_equal_oracle(pkg, oracle, bundled, graph):
     rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
     val_h = oracle.hash_val(g["nnz"], seed=7)
     val = _dev(val_h)
-    for N in (3, 32, 100, 128, 260, 512):
-        plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True)
+    for N, kernel in ((3, "auto"), (32, "lds-rows"), (32, "stream"), (100, "lds-rows"), (128, "lds-rows"), (128, "stream"),
+                      (260, "lds-rows"), (512, "auto"), (16, "lds-rows"), (64, "lds-rows"), (8, "lds-rows")):
+        plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True, kernel=kernel)
         assert plan.clustered, plan.describe()
+        if kernel == "lds-rows":
+            assert "kernel=lds-rows" in plan.describe(), plan.describe()
         order = plan.order().numpy()
         assert np.array_equal(np.sort(order), np.arange(g["M"]))
         B_h = oracle.hash_B(g["K"], N, seed=N)
@@ -67,19 +70,21 @@ def test_edge_shapes_rectangular_empty_rows_duplicates(pkg, oracle):
     g = edge_case_csr(seed=4)
     rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
     val_h = oracle.hash_val(g["nnz"], seed=3)
-    for N in (1, 7, 64, 130):
+    for N in (1, 7, 64, 132):
         B_h = oracle.hash_B(g["K"], N, seed=N + 1)
-        for te in (0, 8, 1000):  # tiny budgets: every row its own task; huge: 32-row tasks
-            plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=_dev(val_h), reorder=True, task_entries=te)
+        for te, kernel in ((0, "stream"), (8, "stream"), (1000, "stream"), (0, "lds-rows"), (8, "lds-rows")):
+            if kernel == "lds-rows" and N % 4:
+                continue
+            plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=_dev(val_h), reorder=True, task_entries=te, kernel=kernel)
             got = plan.run(None, _dev(B_h)).cpu().numpy()
             ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
             assert np.array_equal(bits(got), bits(ref)), (N, te)
-            mx = spmm.SpmmPlan(rp, ci, g["K"], N, reorder=True, task_entries=te).run(None, _dev(B_h), reduce_max=-10000.0)
+            mx = spmm.SpmmPlan(rp, ci, g["K"], N, reorder=True, task_entries=te, kernel=kernel).run(None, _dev(B_h), reduce_max=-10000.0)
             assert np.array_equal(bits(mx.cpu().numpy()), bits(oracle.spmm_max(g["rowptr"], g["colind"], B_h)))
 
 
 def test_fuzz_plans_against_plain_calls(pkg):
-    from gespmm_amd import spmm
+    from gespmm_amd import _lib, spmm
 
     rng = np.random.RandomState(5)
     for case in range(40):
@@ -95,9 +100,11 @@ def test_fuzz_plans_against_plain_calls(pkg):
         rp, ci = _dev(rowptr), _dev(colind)
         val = torch.rand(colind.size, device="cuda") - 0.5
         B = torch.rand(K, N, device="cuda") - 0.5
-        plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=int(rng.choice([0, 16, 64])))
+        # hub rows: the plan would switch the long-row pass on (a re-association); pin both sides to the strict chain
+        plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=int(rng.choice([0, 16, 64])),
+                             flags=_lib.FLAG_STRICT_ORDER, kernel=str(rng.choice(["auto", "stream", "lds-rows"])))
         got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
-        ref = spmm.csr_spmm(rp, ci, val, B)
+        ref = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_STRICT_ORDER})
         assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (case, M, K, N)
 
 
@@ -125,9 +132,10 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     # N = 32 and 512 through plans of their own
     for N in (32, 512):
         Bn = (torch.randint(0, 100, (M, N), device="cuda", dtype=torch.int32) - 50).float() / 100
-        pn = spmm.SpmmPlan(rp, ci, M, N, values=val, reorder=True)
-        assert torch.equal(spmm.csr_spmm(rp, ci, val, Bn, plan=pn).view(torch.int32),
-                           spmm.csr_spmm(rp, ci, val, Bn).view(torch.int32)), N
+        for kernel in ("stream", "lds-rows"):
+            pn = spmm.SpmmPlan(rp, ci, M, N, values=val, reorder=True, kernel=kernel)
+            assert torch.equal(spmm.csr_spmm(rp, ci, val, Bn, plan=pn).view(torch.int32),
+                               spmm.csr_spmm(rp, ci, val, Bn).view(torch.int32)), (N, kernel)
 
 
 def test_hub_rows_through_a_clustered_plan(pkg):
