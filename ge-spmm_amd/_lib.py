@@ -74,6 +74,7 @@ PLAN_NO_REORDER = 2
 PLAN_KERNEL_AUTO = 0
 PLAN_KERNEL_STREAM = 1
 PLAN_KERNEL_LDS_ROWS = 2
+PLAN_KERNEL_SEG_STREAM = 3
 
 
 class LaunchCfg(Structure):

@@ -82,9 +82,10 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
             (void)hipGetLastError();
         }
     }
-    if (pl) {  // task tables exist for the batch-stream kernel only
-        flags |= gespmm::kFlagBatchStream | gespmm::kFlagNoSlabBlocked;
-        flags &= ~(gespmm::kFlagSlabBlocked | gespmm::kFlagSegStream);
+    if (pl) {  // task tables exist for the two streaming kernels only
+        flags |= gespmm::kFlagNoSlabBlocked;
+        flags &= ~(gespmm::kFlagSlabBlocked | gespmm::kFlagSegStream | gespmm::kFlagBatchStream);
+        flags |= (pl->prefer_segmented && pl->gtasks) ? gespmm::kFlagSegStream : gespmm::kFlagBatchStream;
     }
     const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
                                              cfg ? cfg->strips : 0, cfg ? cfg->group : 0,
@@ -116,6 +117,8 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.tasks = pl ? pl->tasks : nullptr;
     a.perm = pl ? pl->perm : nullptr;
     a.ntasks = pl ? pl->ntasks : 0;
+    a.gtasks = pl ? pl->gtasks : nullptr;
+    a.ngtasks = pl ? pl->ngtasks : 0;
 
     hipError_t e;
     a.rpw = sel.geo.rows_per_group;

@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,8 @@ struct gespmm_plan {
     int32_t* d_src_begin = nullptr;
     int32_t* d_tasks = nullptr;
     int32_t ntasks = 0;
+    int32_t* d_gtasks = nullptr;  // lane-group tasks of the segmented-stream kernel
+    int32_t ngtasks = 0;
     int32_t task_entries = 0;
     // LDS-staged-rows kernel (spmm_ldsrow.hip): one 640-byte record per task
     int32_t* d_recs = nullptr;
@@ -81,10 +84,10 @@ __global__ void permute_values_kernel(const int32_t* __restrict__ rowptr_p, cons
 }
 
 void free_device(gespmm_plan* p) {
-    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src};
+    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
-    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = nullptr;
+    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = p->d_gtasks = nullptr;
     p->d_val = nullptr;
     p->ws = nullptr;
 }
@@ -137,7 +140,7 @@ void build_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, const s
         };
         const int32_t deg = rp[i + 1] - rp[i];
         if (deg > kRecEntries || (deg > kRecDistinct && row_distinct(i) > kRecDistinct)) {
-            // ---- long row: chain of records
+            // ---- long row: chain of records = one unit
             const size_t first_word = rb.recs.size();
             int nseg = 0;
             int32_t p = rp[i];
@@ -163,7 +166,7 @@ void build_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, const s
                 rec[0] = 1;
                 rec[1] = nent;
                 rec[2] = ndist;
-                rec[3] = -1;
+                rec[3] = 3;  // continues from the previous record and into the next (fixed up below)
                 rec[kRecOffCrow] = perm[i];
                 set_byte(rec, kRecOffRpBytes + 0, 0);
                 set_byte(rec, kRecOffRpBytes + 1, nent);
@@ -171,7 +174,8 @@ void build_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, const s
                 rb.distinct += ndist;
                 ++nseg;
             }
-            rb.recs[first_word + 3] = nseg > 1 ? nseg : 0;
+            rb.recs[first_word + 3] &= ~1;                                        // first: nothing before it
+            rb.recs[first_word + (size_t)(nseg - 1) * kRecWords + 3] &= ~2;       // last: nothing after it
             ++i;
             continue;
         }
@@ -231,13 +235,12 @@ hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
 }
 
 // Non-zeros per wavefront task. Storage-order launches take ~12 KB of gathered B per task (select.cpp);
-// with clustered rows part of the gathers hit L2 and the per-task prologue weighs more: twice that
-// (profiles/r02/plan_task_size.log).
+// clustered plans take ~32 KB (64 entries at N = 128; profiles/r02/plan_task_size.log), see the caller for the L2-hit case.
 int default_task_entries(int64_t N) {
     const int64_t row_bytes = 4 * (N < 256 ? N : 256);
-    int64_t t = (24 << 10) / (row_bytes > 0 ? row_bytes : 4);
+    int64_t t = (32 << 10) / (row_bytes > 0 ? row_bytes : 4);
     if (t < 32) t = 32;
-    if (t > 192) t = 192;
+    if (t > 256) t = 256;
     return (int)t;
 }
 
@@ -273,7 +276,7 @@ double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int
 }
 
 // Test hook (HOST pointers): the records build_records() cuts from a matrix in the given processing order, so the
-// CPU test-suite can interpret them and compare with the oracle. *recs_out is malloc'ed; free() it.
+// CPU test-suite can interpret them against its CPU checker. *recs_out is malloc'ed; free() it.
 int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                int32_t target, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out) {
     if (!rowptr || !perm || !recs_out || !nrec_out || M < 0 || K <= 0) return GESPMM_EINVAL;
@@ -395,14 +398,17 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 delete p;
                 return GESPMM_EINVAL;
             }
+            // (Moving the heavy rows to the front of each XCD slice, so that no long sequential chain starts late, was
+            // measured: no effect on the community graph, 151 vs 137 us on the structureless one — hubs stay where the
+            // clustering puts them, next to the rows that share their neighbours. profiles/r02/plan_hubs_first.log)
             p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
             // A model of the XCD L2s says whether the new order is worth having (graphs whose storage order is
             // already local, or that have no structure to find, keep their order and pay nothing per launch).
-            if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && nnz <= (1ll << 25)) {
+            if (nnz <= (1ll << 25)) {
                 const int64_t window = (3ll << 20) / (4 * (N < tile_cols ? N : tile_cols) > 0 ? 4 * (N < tile_cols ? N : tile_cols) : 4);
                 p->hits_before = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), nullptr, 8, window);
                 p->hits_after = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), p->perm_host.data(), 8, window);
-                if (p->hits_after < p->hits_before + 0.03) reorder = false;
+                if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && p->hits_after < p->hits_before + 0.03) reorder = false;
             }
         }
         if (reorder) {
@@ -416,33 +422,45 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 std::memcpy(ci.data() + rp[i], h_colind.data() + b, (size_t)d * 4);
                 rp[i + 1] = rp[i] + d;
             }
-            const int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
+            // task size: ~32 KB of gathered B per wavefront; twice that when the order is modelled to hit L2 for >= 40 % of
+            // the gathers (the per-task prologue then weighs more than the coarser balance; plan_task_size.log)
+            int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
+            if (!(opt && opt->task_entries > 0) && p->hits_after >= 0.40) budget *= 2;
             const int floor_opt = opt ? opt->row_floor : 0;
             const int64_t row_floor = floor_opt < 0 ? 0 : (floor_opt > 0 ? floor_opt : 8);
             p->task_entries = budget;
             auto cost = [&](int64_t i2) { const int64_t d = rp[i2 + 1] - rp[i2]; return d > row_floor ? d : row_floor; };
-            std::vector<int32_t> tasks;
-            tasks.reserve((size_t)(nnz / budget + M / gespmm::kMaxRowsPerWave + 16) * 4);
-            int64_t i = 0;
-            while (i < M) {
-                const int64_t first = i;
-                int64_t acc = cost(i);
-                ++i;
-                while (i < M && i - first < gespmm::kMaxRowsPerWave && acc + cost(i) <= budget) {
-                    acc += cost(i);
-                    ++i;
+            // batch-stream kernel: a task per WAVEFRONT; segmented-stream kernel: a task per lane GROUP (its time is
+            // proportional to the entries it streams, so its tasks are cut by non-zeros alone, half the budget)
+            auto cut_tasks = [&](int64_t budget_, bool floor_rows, std::vector<int32_t>& out_) {
+                out_.reserve((size_t)(nnz / (budget_ > 0 ? budget_ : 1) + M / gespmm::kMaxRowsPerWave + 16) * 4);
+                int64_t i2 = 0;
+                while (i2 < M) {
+                    const int64_t first = i2;
+                    auto c2 = [&](int64_t r) { return floor_rows ? cost(r) : (int64_t)(rp[r + 1] - rp[r]); };
+                    int64_t acc = c2(i2);
+                    ++i2;
+                    while (i2 < M && i2 - first < gespmm::kMaxRowsPerWave && acc + c2(i2) <= budget_) {
+                        acc += c2(i2);
+                        ++i2;
+                    }
+                    out_.push_back((int32_t)first);
+                    out_.push_back((int32_t)(i2 - first));
+                    out_.push_back(rp[first]);
+                    out_.push_back(rp[i2]);
                 }
-                tasks.push_back((int32_t)first);
-                tasks.push_back((int32_t)(i - first));
-                tasks.push_back(rp[first]);
-                tasks.push_back(rp[i]);
-            }
+            };
+            std::vector<int32_t> tasks, gtasks;
+            cut_tasks(budget, true, tasks);
+            cut_tasks(budget / 2 > 16 ? budget / 2 : 16, false, gtasks);
+            p->ngtasks = (int32_t)(gtasks.size() / 4);
             p->ntasks = (int32_t)(tasks.size() / 4);
             e = upload(&p->d_rowptr, rp, st);
             if (e == hipSuccess) e = upload(&p->d_colind, ci, st);
             if (e == hipSuccess) e = upload(&p->d_perm, p->perm_host, st);
             if (e == hipSuccess) e = upload(&p->d_src_begin, src, st);
             if (e == hipSuccess) e = upload(&p->d_tasks, tasks, st);
+            if (e == hipSuccess) e = upload(&p->d_gtasks, gtasks, st);
             if (e == hipSuccess && p->valued) e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(nnz > 0 ? nnz : 1) * 4);
             if (e == hipSuccess && p->valued && nnz > 0) {
                 hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
@@ -452,7 +470,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             // ---- records of the LDS-staged-rows kernel (not for matrices that need the long-row pass)
             p->kernel_choice = opt ? opt->kernel : GESPMM_PLAN_KERNEL_AUTO;
             RecordBuilder rb;
-            if (e == hipSuccess && p->kernel_choice != GESPMM_PLAN_KERNEL_STREAM && !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) &&
+            if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS && !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) &&
                 K > 0) {
                 build_records(M, K, rp, ci, src, p->perm_host, (opt && opt->task_entries > 0) ? opt->task_entries : 0, rb);
                 p->nrec = rb.nrec();
@@ -510,9 +528,9 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
                             p->variant == GESPMM_VARIANT_CRC_CWM8;
     bool lds_rows = p->reordered && p->d_recs && p->nrec > 0 && gespmm::ldsrow_group_width(N) > 0 && variant_v4 &&
                     (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-    // AUTO: staging pays when a record's rows really share B rows (>= 1.25 non-zeros per distinct row) and a row is
-    // at least 64 bytes wide; GESPMM_PLAN_KERNEL_LDS_ROWS forces it wherever it is defined
-    if (lds_rows && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO) lds_rows = p->rec_dup >= 1.25 && N >= 16;
+    // opt-in (GESPMM_PLAN_KERNEL_LDS_ROWS): 118 us vs 112 us for the batch-stream kernel on the clustered bench graph —
+    // its persistent wavefronts are instruction-issue bound at the 8 wavefronts per CU its LDS footprint allows
+    if (lds_rows && p->kernel_choice != GESPMM_PLAN_KERNEL_LDS_ROWS) lds_rows = false;
     if (lds_rows) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::LdsRowArgs la;
@@ -523,10 +541,15 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         la.N = (int32_t)N;
         la.ntile = la.nblk = 0;
         la.empty = empty;
+        static const int dbg = getenv("GESPMM_LDSROW_DEBUG") ? atoi(getenv("GESPMM_LDSROW_DEBUG")) : 0;
+        la.debug = dbg;
         const bool idx64 = (uint64_t)p->K * (uint64_t)N * 4ull >= (1ull << 32);
         rc = (int)gespmm::launch_spmm_ldsrow(la, p->valued, idx64, reduce, reinterpret_cast<hipStream_t>(stream));
     } else if (p->reordered) {
-        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm};
+        // segmented-stream kernel where the rows are short and the clustered order hits L2 (its continuous gather stream
+        // hides the mixed hit/miss latencies better); batch-stream kernel otherwise and whenever long rows are split
+        const bool seg = p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM;  // opt-in: measured behind the batch kernel
+        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
                               p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
     } else {
@@ -594,8 +617,7 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             off += snprintf(lv + off, sizeof lv - (size_t)off, "%s%d", i ? ">" : "", p->stats.clusters[i]);
         char kern[160];
         const int W = gespmm::ldsrow_group_width(p->N);
-        const bool lds = p->d_recs && p->nrec > 0 && W > 0 &&
-                         (p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS || (p->rec_dup >= 1.25 && p->N >= 16)) &&
+        const bool lds = p->d_recs && p->nrec > 0 && W > 0 && p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS &&
                          (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
         if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
         else snprintf(kern, sizeof kern, "%s", what);

@@ -10,6 +10,9 @@ struct PlanLaunch {
     const int32_t* tasks;  // int4 per task (device)
     int32_t ntasks;
     const int32_t* perm;   // permuted row -> original row (device)
+    const int32_t* gtasks; // int4 per lane-group task of the segmented-stream kernel (device), may be NULL
+    int32_t ngtasks;
+    bool prefer_segmented; // launch the segmented-stream kernel when the geometry allows it
 };
 
 int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,

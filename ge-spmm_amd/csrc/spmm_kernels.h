@@ -63,6 +63,9 @@ struct SpmmArgs {
     const int32_t* tasks;
     const int32_t* perm;
     int32_t ntasks;
+    // the same for the segmented-stream kernel, whose unit of work is a lane GROUP: group q works on gtasks[q]
+    const int32_t* gtasks;
+    int32_t ngtasks;
 };
 
 // Launch geometry resolved by the host-side selector (select.cpp).
@@ -95,22 +98,27 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void*
                                    hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
-// spmm_ldsrow.hip — the plan's kernel for clustered matrices. A task is one fixed-size RECORD (plan.cpp writes them):
-//   words 0-3    nrows, nent, ndist, kind (0: single record; k > 0: first of a k-record chain = one long row; -1: continuation)
-//   words 4-35   C row of each of the (<= 32) rows
-//   words 36-67  the (<= 32) distinct column ids
-//   words 68-131 value of each of the (<= 64) entries (fp32)
-//   bytes 528-591  LDS slot (index into the distinct columns) of each entry
-//   bytes 592-624  first entry of each row (nrows + 1 values)
-constexpr int kRecEntries = 64;
-constexpr int kRecDistinct = 32;
-constexpr int kRecRows = 32;
-constexpr int kRecWords = 160;
+// spmm_ldsrow.hip — the plan's kernel for clustered matrices. A task is one fixed-size RECORD of 96 words (plan.cpp):
+//   words 0-3      nrows, nent, ndist, flags (bit 0: the record's single row continues FROM the previous record,
+//                  bit 1: ... INTO the next one — the chain of records of one long row)
+//   words 4-19     C row of each of the (<= 16) rows            } one coalesced load: word 4 + lane
+//   words 20-35    the (<= 16) distinct column ids              }
+//   words 36-67    value of each of the (<= 32) entries (fp32)  }
+//   bytes 272-303  LDS slot (index into the distinct columns) of each entry   } one byte load: 272 + lane
+//   bytes 304-320  first entry of each row (nrows + 1 values)                 }
+constexpr int kRecEntries = 32;
+constexpr int kRecDistinct = 16;
+constexpr int kRecRows = 16;
+constexpr int kRecWords = 96;
 constexpr int kRecOffCrow = 4;
-constexpr int kRecOffDcol = 36;
-constexpr int kRecOffVal = 68;
-constexpr int kRecOffSlotBytes = 132 * 4;
-constexpr int kRecOffRpBytes = 148 * 4;
+constexpr int kRecOffDcol = 20;
+constexpr int kRecOffVal = 36;
+constexpr int kRecOffSlotBytes = 68 * 4;
+constexpr int kRecOffRpBytes = 76 * 4;
+static_assert(kRecOffDcol == kRecOffCrow + kRecRows && kRecOffVal == kRecOffDcol + kRecDistinct &&
+                  kRecOffVal + kRecEntries == 68 && kRecRows + kRecDistinct == 32 && kRecEntries == 32 &&
+                  kRecOffRpBytes == kRecOffSlotBytes + kRecEntries,
+              "the kernel reads a record with one word load and one byte load per lane");
 
 struct LdsRowArgs {
     const int32_t* recs;
@@ -119,8 +127,9 @@ struct LdsRowArgs {
     int32_t nrec;
     int32_t N;
     int32_t ntile;  // filled in by the launcher
-    int32_t nblk;
+    int32_t nblk;   // workgroups per XCD (and column tile)
     float empty;
+    int32_t debug;  // experiments only (GESPMM_LDSROW_DEBUG): 1 = no row fetches, 2 = no sums, 4 = no C stores
 };
 int ldsrow_group_width(int64_t N);  // lanes per row (4..32), 0 if N is not served (N % 4 != 0)
 hipError_t launch_spmm_ldsrow(const LdsRowArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         rb = item / a.ntile;
     }
     int row_first, nrows, wb, we;  // wave-uniform
+    int rp_plan = 0, pm_plan = 0;
     const bool planned = a.tasks != nullptr;
     if (planned) {
         // Plan mode: the task table names the rows and the CSR range, so the first CSR tile, the row
@@ -291,9 +292,8 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         nrows = __builtin_amdgcn_readfirstlane(t.y);
         wb = __builtin_amdgcn_readfirstlane(t.z);
         we = __builtin_amdgcn_readfirstlane(t.w);
-        const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
-        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
-        if (lane < kMaxRowsPerWave) s_perm[wave][lane] = a.perm[row_first + (lane < nrows ? lane : nrows - 1)];
+        rp_plan = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
+        pm_plan = a.perm[row_first + (lane < nrows ? lane : nrows - 1)];
     } else {
         const int rpw = a.rpw;
         row_first = (rb * kWaves + wave) * rpw;
@@ -335,6 +335,10 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
     };
     int t0 = wb;
     fetch_tile_regs(t0);
+    if (planned) {  // (after the tile loads are on their way: the three loads of a planned task overlap)
+        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp_plan;
+        if (lane < kMaxRowsPerWave) s_perm[wave][lane] = pm_plan;
+    }
     publish_tile();
     fetch_tile_regs(t0 + kTile);
     wave_lds_sync();
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
     __shared__ off_t s_off[kWaves][G][T];
     __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? G : 1][VALUED ? T : 1];
     __shared__ int s_ptr[kWaves][G][kMaxRowsPerWave + 1];
+    __shared__ int s_perm[kWaves][G][kMaxRowsPerWave];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -499,21 +504,34 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
         tile = item % a.ntile;
         rb = item / a.ntile;
     }
-    const int rpg = a.rpw;  // rows per GROUP in this kernel
-    const int task_first = ((rb * kWaves + wave) * G + g) * rpg;
-    if (((rb * kWaves + wave) * G) * rpg >= a.M) return;  // whole wavefront past the end
-    int nrows = a.M - task_first;                          // rows of this group's task
-    nrows = nrows < 0 ? 0 : (nrows > rpg ? rpg : nrows);
-
-    // Row pointers of the task -> LDS (rpg <= 32; lanes of a group cover 0..rpg by striding W).
-    int gb = 0, ge = 0;
-    if (nrows > 0) {
-        for (int i = l; i <= nrows; i += W) s_ptr[wave][g][i] = a.rowptr[task_first + i];
-    }
-    wave_lds_sync();
-    if (nrows > 0) {
-        gb = s_ptr[wave][g][0];
-        ge = s_ptr[wave][g][nrows];
+    const bool planned = a.gtasks != nullptr;
+    int task_first, nrows, gb = 0, ge = 0;
+    if (planned) {
+        // Plan mode: lane group q works on gtasks[q] = {first permuted row, #rows, CSR begin, CSR end}; row i of the
+        // permuted matrix is written to C row perm[i].
+        const int q0 = (rb * kWaves + wave) * G;
+        if (q0 >= a.ngtasks) return;  // whole wavefront past the end
+        int4 t = make_int4(0, 0, 0, 0);
+        if (q0 + g < a.ngtasks) t = reinterpret_cast<const int4*>(a.gtasks)[q0 + g];
+        task_first = t.x;
+        nrows = t.y;
+        gb = t.z;
+        ge = t.w;  // (row pointers and C rows are loaded after the first CSR tile is on its way, below)
+    } else {
+        const int rpg = a.rpw;  // rows per GROUP in this kernel
+        task_first = ((rb * kWaves + wave) * G + g) * rpg;
+        if (((rb * kWaves + wave) * G) * rpg >= a.M) return;  // whole wavefront past the end
+        nrows = a.M - task_first;                              // rows of this group's task
+        nrows = nrows < 0 ? 0 : (nrows > rpg ? rpg : nrows);
+        // Row pointers of the task -> LDS (rpg <= 32; lanes of a group cover 0..rpg by striding W).
+        if (nrows > 0) {
+            for (int i = l; i <= nrows; i += W) s_ptr[wave][g][i] = a.rowptr[task_first + i];
+        }
+        wave_lds_sync();
+        if (nrows > 0) {
+            gb = s_ptr[wave][g][0];
+            ge = s_ptr[wave][g][nrows];
+        }
     }
 
     const int col0 = tile * (W * V * S) + l * V;
@@ -557,6 +575,12 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
 
     int tbase = gb;  // CSR position of the group's resident tile
     fetch_tile_regs(tbase);
+    if (planned) {
+        if (nrows > 0) {
+            for (int i = l; i <= nrows; i += W) s_ptr[wave][g][i] = a.rowptr[task_first + i];
+            for (int i = l; i < nrows; i += W) s_perm[wave][g][i] = a.perm[task_first + i];
+        }
+    }
     publish_tile();
     fetch_tile_regs(tbase + T);
     wave_lds_sync();
@@ -568,9 +592,9 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
         for (int i = 0; i < V; ++i) acc[s][i] = init;
     int cur = 0;                                       // current row of the task
     int rend = (nrows > 0) ? s_ptr[wave][g][1] : 0;    // CSR end of the current row
-    float* Crow = a.C + (size_t)task_first * (size_t)a.N + col0;
-
     auto flush_row = [&]() {
+        const int crow = planned ? s_perm[wave][g][cur] : task_first + cur;
+        float* Crow = a.C + (size_t)crow * (size_t)a.N + col0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if (colok[s]) {
@@ -580,7 +604,6 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
 #pragma unroll
             for (int i = 0; i < V; ++i) acc[s][i] = init;
         }
-        Crow += a.N;
         ++cur;
         rend = s_ptr[wave][g][(cur + 1 <= nrows) ? cur + 1 : nrows];
     };
@@ -1330,6 +1353,7 @@ static hipError_t launch_segstream(const SpmmArgs& a, int rpg, hipStream_t st) {
     if (rpg > kMaxRowsPerWave) rpg = kMaxRowsPerWave;
     args.rpw = rpg;
     args.nblk = (int)(((int64_t)a.M + (int64_t)kWaves * G * rpg - 1) / ((int64_t)kWaves * G * rpg));
+    if (a.gtasks) args.nblk = (a.ngtasks + kWaves * G - 1) / (kWaves * G);  // plan mode: one lane group per task
     args.ntile = (a.N + W * V * S - 1) / (W * V * S);
     const int64_t nitems = (int64_t)args.nblk * args.ntile;
     if (nitems <= 0) return hipSuccess;

@@ -1,25 +1,28 @@
-// spmm_ldsrow.hip — the plan's kernel for row-clustered matrices: distinct B rows of a task staged in LDS.
+// spmm_ldsrow.hip — the plan's kernel for row-clustered matrices: distinct B rows of a task staged in LDS by
+// persistent, software-pipelined wavefronts.
 //
 // A clustered plan (plan.cpp) processes rows that share neighbours next to each other. The streaming kernels
-// still gather a B row once per USE (one global load per non-zero); with clustered rows half or more of those
-// loads name a row that the same wavefront needs again a few entries later. This kernel fetches every DISTINCT
-// B row of a task once, straight into LDS (gfx950 `global_load_lds_dwordx4`: no VGPR staging, all of a task's
-// row fetches in flight at the same time), and the row sums then read LDS:
+// still gather a B row once per USE (one global load per non-zero) and a wavefront walks its task phase after
+// phase — CSR, gathers, sums, stores — each phase one exposed memory round trip. Here
 //
-//   * a task is one 640-byte RECORD the plan writes at analysis time — header, C row ids, the distinct column
-//     ids (<= 32), per non-zero the value and the LDS slot of its B row, per row the entry range — so the whole
-//     description of a task is ONE memory round trip at a computable address (record w belongs to wavefront w);
-//   * all distinct rows are requested back to back (64/W rows per instruction: W lanes x 16 bytes cover the
-//     column tile of one row), then one wait;
-//   * the W-lane groups of the wavefront walk the task's rows; each output element is ONE fp32 chain over the
-//     row's non-zeros in CSR order with one fused multiply-add per non-zero — the same arithmetic as every other
-//     variant (spmm_test.cu:182-203 semantics), so the bits are unchanged;
-//   * rows that do not fit one record (more than 64 entries or 32 distinct columns) are a chain of records
-//     handled by ONE wavefront that carries the accumulator from record to record (the wavefronts of the
-//     continuation records exit at once).
+//   * a task is one fixed-size RECORD the plan writes at analysis time — header, C row ids, the DISTINCT column
+//     ids (<= 16), per non-zero its value and the LDS slot of its B row, per row its entry range: the whole
+//     description of a task is two coalesced loads at a computable address;
+//   * every distinct B row of a record is fetched ONCE, straight into LDS (gfx950 `global_load_lds_dwordx4`: no
+//     VGPR staging; 64/W rows per instruction, all of a record's fetches in flight together);
+//   * wavefronts are PERSISTENT and pipelined: while record i is summed out of one LDS buffer, the row fetches of
+//     record i+1 land in the other, the description of record i+2 is on its way, and the C rows of record i-1 are
+//     being written (they stay in registers for one iteration so that no wait ever covers a fresh store);
+//   * records are dealt round-robin to the wavefronts of an XCD inside that XCD's contiguous slice of the clustered
+//     order, so at any moment an XCD works on a narrow window of neighbouring clusters — what keeps the shared B
+//     rows in its L2; a long row is a CHAIN of records walked by the wavefront that owns the first of them (it
+//     carries the accumulator from record to record; the owners of the other records skip them);
+//   * the W-lane groups of a wavefront walk the record's rows; each output element is ONE fp32 chain over the
+//     row's non-zeros in CSR order with one fused multiply-add per non-zero — the arithmetic of every other
+//     variant (spmm_test.cu:182-203 semantics), so the bits are unchanged.
 //
-// Column tiles are 4W floats (W = 4..32 lanes x dwordx4), wider N takes several tiles (several workgroups per
-// record). N must be a multiple of 4; everything else stays on the streaming kernel with the plan's task table.
+// Column tiles are 4W floats (W = 4..32 lanes x dwordx4); wider N takes several tiles. N must be a multiple of 4;
+// everything else stays on the streaming kernel with the plan's task table.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,13 +33,6 @@
 namespace gespmm {
 
 namespace {
-
-__device__ __forceinline__ int xcd_contiguous_id(int bid, int n) {
-    const int q = n >> 3, r = n & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -53,35 +49,48 @@ __device__ __forceinline__ float combine1(float acc, float a, float b) {
 
 using f4 = float __attribute__((ext_vector_type(4)));
 
+struct RecRegs {
+    int nrows, ndist, flags;  // wave-uniform
+    int w;                    // word 4 + lane of the record: C rows (lanes 0-15), distinct columns (16-31), values (32-63)
+    int b;                    // byte: slot of entry `lane` (lanes 0-31), first entry of row `lane - 32` (lanes 32-48)
+};
+
+__device__ __forceinline__ void load_record(const int32_t* recs, int idx, int lane, RecRegs& r) {
+    const int32_t* rec = recs + (size_t)idx * kRecWords;
+    const int4 h = *reinterpret_cast<const int4*>(rec);
+    r.nrows = h.x;
+    r.ndist = h.z;
+    r.flags = h.w;
+    r.w = rec[kRecOffCrow + lane];
+    r.b = reinterpret_cast<const uint8_t*>(rec)[kRecOffSlotBytes + lane];  // slots then row starts: contiguous bytes
+}
+
 template <int W, bool VALUED, bool IDX64, int RED>
 __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
-    constexpr int G = 64 / W;       // lane groups per wavefront = B rows fetched per instruction
-    constexpr int ROWB = W * 16;    // bytes of one staged row (this column tile)
+    constexpr int G = 64 / W;                 // lane groups per wavefront = B rows fetched per instruction
+    constexpr int ROWB = W * 16;              // bytes of one staged row (this column tile)
+    constexpr int BUFB = kRecDistinct * ROWB; // one LDS buffer
+    constexpr int RS = (kRecRows + G - 1) / G;  // row slots per lane group
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
 
-    __shared__ __attribute__((aligned(16))) char s_rows[kWaves][kRecDistinct * ROWB];
+    __shared__ __attribute__((aligned(16))) char s_rows[kWaves][2][BUFB];
     __shared__ int s_off[kWaves][kRecEntries];
     __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? kRecEntries : 1];
-    __shared__ int s_rp[kWaves][kRecRows + 1];
+    __shared__ int s_rp[kWaves][32];
     __shared__ int s_crow[kWaves][kRecRows];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane / W;
     const int l = lane % W;
-    const int item = xcd_contiguous_id(blockIdx.x, a.nblk * a.ntile);
-    int tile = 0, rb = item;
-    if (a.ntile > 1) {
-        tile = item % a.ntile;
-        rb = item / a.ntile;
-    }
-    const int wid = rb * kWaves + wave;
-    if (wid >= a.nrec) return;
-    const int32_t* rec = a.recs + (size_t)wid * kRecWords;
-    int4 h = *reinterpret_cast<const int4*>(rec);
-    const int kind = __builtin_amdgcn_readfirstlane(h.w);
-    if (kind < 0) return;  // continuation of a long row: the wavefront of its first record does it
-    const int nseg = kind > 0 ? kind : 1;
+    // grid = 8 XCDs x slots x column tiles; the hardware deals workgroup b to XCD b % 8
+    const int xcd = blockIdx.x & 7;
+    const int rest = blockIdx.x >> 3;
+    const int tile = rest % a.ntile;
+    const int slot = rest / a.ntile;
+    const int nwx = a.nblk * kWaves;  // wavefronts per XCD (and tile)
+    const int lw = slot * kWaves + wave;
+    const int x0 = (int)((int64_t)a.nrec * xcd / 8), x1 = (int)((int64_t)a.nrec * (xcd + 1) / 8);
 
     const int col0 = tile * (W * 4) + l * 4;
     const bool colok = col0 < a.N;  // N % 4 == 0: a lane's four columns are in range together
@@ -89,78 +98,162 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
     const off_t cbyte = colok ? (off_t)col0 * 4u : (off_t)0;
     const char* Bbase = reinterpret_cast<const char*>(a.B);
     const float init = (RED == kReduceMax) ? a.empty : 0.0f;
-    char* rows_lds = s_rows[wave];
 
-    float acc[4] = {init, init, init, init};
-    for (int seg = 0; seg < nseg; ++seg) {
-        if (seg > 0) {
-            rec += kRecWords;
-            h = *reinterpret_cast<const int4*>(rec);
-        }
-        const int nrows = __builtin_amdgcn_readfirstlane(h.x);
-        const int ndist = __builtin_amdgcn_readfirstlane(h.z);
-        // ---- the record: five independent loads at fixed offsets
-        const int crow = rec[kRecOffCrow + (lane & 31)];
-        const int dcol = rec[kRecOffDcol + (lane & 31)];
-        float v = 1.0f;
-        if constexpr (VALUED) v = reinterpret_cast<const float*>(rec)[kRecOffVal + lane];
-        const int slot = reinterpret_cast<const uint8_t*>(rec)[kRecOffSlotBytes + lane];
-        const int rpb = reinterpret_cast<const uint8_t*>(rec)[kRecOffRpBytes + (lane <= kRecRows ? lane : kRecRows)];
-        // ---- every distinct B row of the record: global -> LDS, G rows per instruction, all in flight together
-        for (int j = 0; j < ndist; j += G) {
-            const int c = __shfl(dcol, (j + g) & 31, 64);
-            if (j + g < ndist && colok) {
+    // Records of this XCD's slice are dealt round-robin: wavefront lw owns records x0 + lw, x0 + lw + nwx, ...
+    // A chain (one long row) is done by the wavefront that owns its FIRST record, which simply walks on through
+    // the following records; the owners of those records skip them (flag bit 0).
+    int own0 = x0 + lw;
+    if (own0 >= x1) return;
+
+    auto issue_rows = [&](const RecRegs& r, int buf) {
+        char* dst = s_rows[wave][buf];
+        for (int j = 0; j < r.ndist; j += G) {
+            const int c = __shfl(r.w, kRecRows + ((j + g) & (kRecDistinct - 1)), 64);
+            if (j + g < r.ndist && colok) {
                 const char* src = Bbase + (off_t)((off_t)(uint32_t)c * rowbytes + cbyte);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(rows_lds + j * ROWB), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + j * ROWB), 16, 0, 0);
             }
         }
-        s_off[wave][lane] = slot * ROWB;
-        if constexpr (VALUED) s_val[wave][lane] = v;
-        if (lane <= kRecRows) s_rp[wave][lane] = rpb;
-        if (lane < kRecRows) s_crow[wave][lane] = crow;
+    };
+    // make the header wave-uniform; a continuation record met as an OWN record belongs to somebody else's chain
+    auto settle = [&](RecRegs& r, int own, int idx) {
+        r.nrows = __builtin_amdgcn_readfirstlane(r.nrows);
+        r.ndist = __builtin_amdgcn_readfirstlane(r.ndist);
+        r.flags = __builtin_amdgcn_readfirstlane(r.flags);
+        if (idx == own && (r.flags & 1)) {
+            r.nrows = 0;
+            r.ndist = 0;
+            r.flags = 0;
+        }
+    };
+    // record after (own, idx): the chain goes on, or the next own record; idx < 0 = nothing left
+    auto advance = [&](int& own, int& idx, int flags) {
+        if (flags & 2) {
+            ++idx;
+        } else {
+            own += nwx;
+            idx = own < x1 ? own : -1;
+        }
+    };
+
+    RecRegs m0, m1, m2;
+    int own_a = own0, idx0 = own0;  // cursor of m0
+    load_record(a.recs, idx0, lane, m0);
+    settle(m0, own_a, idx0);
+    int own_b = own_a, idx1 = idx0;  // cursor of m1
+    advance(own_b, idx1, m0.flags);
+    if (idx1 >= 0) load_record(a.recs, idx1, lane, m1);
+    if (!(a.debug & 1)) issue_rows(m0, 0);
+
+    float acc[RS][4];    // running sums of this record's rows (a chained row keeps slot 0 across records)
+    float outv[RS][4];   // finished rows of the PREVIOUS record, stored one iteration late
+    int outrow[RS];
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+        outrow[s] = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][i] = init;
+    }
+
+    int buf = 0;
+    for (;;) {
+        // ---- everything issued during the previous iteration has had one whole iteration to arrive: the rows of m0,
+        //      the description of m1, the C rows of the record before m0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-
-        for (int r = g; r < nrows; r += G) {
-            const int lb = s_rp[wave][r], hb = s_rp[wave][r + 1];
-            if (seg == 0) {
+        int own_c = own_b, idx2 = -1;  // cursor of m2
+        if (idx1 >= 0) {
+            settle(m1, own_b, idx1);
+            idx2 = idx1;
+            advance(own_c, idx2, m1.flags);
+            if (idx2 >= 0) load_record(a.recs, idx2, lane, m2);  // two records ahead
+        }
+        // ---- C rows of the previous record leave now, then the row fetches of the next record
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = init;
-            }
-            int k = lb;
-            for (; k + 4 <= hb; k += 4) {
-                int o[4];
-                float vv[4];
-                f4 b[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = s_off[wave][k + j];
-                    if constexpr (VALUED) vv[j] = s_val[wave][k + j];
-                    else vv[j] = 1.0f;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f4*>(rows_lds + o[j] + l * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = combine1<RED, VALUED>(acc[i], vv[j], b[j][i]);
-            }
-            for (; k < hb; ++k) {
-                const int o = s_off[wave][k];
-                float vv = 1.0f;
-                if constexpr (VALUED) vv = s_val[wave][k];
-                const f4 b = *reinterpret_cast<const f4*>(rows_lds + o + l * 16);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = combine1<RED, VALUED>(acc[i], vv, b[i]);
-            }
-            if (seg == nseg - 1 && colok) {
-                float* dst = a.C + (size_t)s_crow[wave][r] * (size_t)a.N + col0;
-                f4 o4 = {acc[0], acc[1], acc[2], acc[3]};
+        for (int s = 0; s < RS; ++s) {
+            if (outrow[s] >= 0 && colok && !(a.debug & 4)) {
+                float* dst = a.C + (size_t)outrow[s] * (size_t)a.N + col0;
+                f4 o4 = {outv[s][0], outv[s][1], outv[s][2], outv[s][3]};
                 *reinterpret_cast<f4*>(dst) = o4;
             }
+            outrow[s] = -1;
         }
-        wave_sync();  // reads of this record's LDS image precede the next record's writes
+        if (idx1 >= 0 && !(a.debug & 1)) issue_rows(m1, buf ^ 1);
+        // ---- sums of m0 out of LDS buffer `buf`
+        const RecRegs& cur = m0;
+        const char* rows_lds = s_rows[wave][buf];
+        const bool from_prev = (cur.flags & 1) != 0;  // the (single) row continues from the previous record
+        const bool to_next = (cur.flags & 2) != 0;    // ... and into the next one
+        // the description of m0 moves from the registers that loaded it to LDS, where every lane can index it
+        if (lane < kRecEntries) s_off[wave][lane] = (cur.b & (kRecDistinct - 1)) * ROWB;
+        else s_rp[wave][lane - 32] = cur.b;  // lanes 32..48 carry the rows' first entries
+        if (lane < kRecRows) s_crow[wave][lane] = cur.w;
+        if constexpr (VALUED) {
+            if (lane >= 32) s_val[wave][lane - 32] = __int_as_float(cur.w);
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < RS; ++s) {
+            if (s * G >= cur.nrows || (a.debug & 2)) break;  // wave-uniform
+            const int r = s * G + g;
+            if (r < cur.nrows) {
+                const int lb = s_rp[wave][r], hb = s_rp[wave][r + 1];
+                if (!(from_prev && s == 0)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[s][i] = init;
+                }
+                int k = lb;
+                for (; k + 4 <= hb; k += 4) {
+                    int o[4];
+                    float vv[4];
+                    f4 bb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = s_off[wave][k + j];
+                        if constexpr (VALUED) vv[j] = s_val[wave][k + j];
+                        else vv[j] = 1.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const f4*>(rows_lds + o[j] + l * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[s][i] = combine1<RED, VALUED>(acc[s][i], vv[j], bb[j][i]);
+                }
+                for (; k < hb; ++k) {
+                    const int o = s_off[wave][k];
+                    float vv = 1.0f;
+                    if constexpr (VALUED) vv = s_val[wave][k];
+                    const f4 bb = *reinterpret_cast<const f4*>(rows_lds + o + l * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[s][i] = combine1<RED, VALUED>(acc[s][i], vv, bb[i]);
+                }
+                if (!(to_next && s == 0)) {
+                    outrow[s] = s_crow[wave][r];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) outv[s][i] = acc[s][i];
+                }
+            }
+        }
+        wave_sync();  // this record's description is read before the next one overwrites it
+        if (idx1 < 0) break;
+        m0 = m1;
+        m1 = m2;
+        own_a = own_b;
+        idx0 = idx1;
+        own_b = own_c;
+        idx1 = idx2;
+        buf ^= 1;
+    }
+    // ---- the last record's rows
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+        if (outrow[s] >= 0 && colok && !(a.debug & 4)) {
+            float* dst = a.C + (size_t)outrow[s] * (size_t)a.N + col0;
+            f4 o4 = {outv[s][0], outv[s][1], outv[s][2], outv[s][3]};
+            *reinterpret_cast<f4*>(dst) = o4;
+        }
     }
 }
 
@@ -168,11 +261,17 @@ template <int W, bool VALUED, bool IDX64, int RED>
 hipError_t launch_w(const LdsRowArgs& a0, hipStream_t st) {
     LdsRowArgs a = a0;
     a.ntile = (a.N + W * 4 - 1) / (W * 4);
-    a.nblk = (a.nrec + kWaves - 1) / kWaves;
-    const int64_t nitems = (int64_t)a.nblk * a.ntile;
-    if (nitems <= 0) return hipSuccess;
-    if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((spmm_ldsrow_kernel<W, VALUED, IDX64, RED>), dim3((unsigned)nitems), dim3(kThreads), 0, st, a);
+    // persistent wavefronts: LDS allows 2 workgroups per CU at W = 32 (4 at W = 16, ...): 64 slots per XCD for the
+    // widest tile, never more wavefronts than an XCD has units
+    int per_xcd = 64 * (32 / W);
+    if (per_xcd > 256) per_xcd = 256;
+    const int64_t units_per_xcd = (a.nrec + 7) / 8;
+    while (per_xcd > 1 && (int64_t)per_xcd * kWaves > units_per_xcd) per_xcd >>= 1;
+    a.nblk = per_xcd;
+    const int64_t nblocks = (int64_t)8 * per_xcd * a.ntile;
+    if (a.nrec <= 0) return hipSuccess;
+    if (nblocks > kMaxGridBlocks) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL((spmm_ldsrow_kernel<W, VALUED, IDX64, RED>), dim3((unsigned)nblocks), dim3(kThreads), 0, st, a);
     return hipGetLastError();
 }
 

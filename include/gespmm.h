@@ -271,6 +271,7 @@ typedef struct gespmm_plan_options {
 
 #define GESPMM_PLAN_KERNEL_AUTO     0  /* LDS-staged rows when the tasks' rows share B rows, else the streaming kernel */
 #define GESPMM_PLAN_KERNEL_STREAM   1  /* batch-stream kernel on the task table */
+#define GESPMM_PLAN_KERNEL_SEG_STREAM 3 /* segmented-stream kernel on a task table per lane group */
 #define GESPMM_PLAN_KERNEL_LDS_ROWS 2  /* distinct B rows of a task fetched once into LDS (N % 4 == 0, no long-row pass) */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,

@@ -118,6 +118,9 @@ def test_degenerate_inputs(pkg):
     assert _lib.lib.gespmm_cluster_rows(None, None, 5, 5, 0, p.ctypes.data, None, None) == -1
 
 
+REC_WORDS, REC_ENTRIES, REC_DISTINCT, REC_ROWS = 96, 32, 16, 16  # csrc/spmm_kernels.h
+
+
 def _records(lib, rowptr, colind, M, K, perm, target=0):
     recs = ctypes.POINTER(ctypes.c_int32)()
     src = ctypes.POINTER(ctypes.c_int32)()
@@ -131,8 +134,8 @@ def _records(lib, rowptr, colind, M, K, perm, target=0):
             ctypes.byref(nrec))
     assert rc == 0
     n = nrec.value
-    r = np.ctypeslib.as_array(recs, shape=(n * 160,)).copy().reshape(n, 160)
-    s = np.ctypeslib.as_array(src, shape=(n * 64,)).copy().reshape(n, 64)
+    r = np.ctypeslib.as_array(recs, shape=(n * REC_WORDS,)).copy().reshape(n, REC_WORDS)
+    s = np.ctypeslib.as_array(src, shape=(n * REC_ENTRIES,)).copy().reshape(n, REC_ENTRIES)
     libc = ctypes.CDLL(None)
     libc.free.argtypes = [ctypes.c_void_p]
     libc.free(recs)
@@ -141,72 +144,73 @@ def _records(lib, rowptr, colind, M, K, perm, target=0):
 
 
 def _interpret_records(recs, src, val, B, M):
-    """What spmm_ldsrow.hip computes, restated with numpy float32 in the kernel's order: one fused multiply-add
-    per entry (emulated in float64 -> float32: exact for the fma of two floats plus a float)."""
+    """What spmm_ldsrow.hip computes, restated with numpy in the kernel's order: one fused multiply-add per entry
+    (float64 product + sum rounded once to float32 = fma for float operands), one chain per output element, chains
+    of records carrying the accumulator."""
     N = B.shape[1]
     C = np.full((M, N), np.nan, dtype=np.float32)
-    i = 0
-    while i < len(recs):
-        kind = recs[i, 3]
-        assert kind >= 0, "a continuation record must follow a first record"
-        nseg = kind if kind > 0 else 1
-        acc = None
-        for sgm in range(nseg):
-            rec = recs[i + sgm]
-            nrows, nent, ndist = int(rec[0]), int(rec[1]), int(rec[2])
-            assert 0 <= nrows <= 32 and 0 <= nent <= 64 and 0 <= ndist <= 32
-            if sgm > 0:
-                assert rec[3] == -1 and nrows == 1
-            raw = rec.view(np.uint8)
-            slots = raw[528:528 + 64]
-            rpb = raw[592:592 + 33]
-            assert rpb[0] == 0 and rpb[nrows] == nent and np.all(np.diff(rpb[:nrows + 1].astype(int)) >= 0)
-            dcols = rec[36:36 + 32]
-            assert len(set(dcols[:ndist].tolist())) == ndist, "distinct columns must be distinct"
-            rows_lds = B[dcols[:ndist]]
-            for r in range(nrows):
-                if sgm == 0:
-                    acc = np.zeros(N, dtype=np.float32)
-                for k in range(rpb[r], rpb[r + 1]):
-                    assert slots[k] < ndist
-                    v = np.float32(val[src[i + sgm, k]]) if val is not None else np.float32(1.0)
-                    acc = (v.astype(np.float64) * rows_lds[slots[k]].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
-                if sgm == nseg - 1:
-                    crow = int(rec[4 + r])
-                    assert np.all(np.isnan(C[crow])), "every C row is written exactly once"
-                    C[crow] = acc
-        i += nseg
+    acc = None
+    open_chain = False
+    for i in range(len(recs)):
+        rec = recs[i]
+        nrows, nent, ndist, flags = int(rec[0]), int(rec[1]), int(rec[2]), int(rec[3])
+        assert 0 <= nrows <= REC_ROWS and 0 <= nent <= REC_ENTRIES and 0 <= ndist <= REC_DISTINCT and 0 <= flags <= 3
+        assert bool(flags & 1) == open_chain, "a record continues from the previous one iff that one continues into it"
+        if flags:
+            assert nrows == 1
+        raw = rec.view(np.uint8)
+        slots = raw[272:272 + REC_ENTRIES]
+        rpb = raw[304:304 + REC_ROWS + 1]
+        assert rpb[0] == 0 and rpb[nrows] == nent and np.all(np.diff(rpb[:nrows + 1].astype(int)) >= 0)
+        dcols = rec[20:20 + REC_DISTINCT]
+        assert len(set(dcols[:ndist].tolist())) == ndist, "distinct columns must be distinct"
+        rows_lds = B[dcols[:ndist]]
+        for r in range(nrows):
+            if not (flags & 1):
+                acc = np.zeros(N, dtype=np.float32)
+            for k in range(rpb[r], rpb[r + 1]):
+                assert slots[k] < ndist
+                v = np.float32(val[src[i, k]]) if val is not None else np.float32(1.0)
+                acc = (v.astype(np.float64) * rows_lds[slots[k]].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+            if not (flags & 2):
+                crow = int(rec[4 + r])
+                assert np.all(np.isnan(C[crow])), "every C row is written exactly once"
+                C[crow] = acc
+        open_chain = bool(flags & 2)
+    assert not open_chain
     return C
 
 
 def test_records_of_the_lds_rows_kernel_reproduce_the_oracle(pkg, oracle):
-    """Host logic of the plan's second representation: records cut from a clustered order, interpreted on the CPU
-    in the kernel's arithmetic, must give the oracle's bits — incl. rows longer than a record, rows with more than
-    32 distinct columns, duplicates inside a row, empty rows."""
+    """Host logic of the plan's second representation: records cut from a processing order, interpreted on the CPU
+    in the kernel's arithmetic, must give the oracle's bits — incl. rows longer than a record, rows with more
+    distinct columns than a record holds, duplicates inside a row, empty rows."""
     from gespmm_amd import _lib
 
     rng = np.random.RandomState(11)
     M, K = 700, 500
     deg = rng.geometric(0.15, size=M) - 1
     deg[5] = 300       # chain of records (entries)
-    deg[6] = 50        # 33..64 entries with > 32 distinct columns: chain as well
-    deg[7] = 64
+    deg[6] = 25        # 17..32 entries with > 16 distinct columns: chain as well
+    deg[7] = 32
     deg[100:140] = 0   # a run of empty rows
     rp = np.zeros(M + 1, dtype=np.int32)
     rp[1:] = np.cumsum(deg)
     ci = rng.randint(0, K, size=int(rp[-1])).astype(np.int32)
-    ci[rp[7]:rp[8]] = rng.randint(0, 20, size=64)  # 64 entries over <= 20 distinct columns: fits ONE record
+    ci[rp[6]:rp[7]] = np.arange(25) * 3
+    ci[rp[7]:rp[8]] = rng.randint(0, 10, size=32)  # 32 entries over <= 10 distinct columns: fits ONE record
     val = oracle.hash_val(int(rp[-1]), seed=3)
     B = oracle.hash_B(K, 8, seed=4)
     for perm in (np.arange(M, dtype=np.int32), rng.permutation(M).astype(np.int32)):
-        for target in (0, 16):
+        for target in (0, 8):
             recs, src = _records(_lib.lib, rp, ci, M, K, perm, target)
             got = _interpret_records(recs, src, val, B, M)
             ref = oracle.spmm(rp, ci, val, B, "fma")
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), target
             got_u = _interpret_records(recs, src, None, B, M)
             assert np.array_equal(got_u.view(np.uint32), oracle.spmm(rp, ci, None, B, "golden").view(np.uint32))
-    # the 64-entry row over 20 columns sits in a single record; the 300-entry row in a chain
     recs, _ = _records(_lib.lib, rp, ci, M, K, np.arange(M, dtype=np.int32), 0)
-    kinds = recs[:, 3]
-    assert kinds.max() >= 5 and (kinds == -1).sum() >= 5
+    flags = recs[:, 3]
+    assert (flags == 3).sum() >= 5 and (flags == 2).sum() >= 2 and (flags == 1).sum() == (flags == 2).sum()
+    # row 7 (32 entries, <= 10 distinct columns) sits in ONE ordinary record of its own or with neighbours
+    assert any(int(r[3]) == 0 and 7 in r[4:4 + int(r[0])].tolist() for r in recs)
