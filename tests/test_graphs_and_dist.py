@@ -99,6 +99,28 @@ def _worker(rank, world, port, tmpdir):
     Bb = gdist.broadcast_dense(torch.from_numpy(Bfull_ref) if rank == 1 else None, G["K"], N, src=1)
     assert np.array_equal(Bb.numpy(), Bfull_ref)
 
+    # (c) the column-panel pipeline (exchange inside the product): each rank owns K/world rows of B, panels travel by
+    #     all-gather, the shard product of every panel (oracle as checker on the host) == the columns of the full product
+    pcounts = [(G["K"] * (r + 1)) // world - (G["K"] * r) // world for r in range(world)]
+    kk0 = sum(pcounts[:rank])
+    mine_rows = torch.from_numpy(Bfull_ref[kk0:kk0 + pcounts[rank]].copy())
+    widths = [8, 8, 5, 3]
+    assert sum(widths) == N
+    cols = np.concatenate([[0], np.cumsum(widths)])
+    gdist._MAX_ELEMS = 5000  # force the row-chunked staging path of the all-gather (a real run chunks at 2^31 elements)
+
+    def host_product(rowptr_, colind_, val_, Bp, out):
+        out.copy_(torch.from_numpy(oracle_py.spmm(rowptr_.numpy(), colind_.numpy(), val_.numpy(), Bp.numpy(), "fma")))
+        return out
+
+    pipe = gdist.PanelPipeline(torch.from_numpy(lptr), torch.from_numpy(lcol), torch.from_numpy(lval), G["K"], pcounts,
+                               widths, "cpu", product=host_product)
+    Cp = pipe.run([mine_rows[:, cols[i]:cols[i + 1]].contiguous() for i in range(len(widths))])
+    C_cols = oracle_py.spmm(lptr, lcol, lval, Bfull_ref, "fma")
+    for i in range(len(widths)):
+        assert np.array_equal(Cp[i].numpy().view(np.uint32), C_cols[:, cols[i]:cols[i + 1]].copy().view(np.uint32)), i
+    gdist._MAX_ELEMS = (1 << 31) - 1024
+
     # shard product (oracle as checker) == the same rows of the full product
     C_loc = oracle_py.spmm(lptr, lcol, lval, Bfull.numpy(), "fma")
     C_ref = oracle_py.spmm(G["rowptr"], G["colind"], val, Bfull_ref, "fma")
