@@ -54,21 +54,26 @@ def load_edges(dataset, device):
 
 
 def proc(edge_index, n_v, device, add_self_loop=True):
-    """gcn_custom.py:29-49."""
+    """Both index orders of the (self-looped) graph, under the key names the reference's caller uses
+    (gcn_custom.py:29-49: `colptr`/`rowind` hold the source-major order, `rowptr`/`colind` the destination-major one,
+    so the forward product aggregates over in-neighbours). Built on the device: one stable sort per order; duplicate
+    edges add up like scipy's COO -> CSR conversion does."""
+    ei = torch.as_tensor(edge_index, dtype=torch.int64, device=device)
     if add_self_loop:
-        loops = np.array([np.arange(n_v).astype(np.int32)] * 2)
-        edge_index = np.concatenate((edge_index, loops), axis=1)
-    n_e = edge_index.shape[1]
-    adj = scpsp.coo_matrix((np.ones(n_e), (edge_index[0], edge_index[1])), shape=(n_v, n_v))
+        ids = torch.arange(n_v, dtype=torch.int64, device=device)
+        ei = torch.cat([ei, torch.stack([ids, ids])], dim=1)
+
+    def compressed(major, minor):
+        key, inverse = torch.unique(major * n_v + minor, sorted=True, return_inverse=True)
+        weight = torch.zeros(key.numel(), dtype=torch.float32, device=device).index_add_(
+            0, inverse, torch.ones(inverse.numel(), dtype=torch.float32, device=device))
+        ptr = torch.zeros(n_v + 1, dtype=torch.int64, device=device)
+        ptr[1:] = torch.cumsum(torch.bincount(key // n_v, minlength=n_v), 0)
+        return ptr.to(torch.int32), (key % n_v).to(torch.int32), weight
+
     g = {}
-    adj = adj.tocsr()
-    g["colptr"] = torch.tensor(adj.indptr, dtype=torch.int32).to(device)
-    g["rowind"] = torch.tensor(adj.indices, dtype=torch.int32).to(device)
-    g["value_csc"] = torch.tensor(adj.data).to(device).float()
-    adj = adj.tocsc()
-    g["rowptr"] = torch.tensor(adj.indptr, dtype=torch.int32).to(device)
-    g["colind"] = torch.tensor(adj.indices, dtype=torch.int32).to(device)
-    g["value_csr"] = torch.tensor(adj.data).to(device).float()
+    g["colptr"], g["rowind"], g["value_csc"] = compressed(ei[0], ei[1])
+    g["rowptr"], g["colind"], g["value_csr"] = compressed(ei[1], ei[0])
     return g
 
 

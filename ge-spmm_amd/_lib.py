@@ -43,6 +43,7 @@ EXPORTS = [
     "gespmm_describe_launch",
     "gespmm_dgl_csrmm_sum_f32",
     "gespmm_dgl_csrmm_max_f32",
+    "gespmm_dgl_set_readback_rows",
     "gespmm_csr_spmm_f32_cfg",
     "gespmm_csr_spmm_workspace_bytes",
     "gespmm_csr_spmm_f32_ws",
@@ -124,6 +125,8 @@ def _load():
     for fn in (lib.gespmm_dgl_csrmm_sum_f32, lib.gespmm_dgl_csrmm_max_f32):
         fn.restype = c_int
         fn.argtypes = [c_int, c_int, p, p, p, p, p]
+    lib.gespmm_dgl_set_readback_rows.restype = c_int
+    lib.gespmm_dgl_set_readback_rows.argtypes = [c_int64]
     lib.gespmm_describe_launch.restype = c_int
     lib.gespmm_describe_launch.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(LaunchCfg), c_char_p, c_int64]
     lib.gespmm_select_variant.restype = c_int

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -275,6 +276,15 @@ int gespmm_describe_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, int var
 // kernel anyway, binary_reduce_sum.cu:358) buys the dense-graph and long-row paths: reddit-shaped,
 // N=128: 8.3 -> 4.2 ms. The number of source nodes is taken as m for the slab count only (columns beyond
 // it fall into the last slab — same result), offsets into B stay 64-bit. Not on a capturing stream.
+// Rows from which the DGL entry points read nnz back (a stream synchronisation); < 0 = never. Process-wide, set
+// once at start-up by the integrator (gespmm_dgl_set_readback_rows).
+static std::atomic<int64_t> g_dgl_readback_rows{1 << 15};
+
+int gespmm_dgl_set_readback_rows(int64_t rows) {
+    g_dgl_readback_rows.store(rows, std::memory_order_relaxed);
+    return 0;
+}
+
 static int dgl_csrmm(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C, int reduce,
                      float empty, void* stream) {
     int64_t nnz = -1, K = 0x7fffffffLL;
@@ -282,7 +292,8 @@ static int dgl_csrmm(int m, int n, const int32_t* indptr, const int32_t* indices
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
-    if (!capturing && m >= (1 << 15) && indptr) {
+    const int64_t rb_rows = g_dgl_readback_rows.load(std::memory_order_relaxed);
+    if (!capturing && rb_rows >= 0 && m >= rb_rows && indptr) {
         int32_t last = -1;
         if (hipMemcpyAsync(&last, indptr + m, sizeof last, hipMemcpyDeviceToHost, st) == hipSuccess &&
             hipStreamSynchronize(st) == hipSuccess && last >= 0) {

@@ -29,11 +29,15 @@ namespace {
 constexpr int64_t kAlign = 256;
 inline int64_t align_up(int64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
+// Column indices are the caller's and are NOT validated against K anywhere else on the device (the SpMM / SDDMM
+// kernels trust them, as the reference's do); here an index outside [0, K) would be an out-of-bounds atomic on
+// colptr, so such entries are simply not counted (the transpose of a malformed matrix is then short, not corrupt).
 __global__ void k_hist_iota(const int32_t* __restrict__ colind, int32_t* __restrict__ colptr,
-                            int32_t* __restrict__ iota, int nnz) {
+                            int32_t* __restrict__ iota, int nnz, int K) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < nnz) {
-        atomicAdd(&colptr[colind[p] + 1], 1);
+        const int c = colind[p];
+        if ((uint32_t)c < (uint32_t)K) atomicAdd(&colptr[c + 1], 1);
         iota[p] = p;
     }
 }
@@ -101,7 +105,7 @@ hipError_t launch_csr2csc(const int32_t* rowptr, const int32_t* colind, const fl
 
     const int threads = 256;
     const int blocks = (int)((nnz + threads - 1) / threads);
-    hipLaunchKernelGGL(k_hist_iota, dim3(blocks), dim3(threads), 0, st, colind, colptr, iota, (int)nnz);
+    hipLaunchKernelGGL(k_hist_iota, dim3(blocks), dim3(threads), 0, st, colind, colptr, iota, (int)nnz, (int)K);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 
     size_t tb = scan_temp_bytes(K);

@@ -34,6 +34,8 @@
 #include <string>
 #include <thread>
 #include <algorithm>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "../../include/gespmm.h"
@@ -151,9 +153,25 @@ void gespmm_mtx_free(gespmm_coo* coo) {
     coo->nnz = 0;
 }
 
+static int mtx_read_impl(const char* path, gespmm_coo* out);
+
+// The C boundary never lets a C++ exception through (a size line that promises 10^9 entries must be
+// GESPMM_ENOMEM, not std::terminate) and never exits.
 int gespmm_mtx_read(const char* path, gespmm_coo* out) {
     if (!path || !out) return GESPMM_EINVAL;
     memset(out, 0, sizeof *out);
+    try {
+        return mtx_read_impl(path, out);
+    } catch (const std::bad_alloc&) {
+        gespmm_mtx_free(out);
+        return GESPMM_ENOMEM;
+    } catch (const std::exception&) {  // std::system_error from std::thread, length_error from a vector
+        gespmm_mtx_free(out);
+        return GESPMM_ENOMEM;
+    }
+}
+
+static int mtx_read_impl(const char* path, gespmm_coo* out) {
 
     FILE* f = fopen(path, "rb");
     if (!f) return GESPMM_EIO;
@@ -217,9 +235,11 @@ int gespmm_mtx_read(const char* path, gespmm_coo* out) {
     // in the reference ("Error: not enough rows in mtx file." and carry on).
     std::vector<int32_t> row, col;
     std::vector<float> val;
-    row.reserve((size_t)NZ * (symmetric ? 2 : 1));
-    col.reserve((size_t)NZ * (symmetric ? 2 : 1));
-    val.reserve((size_t)NZ * (symmetric ? 2 : 1));
+    // (an entry takes at least four bytes of text — "1 1\n" — so the file size bounds what the size line may promise)
+    const long long nz_cap = std::min<long long>(NZ, (long long)(buf.size() / 4) + 1);
+    row.reserve((size_t)nz_cap * (symmetric ? 2 : 1));
+    col.reserve((size_t)nz_cap * (symmetric ? 2 : 1));
+    val.reserve((size_t)nz_cap * (symmetric ? 2 : 1));
     // One entry: two 1-based indices and, unless `pattern`, a value. 0 = ok, 1 = clean end of input,
     // <0 = malformed.
     auto parse_entry = [field](Cursor& c, int32_t* r0, int32_t* c0, float* v0) -> int {
@@ -270,7 +290,7 @@ int gespmm_mtx_read(const char* path, gespmm_coo* out) {
             for (unsigned t = 0; t < nthr; ++t)
                 pool.emplace_back([&, t]() {
                     Cursor c{cut[t], cut[t + 1]};
-                    const size_t guess = (size_t)NZ / nthr + 1024;
+                    const size_t guess = (size_t)nz_cap / nthr + 1024;
                     prow[t].reserve(guess);
                     pcol[t].reserve(guess);
                     pval[t].reserve(guess);
@@ -320,6 +340,11 @@ int gespmm_mtx_read(const char* path, gespmm_coo* out) {
         col.push_back(c0);
         val.push_back(v0);
     }
+
+    // ---- an index beyond the size line's M x K is a malformed file (the reference only notices in its COO->CSR
+    //      loop, "out of bound row/column", spmm_test.cu:563,571, after the damage is done)
+    for (size_t i = 0; i < row.size(); ++i)
+        if ((long long)row[i] >= M || (long long)col[i] >= K) return GESPMM_EFORMAT;
 
     // ---- symmetric expansion (util.hpp:218-284)
     if (symmetric) {

@@ -1281,8 +1281,11 @@ static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {
     // HIP caps a launch at 2^32 threads (gridDim.x * blockDim.x): with 256-thread workgroups that is
     // kMaxGridBlocks workgroups. Tasks grow until the grid fits (M = 2^26 rows: >= 2 rows per task).
     while (rpw < kMaxRowsPerWave &&
-           (((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw)) * args.ntile > kMaxGridBlocks)
-        rpw *= 2;
+           (((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw)) * args.ntile > kMaxGridBlocks) {
+        rpw *= 2;  // (never past the kernel's row-pointer staging, whatever the caller's rows_per_wave was)
+        if (rpw > kMaxRowsPerWave) rpw = kMaxRowsPerWave;
+        rpw = rpw / G * G;
+    }
     args.rpw = rpw;
     args.nblk = (int)(((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw));
     if (a.tasks) args.nblk = (a.ntasks + kWaves - 1) / kWaves;  // plan mode: one wavefront per task

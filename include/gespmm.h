@@ -37,7 +37,10 @@
  *     negative GESPMM_E* codes below; the library never calls exit();
  *   - re-entrant; the only global state is cached, immutable device properties and one memory
  *     pool per device for stream-ordered temporaries (created on first use);
- *   - the device that owns `stream` and the pointers is the calling thread's current device.
+ *   - the device that owns `stream` and the pointers is the calling thread's current device;
+ *   - index RANGES are the caller's responsibility, as in the reference: rowptr must be non-decreasing with
+ *     rowptr[M] = nnz and every colind entry must lie in [0, K). The device kernels do not check (a check would cost
+ *     a pass over the matrix per call); the host-side entry points (loader, COO->CSR, plans) do.
  *
  * There is NO CPU fallback: without a HIP device every compute entry point
  * returns the HIP error (hipErrorNoDevice = 100).
@@ -202,7 +205,11 @@ int gespmm_describe_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, int var
  * strict CSR-order chain for every row. Rows without neighbours give 0 (sum) or -10000 (max: the patch's
  * max_init, binary_reduce_max.cu:22-24). Returns 0 or an error code as above (the patch returns
  * its cudaError the same way).
+ * The read-back is a policy, not part of the product: gespmm_dgl_set_readback_rows(rows) moves the threshold
+ * (process-wide; rows < 0 = never synchronise: every call is then fully asynchronous and every row a strict chain;
+ * 0 = always). On a stream under capture the entry points never read back, whatever the threshold.
  */
+int gespmm_dgl_set_readback_rows(int64_t rows);
 int gespmm_dgl_csrmm_sum_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,
                              void* stream);
 int gespmm_dgl_csrmm_max_f32(int m, int n, const int32_t* indptr, const int32_t* indices, const float* B, float* C,

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from the rocprofv3 PMC summaries (scripts/gpu_pmc.sh): bytes per launch =
+2 * FETCH_SIZE + WRITE_SIZE (KiB -> B; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads,
+MI355X_MICROARCH.md HBM section), L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS).
+usage: update_traffic_json.py key=summary.csv [key=summary.csv ...]"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+data = json.load(open(path)) if os.path.exists(path) else {}
+for arg in sys.argv[1:]:
+    key, f = arg.split("=", 1)
+    c = {}
+    for r in csv.DictReader(open(f)):
+        c[r["counter"]] = float(r["mean_per_dispatch"])
+        kern = r["kernel"]
+    entry = {
+        "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+        "bytes_per_launch": int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)),
+        "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4),
+        "kernel": kern,
+        "source": "%s (2*FETCH_SIZE + WRITE_SIZE, KiB->B; separate --pmc passes of `python bench.py --no-extra --no-cpu-baseline "
+                  "--steps 50 --warmup 5 ...`; memory-side requests include Infinity-Cache hits)" % os.path.relpath(f, ROOT),
+    }
+    data[key] = entry
+    print(key, entry["bytes_per_launch"], entry["l2_hit_rate"])
+json.dump(data, open(path, "w"), indent=1)

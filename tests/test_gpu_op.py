@@ -12,19 +12,35 @@ pytestmark = pytest.mark.gpu
 
 
 def proc_like_reference(edge_index, n_v, add_self_loop=True):
-    """gcn_custom.py:29-49 with scipy, returning host arrays."""
+    """Host-side restatement of what the reference's caller hands the op (gcn_custom.py:29-49): A = adjacency of
+    (src, dst) pairs plus the identity, duplicates summed; `colptr/rowind/value_csc` describe A row-major (by source),
+    `rowptr/colind/value_csr` describe A^T row-major (by destination). Returns host arrays and the dense A."""
+    src, dst = np.asarray(edge_index[0], np.int64), np.asarray(edge_index[1], np.int64)
+    A = sp.csr_matrix((np.ones(src.size), (src, dst)), shape=(n_v, n_v))
     if add_self_loop:
-        loops = np.array([np.arange(n_v).astype(np.int32)] * 2)
-        edge_index = np.concatenate((edge_index, loops), axis=1)
-    n_e = edge_index.shape[1]
-    adj = sp.coo_matrix((np.ones(n_e), (edge_index[0], edge_index[1])), shape=(n_v, n_v))
-    g = {}
-    csr = adj.tocsr()
-    g["colptr"], g["rowind"], g["value_csc"] = csr.indptr, csr.indices, csr.data.astype(np.float32)
-    csc = adj.tocsc()
-    g["rowptr"], g["colind"], g["value_csr"] = csc.indptr, csc.indices, csc.data.astype(np.float32)
-    g["dense"] = adj.toarray().astype(np.float64)
-    return g
+        A = A + sp.identity(n_v, format="csr")
+    A.sum_duplicates()
+    A.sort_indices()
+    At = A.T.tocsr()
+    At.sort_indices()
+    return {"colptr": A.indptr, "rowind": A.indices, "value_csc": A.data.astype(np.float32),
+            "rowptr": At.indptr, "colind": At.indices, "value_csr": At.data.astype(np.float32),
+            "dense": A.toarray().astype(np.float64)}
+
+
+def test_example_proc_builds_the_same_operands(graph):
+    """examples/gcn_custom.py builds both index orders on the device with torch ops; same arrays as the scipy route."""
+    import importlib.util
+    import os
+
+    from helpers import ROOT
+
+    spec = importlib.util.spec_from_file_location("gcn_example", os.path.join(ROOT, "examples", "gcn_custom.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = mod.proc(graph["edge_index"], graph["n_v"], "cuda")
+    for k in ("colptr", "rowind", "value_csc", "rowptr", "colind", "value_csr"):
+        assert np.array_equal(g[k].cpu().numpy(), graph[k]), k
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +57,7 @@ def graph():
     g["value_csr_d"] = torch.from_numpy(g["value_csr"]).cuda()
     g["value_csc_d"] = torch.from_numpy(g["value_csc"]).cuda()
     g["n_v"] = n_v
+    g["edge_index"] = ei
     return g
 
 

@@ -277,6 +277,18 @@ def test_dgl_entry_points(pkg, oracle, bundled):
             assert rc == 0
             torch.cuda.synchronize()
             assert_bits_equal(out.cpu().numpy(), oracle.spmm_max(G["rowptr"], G["colind"], B), "dgl max")
+    # the read-back threshold is a process-wide policy: "never" keeps every call asynchronous (strict chains), same bits here
+    G = bundled["cora"]
+    rp, ci = dev_csr(G)
+    B = oracle.hash_B(G["K"], 64, seed=1)
+    Bd = torch.from_numpy(B).cuda()
+    out = torch.empty(G["M"], 64, dtype=torch.float32, device="cuda")
+    for rows in (-1, 0, 1 << 15):
+        assert _lib.lib.gespmm_dgl_set_readback_rows(rows) == 0
+        assert _lib.lib.gespmm_dgl_csrmm_sum_f32(G["M"], 64, rp.data_ptr(), ci.data_ptr(), Bd.data_ptr(), out.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert_bits_equal(out.cpu().numpy(), oracle.spmm(G["rowptr"], G["colind"], None, B, "golden"), "dgl sum, readback %d" % rows)
     # a large dense graph: the entry point reads nnz back and takes the cache-blocked path (K taken as m)
     from gespmm_amd import spmm
 

@@ -204,3 +204,20 @@ def test_binary_cache_round_trip(pkg, tmp_path):
     assert graphs.read_mtx(os.path.join(GOLDEN, "cora.mtx"), cache_dir=tmp_path / "does_not_exist")["nnz"] == 10556
     with pytest.raises(_lib.GespmmError):
         graphs.read_mtx(tmp_path / "missing.mtx", cache_dir=cache)
+
+
+def test_loader_never_throws_across_the_c_boundary(pkg, tmp_path):
+    """A size line that promises 10^9 entries in a 60-byte file must not reserve 24 GB (or std::terminate): the file
+    size bounds the reservation and the missing entries are the reference's "not enough rows" case; an index outside
+    the declared M x K is a malformed file, not a later out-of-bounds write."""
+    from gespmm_amd import _lib, graphs
+
+    p = tmp_path / "huge_promise.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n5 5 1000000000\n1 2\n3 4\n")
+    coo = graphs.read_mtx(str(p))
+    assert coo["nnz"] == 2 and list(coo["row"]) == [0, 2] and list(coo["col"]) == [1, 3]
+    q = tmp_path / "out_of_range.mtx"
+    q.write_text("%%MatrixMarket matrix coordinate pattern general\n3 3 2\n1 2\n4 1\n")
+    with pytest.raises(_lib.GespmmError) as e:
+        graphs.read_mtx(str(q))
+    assert e.value.code == -5  # GESPMM_EFORMAT
