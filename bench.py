@@ -293,17 +293,36 @@ def main():
             extra["reddit-like_N%d_valued" % N] = r2
             del g2, val2, B2, C2, plan2, step2
 
-            # ---- BASELINE configs[2]: products-shaped, N in {16..512}, the library's own choice per width
-            torch.cuda.empty_cache()
-            g3 = graphs.synthetic_graph("products-like", seed=42, device=dev)
-            val3 = torch.rand(g3["nnz"], device=dev) - 0.5
-            sweep = {}
-            for n3 in (16, 32, 64, 128, 256, 512):
+            # ---- BASELINE configs[2]: products-shaped, N in {16..512}, the library's own choice per width — on the
+            #      structureless stand-in and on the planted-community one (ids shuffled); ONE plan per graph (made for
+            #      N = 128: the clustering does not depend on the width) serves the whole sweep
+            for pname in ("products-like", "products-sbm"):
                 torch.cuda.empty_cache()
-                r3 = measure_graph(g3, val3, n3, True, use_plan=False, samples=10)
-                sweep["N%d" % n3] = {k: r3[k] for k in ("kernel_us", "gflops", "achieved_GBs", "frac", "roof_gflops")}
-            extra["products-like_sweep_valued"] = sweep
-            del g3, val3
+                g3 = graphs.synthetic_graph(pname, seed=42, device=dev)
+                val3 = torch.rand(g3["nnz"], device=dev) - 0.5
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                plan3 = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], 128, values=val3)
+                torch.cuda.synchronize()
+                sweep = {"plan_ms": (time.perf_counter() - t0) * 1e3, "plan": plan3.describe()}
+                for n3 in (16, 32, 64, 128, 256, 512):
+                    torch.cuda.empty_cache()
+                    B3 = make_B(g3["K"], n3)
+                    C3 = torch.empty((g3["M"], n3), dtype=torch.float32, device=dev)
+                    ab3 = algorithmic_bytes(g3["M"], g3["K"], n3, g3["nnz"], True)
+                    row = {"roof_gflops": roof_gflops(g3["M"], g3["K"], n3, g3["nnz"], True)}
+                    for label, pl in (("plain", None), ("plan", plan3)):
+                        def st3():
+                            spmm.csr_spmm(g3["rowptr"], g3["colind"], val3, B3, variant=args.variant, out=C3, plan=pl)
+                        for _ in range(2):
+                            st3()
+                        med3 = statistics.median(kernel_times_us(st3, 10))
+                        row[label] = {"kernel_us": med3, "gflops": 2.0 * g3["nnz"] * n3 / med3 / 1e3,
+                                      "achieved_GBs": ab3 / med3 / 1e3, "frac": ab3 / med3 / 1e3 / HBM_PEAK_GBS}
+                    sweep["N%d" % n3] = row
+                    del B3, C3
+                extra["%s_sweep_valued" % pname] = sweep
+                del g3, val3, plan3
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -404,11 +404,14 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
             // A model of the XCD L2s says whether the new order is worth having (graphs whose storage order is
             // already local, or that have no structure to find, keep their order and pay nothing per launch).
-            if (nnz <= (1ll << 25)) {
-                const int64_t window = (3ll << 20) / (4 * (N < tile_cols ? N : tile_cols) > 0 ? 4 * (N < tile_cols ? N : tile_cols) : 4);
-                p->hits_before = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), nullptr, 8, window);
-                p->hits_after = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), p->perm_host.data(), 8, window);
-                if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && p->hits_after < p->hits_before + 0.03) reorder = false;
+            {
+                // (matrices beyond 2^25 non-zeros: the first 2^22 non-zeros of each of the 8 slices are the sample)
+                const int64_t sample = nnz <= (1ll << 25) ? 0 : (1ll << 22);
+                const int64_t rowb = 4 * (N < tile_cols ? N : tile_cols);
+                const int64_t window = (3ll << 20) / (rowb > 0 ? rowb : 4);
+                p->hits_before = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), nullptr, 8, window, sample);
+                p->hits_after = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), p->perm_host.data(), 8, window, sample);
+                if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && p->hits_after < p->hits_before + 0.05) reorder = false;
             }
         }
         if (reorder) {

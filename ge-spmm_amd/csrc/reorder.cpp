@@ -303,9 +303,10 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
 // Distinct-column share of a processing order under an LRU of `window` B rows per slice (the model of
 // the per-XCD L2 used in DESIGN.md): returns the fraction of non-zeros whose B row is already resident.
 double simulate_l2_hits(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* colind, const int32_t* perm,
-                        int slices, int64_t window) {
+                        int slices, int64_t window, int64_t max_entries_per_slice) {
     const int64_t nnz = rowptr[M];
     if (nnz == 0 || K <= 0) return 0.0;
+    int64_t simulated = 0;
     // exact LRU with a time-stamp array and a ring of (stamp, column) — an entry is live if its stamp is current
     int64_t hits = 0;
     std::vector<int64_t> cuts((size_t)slices + 1, M);
@@ -327,7 +328,9 @@ double simulate_l2_hits(int64_t M, int64_t K, const int32_t* rowptr, const int32
         size_t head = 0;
         int64_t live = 0, now = 0;
         for (int64_t i = cuts[s]; i < cuts[s + 1]; ++i) {
+            if (max_entries_per_slice > 0 && now >= max_entries_per_slice) break;  // a prefix of the slice is a fair sample
             const int32_t r = perm ? perm[i] : (int32_t)i;
+            simulated += rowptr[r + 1] - rowptr[r];
             for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
                 const int32_t c = colind[p];
                 if (c < 0 || c >= K) continue;
@@ -346,7 +349,7 @@ double simulate_l2_hits(int64_t M, int64_t K, const int32_t* rowptr, const int32
             }
         }
     }
-    return (double)hits / (double)nnz;
+    return simulated > 0 ? (double)hits / (double)simulated : 0.0;
 }
 
 }  // namespace gespmm

@@ -24,7 +24,8 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
 // Model of the per-XCD L2: rows processed in `perm` order (NULL = storage order), cut into `slices`
 // contiguous parts of equal non-zero count, each with an LRU of `window` B rows. Returns the share of
 // non-zeros whose B row is resident when it is gathered.
+// max_entries_per_slice > 0: only that many non-zeros at the head of every slice are simulated (large matrices).
 double simulate_l2_hits(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* colind, const int32_t* perm,
-                        int slices, int64_t window);
+                        int slices, int64_t window, int64_t max_entries_per_slice = 0);
 
 }  // namespace gespmm
