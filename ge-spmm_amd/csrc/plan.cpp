@@ -551,7 +551,14 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     } else if (p->reordered) {
         // segmented-stream kernel where the rows are short and the clustered order hits L2 (its continuous gather stream
         // hides the mixed hit/miss latencies better); batch-stream kernel otherwise and whenever long rows are split
-        const bool seg = p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM;  // opt-in: measured behind the batch kernel
+        // segmented-stream kernel (one continuous gather stream per lane group): ahead of the batch kernel on
+        // clustered matrices with longer rows at one 128-column tile (products-shaped communities, N = 128: 3.70 vs
+        // 4.34 ms), behind it on short rows (com-Amazon-shaped: 118 vs 108 us) and at the other tile widths
+        // (profiles/r02/plan_products_kernels.log)
+        const int64_t mean_deg = p->M > 0 ? p->nnz / p->M : 0;
+        const bool seg = p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM ||
+                         (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean_deg >= 16 && p->hits_after >= 0.40 && N > 64 &&
+                          N <= 128 && N % 4 == 0);
         gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
                               p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
