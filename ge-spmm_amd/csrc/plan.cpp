@@ -531,8 +531,8 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
                             p->variant == GESPMM_VARIANT_CRC_CWM8;
     bool lds_rows = p->reordered && p->d_recs && p->nrec > 0 && gespmm::ldsrow_group_width(N) > 0 && variant_v4 &&
                     (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-    // opt-in (GESPMM_PLAN_KERNEL_LDS_ROWS): 118 us vs 112 us for the batch-stream kernel on the clustered bench graph —
-    // its persistent wavefronts are instruction-issue bound at the 8 wavefronts per CU its LDS footprint allows
+    // opt-in (GESPMM_PLAN_KERNEL_LDS_ROWS): 118-128 us vs 108-113 us for the batch-stream kernel on the clustered bench
+    // graph — its sums are instruction-issue bound at the 8 wavefronts per CU its LDS footprint allows
     if (lds_rows && p->kernel_choice != GESPMM_PLAN_KERNEL_LDS_ROWS) lds_rows = false;
     if (lds_rows) {
         if (!B || !C) return GESPMM_EINVAL;

@@ -11,14 +11,14 @@
 //   * every distinct B row of a record is fetched ONCE, straight into LDS (gfx950 `global_load_lds_dwordx4`: no
 //     VGPR staging; 64/W rows per instruction, all of a record's fetches in flight together);
 //   * wavefronts are PERSISTENT and pipelined: while record i is summed out of one LDS buffer, the row fetches of
-//     record i+1 land in the other, the description of record i+2 is on its way, and the C rows of record i-1 are
-//     being written (they stay in registers for one iteration so that no wait ever covers a fresh store);
+//     record i+1 land in the other and the description of record i+2 is on its way;
 //   * records are dealt round-robin to the wavefronts of an XCD inside that XCD's contiguous slice of the clustered
 //     order, so at any moment an XCD works on a narrow window of neighbouring clusters — what keeps the shared B
 //     rows in its L2; a long row is a CHAIN of records walked by the wavefront that owns the first of them (it
 //     carries the accumulator from record to record; the owners of the other records skip them);
-//   * the W-lane groups of a wavefront walk the record's rows; each output element is ONE fp32 chain over the
-//     row's non-zeros in CSR order with one fused multiply-add per non-zero — the arithmetic of every other
+//   * each W-lane group of a wavefront takes a contiguous share of the record's rows and walks their entries as one
+//     stream (four LDS row reads in flight), storing a row the moment it ends; each output element is ONE fp32 chain
+//     over the row's non-zeros in CSR order with one fused multiply-add per non-zero — the arithmetic of every other
 //     variant (spmm_test.cu:182-203 semantics), so the bits are unchanged.
 //
 // Column tiles are 4W floats (W = 4..32 lanes x dwordx4); wider N takes several tiles. N must be a multiple of 4;
@@ -70,14 +70,13 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
     constexpr int G = 64 / W;                 // lane groups per wavefront = B rows fetched per instruction
     constexpr int ROWB = W * 16;              // bytes of one staged row (this column tile)
     constexpr int BUFB = kRecDistinct * ROWB; // one LDS buffer
-    constexpr int RS = (kRecRows + G - 1) / G;  // row slots per lane group
     using off_t = typename std::conditional<IDX64, uint64_t, uint32_t>::type;
 
-    __shared__ __attribute__((aligned(16))) char s_rows[kWaves][2][BUFB];
-    __shared__ int s_off[kWaves][kRecEntries];
-    __shared__ float s_val[VALUED ? kWaves : 1][VALUED ? kRecEntries : 1];
-    __shared__ int s_rp[kWaves][32];
-    __shared__ int s_crow[kWaves][kRecRows];
+    // ONE __shared__ object, carved by hand (a second object makes hipcc drain the LDS-DMA queue before every LDS read:
+    // cdna_hip_programming.md, ".s-level traps"): per wavefront two row buffers, then the record's description
+    constexpr int META = kRecEntries * 4 * 2 + 32 * 4 + kRecRows * 4;  // s_off, s_val, s_rp, s_crow
+    constexpr int WAVEB = 2 * BUFB + META;
+    __shared__ __attribute__((aligned(16))) char s_all[kWaves * WAVEB];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -91,6 +90,12 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
     const int nwx = a.nblk * kWaves;  // wavefronts per XCD (and tile)
     const int lw = slot * kWaves + wave;
     const int x0 = (int)((int64_t)a.nrec * xcd / 8), x1 = (int)((int64_t)a.nrec * (xcd + 1) / 8);
+
+    char* const my_lds = s_all + wave * WAVEB;
+    int* const s_off = reinterpret_cast<int*>(my_lds + 2 * BUFB);
+    float* const s_val = reinterpret_cast<float*>(my_lds + 2 * BUFB + kRecEntries * 4);
+    int* const s_rp = reinterpret_cast<int*>(my_lds + 2 * BUFB + kRecEntries * 8);
+    int* const s_crow = reinterpret_cast<int*>(my_lds + 2 * BUFB + kRecEntries * 8 + 32 * 4);
 
     const int col0 = tile * (W * 4) + l * 4;
     const bool colok = col0 < a.N;  // N % 4 == 0: a lane's four columns are in range together
@@ -106,13 +111,20 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
     if (own0 >= x1) return;
 
     auto issue_rows = [&](const RecRegs& r, int buf) {
-        char* dst = s_rows[wave][buf];
-        for (int j = 0; j < r.ndist; j += G) {
-            const int c = __shfl(r.w, kRecRows + ((j + g) & (kRecDistinct - 1)), 64);
-            if (j + g < r.ndist && colok) {
-                const char* src = Bbase + (off_t)((off_t)(uint32_t)c * rowbytes + cbyte);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + j * ROWB), 16, 0, 0);
+        char* dst = my_lds + buf * BUFB;
+        constexpr int T = kRecDistinct / G > 0 ? kRecDistinct / G : 1;  // fetch instructions per record
+        int cj[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)  // all column ids first (cross-lane reads back to back), then the fetches
+            cj[t] = __shfl(r.w, kRecRows + ((t * G + g) & (kRecDistinct - 1)), 64);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (t * G < r.ndist) {  // wave-uniform
+                if (t * G + g < r.ndist && colok) {
+                    const char* src = Bbase + (off_t)((off_t)(uint32_t)cj[t] * rowbytes + cbyte);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + t * G * ROWB), 16, 0, 0);
+                }
             }
         }
     };
@@ -146,20 +158,12 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
     if (idx1 >= 0) load_record(a.recs, idx1, lane, m1);
     if (!(a.debug & 1)) issue_rows(m0, 0);
 
-    float acc[RS][4];    // running sums of this record's rows (a chained row keeps slot 0 across records)
-    float outv[RS][4];   // finished rows of the PREVIOUS record, stored one iteration late
-    int outrow[RS];
-#pragma unroll
-    for (int s = 0; s < RS; ++s) {
-        outrow[s] = -1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[s][i] = init;
-    }
+    float carry[4] = {init, init, init, init};  // running sum of a chained row between its records
 
     int buf = 0;
     for (;;) {
-        // ---- everything issued during the previous iteration has had one whole iteration to arrive: the rows of m0,
-        //      the description of m1, the C rows of the record before m0
+        // ---- everything issued during the previous iteration has had one whole iteration to arrive: the rows of m0 and
+        //      the description of m1 (C rows are stored as they finish; the youngest of them are the price of this wait)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         int own_c = own_b, idx2 = -1;  // cursor of m2
@@ -169,74 +173,72 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
             advance(own_c, idx2, m1.flags);
             if (idx2 >= 0) load_record(a.recs, idx2, lane, m2);  // two records ahead
         }
-        // ---- C rows of the previous record leave now, then the row fetches of the next record
-#pragma unroll
-        for (int s = 0; s < RS; ++s) {
-            if (outrow[s] >= 0 && colok && !(a.debug & 4)) {
-                float* dst = a.C + (size_t)outrow[s] * (size_t)a.N + col0;
-                f4 o4 = {outv[s][0], outv[s][1], outv[s][2], outv[s][3]};
-                *reinterpret_cast<f4*>(dst) = o4;
-            }
-            outrow[s] = -1;
-        }
         if (idx1 >= 0 && !(a.debug & 1)) issue_rows(m1, buf ^ 1);
-        // ---- sums of m0 out of LDS buffer `buf`
+        // ---- the description of m0 moves from the registers that loaded it to LDS, where every lane can index it
         const RecRegs& cur = m0;
-        const char* rows_lds = s_rows[wave][buf];
-        const bool from_prev = (cur.flags & 1) != 0;  // the (single) row continues from the previous record
-        const bool to_next = (cur.flags & 2) != 0;    // ... and into the next one
-        // the description of m0 moves from the registers that loaded it to LDS, where every lane can index it
-        if (lane < kRecEntries) s_off[wave][lane] = (cur.b & (kRecDistinct - 1)) * ROWB;
-        else s_rp[wave][lane - 32] = cur.b;  // lanes 32..48 carry the rows' first entries
-        if (lane < kRecRows) s_crow[wave][lane] = cur.w;
+        if (lane < kRecEntries) s_off[lane] = (cur.b & (kRecDistinct - 1)) * ROWB;
+        else s_rp[lane - 32] = cur.b;  // lanes 32..48 carry the rows' first entries
+        if (lane < kRecRows) s_crow[lane] = cur.w;
         if constexpr (VALUED) {
-            if (lane >= 32) s_val[wave][lane - 32] = __int_as_float(cur.w);
+            if (lane >= 32) s_val[lane - 32] = __int_as_float(cur.w);
         }
         wave_sync();
+        // ---- sums of m0 out of LDS buffer `buf`: lane group g takes the rows [g*R, (g+1)*R) and walks their entries as ONE
+        //      stream, four at a time; a finished row is stored at once
+        const char* rows_lds = my_lds + buf * BUFB;
+        const bool from_prev = (cur.flags & 1) != 0;  // the (single) row continues from the previous record
+        const bool to_next = (cur.flags & 2) != 0;    // ... and into the next one
+        const int R = (cur.nrows + G - 1) / G;
+        int r = g * R;
+        const int r1 = (r + R < cur.nrows) ? r + R : cur.nrows;
+        if (r < r1 && !(a.debug & 2)) {
+            int k = s_rp[r];
+            const int kend = s_rp[r1];
+            int end_cur = s_rp[r + 1];
+            float acc[4];
 #pragma unroll
-        for (int s = 0; s < RS; ++s) {
-            if (s * G >= cur.nrows || (a.debug & 2)) break;  // wave-uniform
-            const int r = s * G + g;
-            if (r < cur.nrows) {
-                const int lb = s_rp[wave][r], hb = s_rp[wave][r + 1];
-                if (!(from_prev && s == 0)) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[s][i] = init;
+            for (int i = 0; i < 4; ++i) acc[i] = from_prev ? carry[i] : init;
+            auto finish_row = [&]() {
+                if (colok && !(a.debug & 4)) {
+                    float* dst = a.C + (size_t)s_crow[r] * (size_t)a.N + col0;
+                    f4 o4 = {acc[0], acc[1], acc[2], acc[3]};
+                    *reinterpret_cast<f4*>(dst) = o4;
                 }
-                int k = lb;
-                for (; k + 4 <= hb; k += 4) {
-                    int o[4];
-                    float vv[4];
-                    f4 bb[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = s_off[wave][k + j];
-                        if constexpr (VALUED) vv[j] = s_val[wave][k + j];
-                        else vv[j] = 1.0f;
+                for (int i = 0; i < 4; ++i) acc[i] = init;
+                ++r;
+                end_cur = s_rp[r + 1];  // (r + 1 <= 16: inside the array)
+            };
+            for (; k < kend; k += 4) {
+                int o[4];
+                float vv[4];
+                f4 bb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kj = (k + j) & (kRecEntries - 1);
+                    o[j] = s_off[kj];
+                    if constexpr (VALUED) vv[j] = s_val[kj];
+                    else vv[j] = 1.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const f4*>(rows_lds + o[j] + l * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (k + j < kend) {
+                        while (k + j >= end_cur) finish_row();  // rows that end before this entry (empty ones included)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = combine1<RED, VALUED>(acc[i], vv[j], bb[j][i]);
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const f4*>(rows_lds + o[j] + l * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[s][i] = combine1<RED, VALUED>(acc[s][i], vv[j], bb[j][i]);
-                }
-                for (; k < hb; ++k) {
-                    const int o = s_off[wave][k];
-                    float vv = 1.0f;
-                    if constexpr (VALUED) vv = s_val[wave][k];
-                    const f4 bb = *reinterpret_cast<const f4*>(rows_lds + o + l * 16);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[s][i] = combine1<RED, VALUED>(acc[s][i], vv, bb[i]);
-                }
-                if (!(to_next && s == 0)) {
-                    outrow[s] = s_crow[wave][r];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) outv[s][i] = acc[s][i];
                 }
             }
+            if (to_next) {  // a chained row: its sum travels on to the next record
+#pragma unroll
+                for (int i = 0; i < 4; ++i) carry[i] = acc[i];
+            } else {
+                while (r < r1) finish_row();  // the last row and trailing empty rows
+            }
         }
-        wave_sync();  // this record's description is read before the next one overwrites it
+        wave_sync();  // this record's description and rows are read before the next iteration overwrites them
         if (idx1 < 0) break;
         m0 = m1;
         m1 = m2;
@@ -245,15 +247,6 @@ __global__ __launch_bounds__(kThreads) void spmm_ldsrow_kernel(LdsRowArgs a) {
         own_b = own_c;
         idx1 = idx2;
         buf ^= 1;
-    }
-    // ---- the last record's rows
-#pragma unroll
-    for (int s = 0; s < RS; ++s) {
-        if (outrow[s] >= 0 && colok && !(a.debug & 4)) {
-            float* dst = a.C + (size_t)outrow[s] * (size_t)a.N + col0;
-            f4 o4 = {outv[s][0], outv[s][1], outv[s][2], outv[s][3]};
-            *reinterpret_cast<f4*>(dst) = o4;
-        }
     }
 }
 
