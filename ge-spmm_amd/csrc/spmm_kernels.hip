@@ -45,6 +45,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "spmm_kernels.h"
@@ -1294,16 +1295,18 @@ static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {
     if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
     // Gather depth U: 8 B-row loads in flight per lane group unless the accumulators are
     // already wide (CF = 8) or the caller asks for the shallow form.
+    // (experiments only: GESPMM_DEBUG_DYN_LDS = bytes of unused dynamic LDS per workgroup, an occupancy limiter)
+    static const unsigned dyn_lds = getenv("GESPMM_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("GESPMM_DEBUG_DYN_LDS")) : 0u;
     if constexpr (V * S >= 8) {
         hipLaunchKernelGGL((spmm_stream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
-                           dim3(kThreads), 0, st, args);
+                           dim3(kThreads), dyn_lds, st, args);
     } else {
         if (a.flags & kFlagShallowUnroll)
             hipLaunchKernelGGL((spmm_stream_kernel<V, S, W, VALUED, IDX64, RED, 4>), dim3((unsigned)nitems),
-                               dim3(kThreads), 0, st, args);
+                               dim3(kThreads), dyn_lds, st, args);
         else
             hipLaunchKernelGGL((spmm_stream_kernel<V, S, W, VALUED, IDX64, RED, 8>), dim3((unsigned)nitems),
-                               dim3(kThreads), 0, st, args);
+                               dim3(kThreads), dyn_lds, st, args);
     }
     return hipGetLastError();
 }

@@ -36,6 +36,8 @@
 //                   the reference's two columns); with --validate it is checked against a CPU scatter loop
 //   --out path      CSV side file                     (default spmm_test_out.out)
 //   --no-vendor     skip the rocSPARSE comparison column
+//   --plan          time the launches through a gespmm plan (the analysis stage: built once per width before the timed
+//                   loop, its time printed; same results) — with --validate the planned product is checked as well
 //   --describe      print what the library launches for each N (gespmm_describe_launch)
 //   --cache dir     keep the parsed matrix as a binary file in `dir` and reuse it next time
 //
@@ -207,7 +209,7 @@ int main(int argc, char** argv) {
     int method = GESPMM_VARIANT_CRC_CWM2;
     int iters = 200;
     bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true, describe = false;
-    bool atomic_baseline = false;
+    bool atomic_baseline = false, use_plan = false;
     unsigned seed = 0;
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
@@ -234,13 +236,14 @@ int main(int argc, char** argv) {
         else if (a == "--no-vendor") vendor = false;
         else if (a == "--describe") describe = true;
         else if (a == "--atomic-baseline") atomic_baseline = true;
+        else if (a == "--plan") use_plan = true;
         else if (a == "--cache") cache_dir = next("--cache");
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
     if (!mtx_path) {
         fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
-                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--no-vendor] [--describe] [--out path]\n", argv[0]);
+                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--plan] [--no-vendor] [--describe] [--out path]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (iters < 1) iters = 1;
@@ -372,6 +375,19 @@ int main(int argc, char** argv) {
                 compare(who);
                 checked++;
             }
+            if (use_plan) {  // the same product through the analysis stage (forced row clustering): must pass the same check
+                gespmm_plan* plan = nullptr;
+                gespmm_plan_options po = {GESPMM_PLAN_REORDER, 0, 0, 0, 0, 0};
+                CHECK_GE(gespmm_plan_create(&plan, g.indptr_dev, g.indices_dev, g.data_dev, M, K, nnz, N,
+                                            method == GESPMM_VARIANT_NAIVE || method == GESPMM_VARIANT_PARREDUCE ? GESPMM_VARIANT_AUTO : method,
+                                            &po, nullptr));
+                CHECK_HIP(hipMemset(g.C_dev, 0xff, (size_t)M * N * sizeof(float)));
+                CHECK_GE(gespmm_plan_spmm_f32(plan, g.B_dev, g.C_dev, N, nullptr));
+                CHECK_HIP(hipMemcpy(g.C, g.C_dev, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost));
+                compare("plan");
+                gespmm_plan_destroy(plan);
+                checked++;
+            }
             if (vendor) {  // reference: csrmm2 checked against golden too (spmm_test.cu:671-679)
                 VendorSpmm vs;
                 if (vs.setup(M, K, N, nnz, g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev) && vs.run()) {
@@ -431,18 +447,30 @@ int main(int argc, char** argv) {
         }
         if (g.fpo) fprintf(g.fpo, "%f,", vendor_gflops);
 
-        CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, method,
-                                     nullptr));
+        gespmm_plan* plan = nullptr;
+        if (use_plan) {
+            const auto t0 = std::chrono::steady_clock::now();
+            CHECK_GE(gespmm_plan_create(&plan, g.indptr_dev, g.indices_dev, g.data_dev, M, K, nnz, N,
+                                        method == GESPMM_VARIANT_NAIVE || method == GESPMM_VARIANT_PARREDUCE ? GESPMM_VARIANT_AUTO : method,
+                                        nullptr, nullptr));
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            char what[512];
+            if (gespmm_plan_describe(plan, what, sizeof what) > 0) printf("N=%d plan (%.3f s): %s\n", N, secs, what);
+        }
+        auto launch = [&]() {
+            return plan ? gespmm_plan_spmm_f32(plan, g.B_dev, g.C_dev, N, nullptr)
+                        : gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz, method, nullptr);
+        };
+        CHECK_GE(launch());
         CHECK_HIP(hipEventRecord(g.start, 0));
-        for (int i = 0; i < iters; i++)
-            CHECK_GE(gespmm_csr_spmm_f32(g.indptr_dev, g.indices_dev, g.data_dev, g.B_dev, g.C_dev, M, K, N, nnz,
-                                         method, nullptr));
+        for (int i = 0; i < iters; i++) CHECK_GE(launch());
         CHECK_HIP(hipEventRecord(g.stop, 0));
         CHECK_HIP(hipEventSynchronize(g.stop));
         CHECK_HIP(hipEventElapsedTime(&rt, g.start, g.stop));
         if (g.fpo) fprintf(g.fpo, "%f,", gflop / (rt / iters));
-        printf("N=%d method=%d: %f ms/iter, %f GFLOP/s (rocsparse %f GFLOP/s)\n", N, method, rt / iters,
+        printf("N=%d method=%d%s: %f ms/iter, %f GFLOP/s (rocsparse %f GFLOP/s)\n", N, method, plan ? " plan" : "", rt / iters,
                gflop / (rt / iters), vendor_gflops);
+        if (plan) gespmm_plan_destroy(plan);
         if (atomic_baseline) {
             // out = A^T * B[0:M] by one atomicAdd per edge and feature; reuses C_dev when it is large enough (M == K)
             float* out_dev = g.C_dev;

@@ -63,6 +63,17 @@ def test_validate_defaults_follow_the_reference(tmp_path):
     assert len(re.findall(r"atomic-baseline: [0-9.]+ ms/iter", r.stdout)) == 3  # N = 128, 256, 512
 
 
+def test_plan_flag_validates_and_times_through_the_analysis_stage(tmp_path):
+    r = subprocess.run([DRIVER, os.path.join(GOLDEN, "pubmed.mtx"), "--plan", "--validate", "--ncols", "64,128", "--method", "-1",
+                        "--iters", "20", "--seed", "5", "--no-vendor", "--out", str(tmp_path / "o.csv")], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "WA" not in r.stdout, r.stdout
+    assert "validate done (8 variants, N=64)" in r.stdout and "validate done (8 variants, N=128)" in r.stdout  # 0..5, AUTO, plan
+    assert re.search(r"N=128 plan \([0-9.]+ s\): order=", r.stdout), r.stdout
+    assert re.search(r"N=128 method=-1 plan: [0-9.]+ ms/iter", r.stdout)
+
+
 def test_error_exits(tmp_path):
     r = subprocess.run([DRIVER, str(tmp_path / "missing.mtx")], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "not found" in r.stdout  # util.hpp:300-303

@@ -214,3 +214,17 @@ def test_records_of_the_lds_rows_kernel_reproduce_the_oracle(pkg, oracle):
     assert (flags == 3).sum() >= 5 and (flags == 2).sum() >= 2 and (flags == 1).sum() == (flags == 2).sum()
     # row 7 (32 entries, <= 10 distinct columns) sits in ONE ordinary record of its own or with neighbours
     assert any(int(r[3]) == 0 and 7 in r[4:4 + int(r[0])].tolist() for r in recs)
+
+
+def test_clustering_on_the_bundled_real_graphs(pkg, bundled):
+    """The only REAL graphs available offline (the reference's cora / citeseer / pubmed citation networks): at an L2
+    window scaled to their size the clustered order multiplies the modelled reuse of the storage order — real graphs
+    behave like the planted-community stand-in, not like the structureless one."""
+    from gespmm_amd import _lib
+
+    for name, floor in (("cora", 0.40), ("citeseer", 0.40), ("pubmed", 0.28)):
+        g = bundled[name]
+        perm, _, _ = _cluster(_lib.lib, g["rowptr"], g["colind"], g["M"], g["K"])
+        before = _hits(_lib.lib, g["rowptr"], g["colind"], g["M"], g["K"], None, window=64)
+        after = _hits(_lib.lib, g["rowptr"], g["colind"], g["M"], g["K"], perm, window=64)
+        assert after >= floor and after >= 3 * before, (name, before, after)
