@@ -44,12 +44,13 @@ def load_edges(dataset, device):
     if dataset in ("cora", "citeseer"):
         coo = graphs.read_mtx(os.path.join(ROOT, "tests", "golden", dataset + ".mtx"))
         return np.stack([coo["row"], coo["col"]]).astype(np.int32), coo["nrows"], 500, 7
-    if dataset == "reddit-like":  # DGL reddit shape: 602 input features, 41 classes
-        g = graphs.synthetic_graph("reddit-like", seed=42, device=device)
+    if dataset in ("reddit-like", "com-amazon-sbm", "com-amazon-like", "products-sbm"):
+        # DGL reddit shape: 602 input features, 41 classes; the co-purchase stand-ins: 100 features, 47 classes (ogbn-products)
+        g = graphs.synthetic_graph(dataset, seed=42, device=device)
         rp = g["rowptr"].long()
         rows = torch.repeat_interleave(torch.arange(g["M"], device=device), rp[1:] - rp[:-1])
         ei = torch.stack([rows, g["colind"].long()]).cpu().numpy().astype(np.int32)
-        return ei, g["M"], 602, 41
+        return (ei, g["M"], 602, 41) if dataset == "reddit-like" else (ei, g["M"], 100, 47)
     raise SystemExit("unknown dataset " + dataset)
 
 
@@ -78,11 +79,11 @@ def proc(edge_index, n_v, device, add_self_loop=True):
 
 
 class Net(torch.nn.Module):
-    def __init__(self, n_in, n_hidden, n_out, convs, weighted):
+    def __init__(self, n_in, n_hidden, n_out, convs, weighted, cached=True):
         super().__init__()
         dims = [n_in] + [n_hidden] * (convs - 1) + [n_out]
         self.convs = torch.nn.ModuleList(
-            [GCNConv(dims[i], dims[i + 1], cached=True, normalize=True) for i in range(convs)])
+            [GCNConv(dims[i], dims[i + 1], cached=cached, normalize=True) for i in range(convs)])
         self.weighted = weighted
         self.reg_params = self.convs[0].parameters()
         self.non_reg_params = [p for c in self.convs[1:] for p in c.parameters()]
@@ -107,6 +108,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--graph-capture", action="store_true", help="capture one training step in a HIP graph")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--no-plans", action="store_true", help="GCNConv(cached=False): every SpMM is a plain call (no analysis stage)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device (the op has no CPU path)")
@@ -127,7 +129,7 @@ def main():
         masks[name] = m.to(device)
 
     weighted = not args.no_edge_weight and args.convs == 2
-    model = Net(n_feat, args.n_hidden, n_cls, args.convs, weighted).to(device)
+    model = Net(n_feat, args.n_hidden, n_cls, args.convs, weighted, cached=not args.no_plans).to(device)
     optimizer = torch.optim.Adam([dict(params=model.reg_params, weight_decay=5e-4),
                                   dict(params=model.non_reg_params, weight_decay=0)], lr=0.01,
                                  capturable=args.graph_capture)

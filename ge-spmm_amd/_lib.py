@@ -60,6 +60,7 @@ EXPORTS = [
     "gespmm_plan_create",
     "gespmm_plan_spmm_f32",
     "gespmm_plan_spmm_max_f32",
+    "gespmm_plan_sddmm_f32",
     "gespmm_plan_set_values",
     "gespmm_plan_get_order",
     "gespmm_plan_describe",
@@ -156,6 +157,8 @@ def _load():
     lib.gespmm_plan_spmm_f32.argtypes = [p, p, p, c_int64, p]
     lib.gespmm_plan_spmm_max_f32.restype = c_int
     lib.gespmm_plan_spmm_max_f32.argtypes = [p, p, p, c_int64, c_float, p]
+    lib.gespmm_plan_sddmm_f32.restype = c_int
+    lib.gespmm_plan_sddmm_f32.argtypes = [p, p, p, p, c_int64, p]
     lib.gespmm_plan_set_values.restype = c_int
     lib.gespmm_plan_set_values.argtypes = [p, p, p]
     lib.gespmm_plan_get_order.restype = c_int

@@ -52,6 +52,11 @@ struct gespmm_plan {
     int32_t ntasks = 0;
     int32_t* d_gtasks = nullptr;  // lane-group tasks of the segmented-stream kernel
     int32_t ngtasks = 0;
+    // SDDMM through the plan (built on first use): edges in clustered order as COO with the ORIGINAL row ids, the
+    // position of every edge in the caller's CSR, and a buffer for the results in clustered order
+    int32_t* d_coo_row = nullptr;
+    int32_t* d_edge_dst = nullptr;
+    float* d_sddmm_tmp = nullptr;
     int32_t task_entries = 0;
     // LDS-staged-rows kernel (spmm_ldsrow.hip): one 640-byte record per task
     int32_t* d_recs = nullptr;
@@ -83,11 +88,33 @@ __global__ void permute_values_kernel(const int32_t* __restrict__ rowptr_p, cons
     val_p[p] = val[src_begin[lo] + (p - rowptr_p[lo])];
 }
 
+__global__ void plan_edge_maps_kernel(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ src_begin,
+                                      const int32_t* __restrict__ perm, int32_t* __restrict__ coo_row,
+                                      int32_t* __restrict__ edge_dst, int M, int nnz) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int lo = 0, hi = M;  // rowptr_p[lo] <= p < rowptr_p[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr_p[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    coo_row[p] = perm[lo];
+    edge_dst[p] = src_begin[lo] + (p - rowptr_p[lo]);
+}
+
+__global__ void scatter_by_index_kernel(const float* __restrict__ src, const int32_t* __restrict__ dst_index,
+                                        float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[dst_index[i]] = src[i];
+}
+
 void free_device(gespmm_plan* p) {
-    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks};
+    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
-    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = p->d_gtasks = nullptr;
+    p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = p->d_gtasks = p->d_coo_row = p->d_edge_dst = nullptr;
+    p->d_sddmm_tmp = nullptr;
     p->d_val = nullptr;
     p->ws = nullptr;
 }
@@ -576,6 +603,40 @@ int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N,
 
 int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, float empty_value, void* stream) {
     return plan_run(plan, B, C, N, gespmm::kReduceMax, empty_value, stream);
+}
+
+// SDDMM on the plan's pattern: out[e] = <D1[row(e), :], D2[col(e), :]> for every edge e of the CALLER's CSR (out in the
+// caller's edge order). A clustered plan walks the edges in its own order — the rows of D2 that neighbouring rows share
+// are then found in L2, as in the SpMM — and scatters the results back; each dot product is the same lane butterfly as in
+// gespmm_sddmm_{coo,csr}_f32, so the bits are the same.
+int gespmm_plan_sddmm_f32(gespmm_plan* p, const float* D1, const float* D2, float* out, int64_t N, void* stream) {
+    if (!p || N < 0) return GESPMM_EINVAL;
+    if (p->nnz == 0) return 0;
+    if (!out || (N > 0 && (!D1 || !D2))) return GESPMM_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // The clustered walk pays a scatter pass at the end: worth it where the order is modelled to hit L2 for >= 40 % of the
+    // gathers and the rows are >= 256 bytes (com-Amazon-shaped communities, N = 128: 114 vs 151 us COO / 167 us CSR; on the
+    // structureless graph or at N = 41 it is equal or slower — profiles/r02/sddmm_plan.log). Otherwise: the plain CSR
+    // form on the caller's arrays (which must therefore still be alive).
+    if (!p->reordered || p->hits_after < 0.40 || N < 64)
+        return gespmm_sddmm_csr_f32(p->rowptr, p->colind, D1, D2, out, p->M, p->nnz, N, stream);
+    hipError_t e = hipSuccess;
+    if (!p->d_coo_row) {
+        const size_t bytes = (size_t)p->nnz * 4;
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_coo_row), bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_edge_dst), bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_sddmm_tmp), bytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(plan_edge_maps_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
+                           p->d_src_begin, p->d_perm, p->d_coo_row, p->d_edge_dst, (int)p->M, (int)p->nnz);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    e = gespmm::launch_sddmm(p->d_coo_row, false, p->d_colind, D1, D2, p->d_sddmm_tmp, p->M, p->nnz, N, 0, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(scatter_by_index_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_sddmm_tmp,
+                       p->d_edge_dst, out, (int)p->nnz);
+    return (int)hipGetLastError();
 }
 
 int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {

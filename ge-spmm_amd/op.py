@@ -25,7 +25,8 @@ GCNConv computes  D_in^-1/2 · A · (D_out^-1/2 ⊙ (X W)) + b  with degrees tak
 the rowptr / colptr differences (op.py:103-109, 128-147). ``glorot`` / ``zeros`` are
 re-implemented (the reference imports them from torch_geometric, op.py:75).
 With ``cached=True`` — which already promises a static graph for the cached normalisation — GCNConv
-also keeps one SpmmPlan per direction (dense graphs: the split scan runs once, not per call).
+also keeps one SpmmPlan per direction (the analysis stage: sparse graphs are row-clustered once and launched from a
+task table, dense graphs keep the split points of the cache-blocked path; results keep their bits).
 The reference's ``normalize=False`` branch raises TypeError (``rowptr.shape(0)``,
 op.py:133-134); here it does what the branch evidently intends: no scaling.
 """
@@ -45,6 +46,7 @@ class SPMMFunction(torch.autograd.Function):
     def forward(ctx, rowptr, colind, colptr, rowind, feat, edge_weight_csr=None, edge_weight_csc=None,
                 need_edge_grad=False, plans=None):
         fwd_plan, ctx.bwd_plan = plans if plans is not None else (None, None)
+        ctx.fwd_plan = fwd_plan
         if edge_weight_csr is None:
             out = _spmm.csr_spmm_no_edge_value(rowptr, colind, feat, plan=fwd_plan)
         else:
@@ -69,7 +71,7 @@ class SPMMFunction(torch.autograd.Function):
             grad_feat = _spmm.csr_spmm(colptr, rowind, edge_weight_csc, grad_out, plan=ctx.bwd_plan)
             if ctx.need_edge_grad:
                 rowptr, colind = ctx.forward_csr
-                grad_edge_weight = _sddmm.csr_sddmm(rowptr, colind, grad_out, feat.detach().contiguous())
+                grad_edge_weight = _sddmm.csr_sddmm(rowptr, colind, grad_out, feat.detach().contiguous(), plan=ctx.fwd_plan)
             elif not _warned_no_grad:
                 print("[I] Treat edge weight as no_grad.")
                 _warned_no_grad = True

@@ -38,7 +38,21 @@ def coo_sddmm(rowind, colind, D1, D2):
     return out
 
 
-def csr_sddmm(rowptr, colind, D1, D2):
+def csr_sddmm(rowptr, colind, D1, D2, plan=None):
+    """``plan``: a ``spmm.SpmmPlan`` of the same pattern — a clustered plan walks the edges in its own order (rows of D2
+    shared by neighbouring rows come from L2) and returns the same bits in the caller's edge order."""
+    if plan is not None:
+        dev = _checked(rowptr, "rowptr", colind, D1, D2)
+        if (rowptr.data_ptr(), colind.data_ptr()) != (plan._rowptr.data_ptr(), plan._colind.data_ptr()) or \
+                (rowptr._version, colind._version) != plan._pattern_version:
+            raise ValueError("the plan was made for a different (or since modified) pattern")
+        if D1.shape[0] != rowptr.numel() - 1:
+            raise ValueError("rowptr must have D1.size(0)+1 entries")
+        out = torch.empty((colind.numel(),), dtype=torch.float32, device=dev)
+        with _on_device(dev):
+            rc = lib.gespmm_plan_sddmm_f32(plan._handle, _ptr(D1), _ptr(D2), _ptr(out), D1.shape[1], _stream(dev))
+        check(rc, "gespmm_plan_sddmm_f32")
+        return out
     if _ext is not None:
         return _ext.csr_sddmm(rowptr, colind, D1, D2)
     dev = _checked(rowptr, "rowptr", colind, D1, D2)

@@ -288,6 +288,10 @@ int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t*
 int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, void* stream);
 /* max reducer (unweighted plans only), see gespmm_csr_spmm_max_f32 */
 int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, float empty_value, void* stream);
+/* SDDMM on the plan's pattern, out[nnz] in the caller's CSR edge order (same bits as gespmm_sddmm_csr_f32); a clustered
+ * plan whose order is modelled to hit L2 walks the edges in its own order (shared rows of D2 come from L2) and scatters the
+ * results back; otherwise the call is gespmm_sddmm_csr_f32 on the arrays the plan was made from (keep them alive). */
+int gespmm_plan_sddmm_f32(gespmm_plan* plan, const float* D1, const float* D2, float* out, int64_t N, void* stream);
 /* New values on the unchanged pattern (val in the caller's CSR order, device memory; NULL = A == 1). */
 int gespmm_plan_set_values(gespmm_plan* plan, const float* val, void* stream);
 /* perm_host[i] = row processed at position i (HOST memory, M entries). Returns 1 if clustered, 0 if storage order. */

@@ -157,3 +157,44 @@ def test_hub_rows_through_a_clustered_plan(pkg):
     strict = spmm.SpmmPlan(rp, ci, K, 64, values=val, reorder=True, flags=_lib.FLAG_STRICT_ORDER)
     ref_s = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_STRICT_ORDER})
     assert torch.equal(spmm.csr_spmm(rp, ci, val, B, plan=strict).view(torch.int32), ref_s.view(torch.int32))
+
+
+def test_sddmm_through_a_plan_keeps_the_bits(pkg, bundled):
+    """gespmm_plan_sddmm_f32: edges walked in the plan's clustered order, results scattered back to the caller's CSR edge
+    order — the same lane butterfly per edge, so the same bits as csr_sddmm / coo_sddmm; also through SPMMFunction's
+    edge-weight gradient with plans."""
+    import gespmm_amd
+    from gespmm_amd import graphs, sddmm, spmm
+
+    cases = [("pubmed", bundled["pubmed"])]
+    gs = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    for name, G in cases + [("com-amazon-sbm", gs)]:
+        rp = G["rowptr"] if torch.is_tensor(G["rowptr"]) else _dev(G["rowptr"])
+        ci = G["colind"] if torch.is_tensor(G["colind"]) else _dev(G["colind"])
+        M, K = G["M"], G["K"]
+        for N in (3, 41, 128):
+            D1 = torch.rand(M, N, device="cuda") - 0.5
+            D2 = torch.rand(K, N, device="cuda") - 0.5
+            plan = spmm.SpmmPlan(rp, ci, K, N, reorder=True)
+            ref = sddmm.csr_sddmm(rp, ci, D1, D2)
+            got = sddmm.csr_sddmm(rp, ci, D1, D2, plan=plan)
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (name, N)
+            keep = spmm.SpmmPlan(rp, ci, K, N, reorder=False)
+            assert torch.equal(sddmm.csr_sddmm(rp, ci, D1, D2, plan=keep).view(torch.int32), ref.view(torch.int32))
+    # autograd: edge-weight gradient with and without plans
+    G = bundled["pubmed"]
+    rp, ci = _dev(G["rowptr"]), _dev(G["colind"])
+    colptr, rowind = graphs.transpose_csr(rp, ci)
+    w = torch.rand(G["nnz"], device="cuda") - 0.5
+    _, _, w_csc = graphs.transpose_csr(rp, ci, val=w)
+    x0 = torch.rand(G["M"], 64, device="cuda") - 0.5
+    go = torch.rand(G["M"], 64, device="cuda") - 0.5
+    grads = []
+    for plans in (None, (spmm.SpmmPlan(rp, ci, G["K"], 64, reorder=True), spmm.SpmmPlan(colptr, rowind, G["M"], 64, reorder=True))):
+        x = x0.clone().requires_grad_(True)
+        ww = w.clone().requires_grad_(True)
+        y = gespmm_amd.SPMMFunction.apply(rp, ci, colptr, rowind, x, ww, w_csc, True, plans)
+        y.backward(go)
+        grads.append((y.detach(), x.grad, ww.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
