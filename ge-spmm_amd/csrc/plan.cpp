@@ -267,7 +267,7 @@ int default_task_entries(int64_t N) {
     const int64_t row_bytes = 4 * (N < 256 ? N : 256);
     int64_t t = (32 << 10) / (row_bytes > 0 ? row_bytes : 4);
     if (t < 32) t = 32;
-    if (t > 256) t = 256;
+    if (t > 96) t = 96;  // narrow rows (N = 32: 128-byte rows) are latency-bound per row pair: the plain path's 96 entries
     return (int)t;
 }
 
@@ -455,7 +455,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             // task size: ~32 KB of gathered B per wavefront; twice that when the order is modelled to hit L2 for >= 40 % of
             // the gathers (the per-task prologue then weighs more than the coarser balance; plan_task_size.log)
             int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
-            if (!(opt && opt->task_entries > 0) && p->hits_after >= 0.40) budget *= 2;
+            if (!(opt && opt->task_entries > 0) && p->hits_after >= 0.40 && N >= 64) budget *= 2;
             const int floor_opt = opt ? opt->row_floor : 0;
             const int64_t row_floor = floor_opt < 0 ? 0 : (floor_opt > 0 ? floor_opt : 8);
             p->task_entries = budget;

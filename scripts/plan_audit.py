@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""AUTO plans against the plain call on a grid of graphs and widths: does the analysis stage ever lose?
+    python scripts/plan_audit.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import gespmm_amd  # noqa: F401,E402
+from gespmm_amd import graphs, spmm  # noqa: E402
+
+dev = torch.device("cuda")
+
+
+def timeit(fn, iters):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def cases():
+    yield "com-amazon-like", graphs.synthetic_graph("com-amazon-like", seed=42, device=dev)
+    yield "com-amazon-like locality 0.9", graphs.synthetic_graph("com-amazon-like", seed=42, device=dev, locality=0.9)
+    yield "com-amazon-sbm", graphs.synthetic_graph("com-amazon-sbm", seed=42, device=dev)
+    yield "com-amazon-sbm (planted order, not shuffled)", None
+    yield "cit-hepth-like", graphs.synthetic_graph("cit-hepth-like", seed=42, device=dev)
+    for name in ("cora", "pubmed"):
+        g = graphs.load_mtx_as_csr(os.path.join(ROOT, "tests", "golden", name + ".mtx"))
+        yield name, {"M": g["M"], "K": g["K"], "nnz": g["nnz"], "rowptr": torch.from_numpy(g["rowptr"]).to(dev),
+                     "colind": torch.from_numpy(g["colind"]).to(dev)}
+    for s in (16, 18, 20):
+        yield "rmat-%d" % s, graphs.rmat_shard(s, 16, 0, 1, seed=42, device=dev)
+    yield "products-sbm x0.25", graphs.synthetic_graph("products-sbm", seed=42, device=dev, scale=0.25)
+    yield "products-like x0.25", graphs.synthetic_graph("products-like", seed=42, device=dev, scale=0.25)
+    yield "reddit-like x0.1", graphs.synthetic_graph("reddit-like", seed=42, device=dev, scale=0.1)
+
+
+for name, g in cases():
+    if g is None:
+        M, nnz = graphs.SPECS["com-amazon-like"][:2]
+        rp, ci, _ = graphs.community_csr(M, nnz, 75149, 1024, 5.0, 0.6, 1.5, 1.55, 42, dev, shuffle=False)
+        g = {"M": M, "K": M, "nnz": int(ci.numel()), "rowptr": rp, "colind": ci}
+    M, K, nnz = g["M"], g["K"], g["nnz"]
+    rp, ci = g["rowptr"], g["colind"]
+    val = torch.rand(nnz, device=dev) - 0.5
+    for N in (32, 128, 512):
+        if 4.0 * (M + K) * N > 40e9:
+            continue
+        B = torch.rand(K, N, device=dev) - 0.5
+        C = torch.empty((M, N), device=dev)
+        iters = 50 if nnz < 5e6 else 10
+        t_plain = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C), iters)
+        ref = C.clone()
+        t0 = time.time()
+        plan = spmm.SpmmPlan(rp, ci, K, N, values=val)
+        dt = time.time() - t0
+        t_plan = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan), iters)
+        same = torch.equal(C.view(torch.int32), ref.view(torch.int32))
+        flag = "  <-- plan loses" if t_plan > 1.05 * t_plain else ""
+        print("%-46s N=%-3d plain %9.1f us  plan %9.1f us  x%.2f  bits=%s  analysis %.2fs  %s%s" %
+              (name, N, t_plain, t_plan, t_plain / t_plan, "same" if same else "LONG-ROW-REASSOC", dt,
+               plan.describe().split(" ")[0], flag), flush=True)
+        del plan, B, C, ref
+    del g
+    torch.cuda.empty_cache()
