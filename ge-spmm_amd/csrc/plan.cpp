@@ -452,10 +452,8 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 std::memcpy(ci.data() + rp[i], h_colind.data() + b, (size_t)d * 4);
                 rp[i + 1] = rp[i] + d;
             }
-            // task size: ~32 KB of gathered B per wavefront; twice that when the order is modelled to hit L2 for >= 40 % of
-            // the gathers (the per-task prologue then weighs more than the coarser balance; plan_task_size.log)
-            int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
-            if (!(opt && opt->task_entries > 0) && p->hits_after >= 0.40 && N >= 64) budget *= 2;
+            // task size: ~32 KB of gathered B per wavefront (plan_task_size.log, plan_unroll_geometry.log)
+            const int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
             const int floor_opt = opt ? opt->row_floor : 0;
             const int64_t row_floor = floor_opt < 0 ? 0 : (floor_opt > 0 ? floor_opt : 8);
             p->task_entries = budget;
@@ -521,6 +519,12 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 return (int)e;
             }
             p->reordered = true;
+            // Where the clustered order is modelled to hit L2 (>= 40 % of the gathers) four B rows in flight per lane group
+            // beat eight at up to 128 columns (com-Amazon-shaped communities, N = 128: 105 vs 114 us, N = 64: 48 vs 60 us;
+            // at 256+ columns and on the structureless graph eight stay ahead) — profiles/r02/plan_unroll_geometry.log
+            // (short rows only: degree-50 rows want the depth — products-shaped communities, N = 32: 525 vs 365 us)
+            if (p->hits_after >= 0.40 && N <= 128 && mean <= 8 && nnz >= (1 << 20) && !(opt && opt->flags & 0x20000))
+                p->launch_flags |= GESPMM_FLAG_SHALLOW_UNROLL;
         } else {
             p->perm_host.clear();
         }
