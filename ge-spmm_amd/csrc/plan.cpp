@@ -590,7 +590,8 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         const bool seg = p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM ||
                          (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean_deg >= 16 && p->hits_after >= 0.40 && N > 64 &&
                           N <= 128 && N % 4 == 0);
-        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg};
+        static const int dbg_wgs = getenv("GESPMM_PERSIST_WGS") ? atoi(getenv("GESPMM_PERSIST_WGS")) : 0;  // experiments only
+        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg, dbg_wgs};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
                               p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
     } else {

@@ -33,6 +33,7 @@ constexpr int kFlagReuseSplit = 0x2000;   // == GESPMM_FLAG_REUSE_SPLIT
 constexpr int kFlagAllowReassoc = 0x1000; // == GESPMM_FLAG_ALLOW_REASSOCIATION
 constexpr int kFlagDebugIdentityStore = 0x4000;  // experiments only: plan mode writes C in processing order (WRONG rows)
 constexpr int kFlagSc1Store = 0x8000;     // == GESPMM_FLAG_SC1_STORE: C stores do not stay in the XCD's L2
+constexpr int kFlagPersistentTasks = 0x40000;  // == GESPMM_FLAG_PERSISTENT_TASKS (plans: persistent wavefronts, cross-task prefetch)
 constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
 
 struct SpmmArgs {
@@ -66,6 +67,7 @@ struct SpmmArgs {
     // the same for the segmented-stream kernel, whose unit of work is a lane GROUP: group q works on gtasks[q]
     const int32_t* gtasks;
     int32_t ngtasks;
+    int32_t persist_wgs;  // persistent mode: workgroups per XCD (0 = as many as stay resident)
 };
 
 // Launch geometry resolved by the host-side selector (select.cpp).

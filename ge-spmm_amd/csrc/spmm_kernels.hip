@@ -283,28 +283,24 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
     int row_first, nrows, wb, we;  // wave-uniform
     int rp_plan = 0, pm_plan = 0;
     const bool planned = a.tasks != nullptr;
-    if (planned) {
-        // Plan mode: the task table names the rows and the CSR range, so the first CSR tile, the row
-        // pointers and the C-row indices are three independent loads instead of a dependent chain.
-        const int wid = rb * kWaves + wave;
-        if (wid >= a.ntasks) return;
-        const int4 t = reinterpret_cast<const int4*>(a.tasks)[wid];
-        row_first = __builtin_amdgcn_readfirstlane(t.x);
-        nrows = __builtin_amdgcn_readfirstlane(t.y);
-        wb = __builtin_amdgcn_readfirstlane(t.z);
-        we = __builtin_amdgcn_readfirstlane(t.w);
-        rp_plan = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
-        pm_plan = a.perm[row_first + (lane < nrows ? lane : nrows - 1)];
-    } else {
-        const int rpw = a.rpw;
-        row_first = (rb * kWaves + wave) * rpw;
-        if (row_first >= a.M) return;  // whole wavefront leaves together
-        nrows = (a.M - row_first < rpw) ? a.M - row_first : rpw;
-        // Row pointers of this wavefront's rows -> LDS (one coalesced load, rpw <= 32).
-        const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
-        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
-        wb = __builtin_amdgcn_readfirstlane(rp);
-        we = __builtin_amdgcn_readlane(rp, nrows);
+    // Persistent mode (plan option): the grid is sized to the chip, wavefront lw of XCD x walks tasks x0 + lw, x0 + lw + nwx,
+    // ... of that XCD's contiguous slice, and while a task is processed the NEXT task's row pointers, C rows and first CSR
+    // tile are already on their way (its descriptor was fetched one task earlier) — the two dependent round trips in front of
+    // every task disappear, which is what makes small tasks (a narrow window of rows in flight per XCD, so more L2 hits) cheap.
+    const bool persistent = planned && (a.flags & kFlagPersistentTasks) != 0;
+    int task_id = 0, task_stride = 0, task_end = 0;
+    int4 dnext = make_int4(0, 0, 0, 0);
+    if (persistent) {
+        const int xcd = blockIdx.x & 7;  // the hardware deals workgroup b to XCD b % 8
+        const int rest = blockIdx.x >> 3;
+        tile = (a.ntile > 1) ? rest % a.ntile : 0;
+        const int slot = (a.ntile > 1) ? rest / a.ntile : rest;
+        task_stride = a.nblk * kWaves;  // wavefronts per XCD (and column tile)
+        task_id = (int)((int64_t)a.ntasks * xcd / 8) + slot * kWaves + wave;
+        task_end = (int)((int64_t)a.ntasks * (xcd + 1) / 8);
+    } else if (planned) {
+        task_id = rb * kWaves + wave;
+        task_end = a.ntasks;
     }
 
     const int col0 = tile * (W * V * S) + l * V;
@@ -334,134 +330,195 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
         s_off[wave][lane] = (off_t)(uint32_t)pc * rowbytes;
         if constexpr (VALUED) s_val[wave][lane] = pv;
     };
-    int t0 = wb;
-    fetch_tile_regs(t0);
-    if (planned) {  // (after the tile loads are on their way: the three loads of a planned task overlap)
-        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp_plan;
-        if (lane < kMaxRowsPerWave) s_perm[wave][lane] = pm_plan;
+
+    if (planned) {
+        // Plan mode: the task table names the rows and the CSR range, so the first CSR tile, the row
+        // pointers and the C-row indices are three independent loads instead of a dependent chain.
+        if (task_id >= task_end) return;
+        const int4 t = reinterpret_cast<const int4*>(a.tasks)[task_id];
+        row_first = __builtin_amdgcn_readfirstlane(t.x);
+        nrows = __builtin_amdgcn_readfirstlane(t.y);
+        wb = __builtin_amdgcn_readfirstlane(t.z);
+        we = __builtin_amdgcn_readfirstlane(t.w);
+        rp_plan = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
+        pm_plan = a.perm[row_first + (lane < nrows ? lane : nrows - 1)];
+        if (persistent && task_id + task_stride < task_end) dnext = reinterpret_cast<const int4*>(a.tasks)[task_id + task_stride];
+    } else {
+        const int rpw = a.rpw;
+        row_first = (rb * kWaves + wave) * rpw;
+        if (row_first >= a.M) return;  // whole wavefront leaves together
+        nrows = (a.M - row_first < rpw) ? a.M - row_first : rpw;
+        // Row pointers of this wavefront's rows -> LDS (one coalesced load, rpw <= 32).
+        const int rp = a.rowptr[row_first + (lane <= nrows ? lane : nrows)];
+        if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp;
+        wb = __builtin_amdgcn_readfirstlane(rp);
+        we = __builtin_amdgcn_readlane(rp, nrows);
     }
-    publish_tile();
-    fetch_tile_regs(t0 + kTile);
-    wave_lds_sync();
+    fetch_tile_regs(wb);  // first tile of the first task
 
-    for (int b = 0; b < nrows; b += G) {
-        const int r = b + g;
-        const bool rowok = r < nrows;
-        int lb = 0, hb = 0;
-        bool rowok2 = rowok;
-        if (rowok) {
-            lb = s_ptr[wave][r];
-            hb = s_ptr[wave][r + 1];
-            if (a.long_row > 0 && hb - lb > a.long_row) {  // left to the long-row pass
-                if (l == 0 && tile == 0 && a.lr_hdr) {  // one lane registers the row: chunk slots + list entry
-                    const int nch = (hb - lb + a.lr_chunk - 1) / a.lr_chunk;
-                    const int base = atomicAdd(a.lr_hdr + 0, nch);
-                    const int j = atomicAdd(a.lr_hdr + 1, 1);
-                    if (j < a.lr_max_rows && base + nch <= a.lr_max_chunks) {
-                        reinterpret_cast<int4*>(a.lr_rows)[j] = make_int4(row_first + r, base, nch, 0);
-                        for (int c = 0; c < nch; ++c)
-                            reinterpret_cast<int2*>(a.lr_chunks)[base + c] = make_int2(row_first + r, c);
-                    }
-                }
-                hb = lb;
-                rowok2 = false;
+    for (;;) {  // the tasks of this wavefront (exactly one unless persistent)
+        // ---- the next task's loads go out before this task's first gather
+        bool has_next = false;
+        int n_row_first = 0, n_nrows = 0, n_wb = 0, n_we = 0, n_rp = 0, n_pm = 0, n_pc = 0;
+        float n_pv = 0.0f;
+        int4 dnext2 = make_int4(0, 0, 0, 0);
+        if (persistent && task_id + task_stride < task_end) {
+            has_next = true;
+            n_row_first = __builtin_amdgcn_readfirstlane(dnext.x);
+            n_nrows = __builtin_amdgcn_readfirstlane(dnext.y);
+            n_wb = __builtin_amdgcn_readfirstlane(dnext.z);
+            n_we = __builtin_amdgcn_readfirstlane(dnext.w);
+            n_rp = a.rowptr[n_row_first + (lane <= n_nrows ? lane : n_nrows)];
+            n_pm = a.perm[n_row_first + (lane < n_nrows ? lane : n_nrows - 1)];
+            if (n_wb + lane < n_we) {
+                n_pc = load_csr(a.colind + n_wb + lane);
+                if constexpr (VALUED) n_pv = load_csr(a.val + n_wb + lane);
             }
-        }
-        const int be = __builtin_amdgcn_readfirstlane(s_ptr[wave][(b + G < nrows) ? b + G : nrows]);
-        if constexpr (G == 1) {
-            lb = __builtin_amdgcn_readfirstlane(lb);
-            hb = __builtin_amdgcn_readfirstlane(hb);
+            if (task_id + 2 * task_stride < task_end)
+                dnext2 = reinterpret_cast<const int4*>(a.tasks)[task_id + 2 * task_stride];
         }
 
-        float acc[S][V];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[s][i] = init;
-
-        for (;;) {
-            const int tend = t0 + kTile;
-            int k = (lb > t0 ? lb : t0) - t0;
-            const int ke = (hb < tend ? hb : tend) - t0;
-            // Full steps: U gathers issued back to back, no predicates.
-            for (; k + U <= ke; k += U) {
-                off_t off[U];
-                float v[U];
-                float bv[U][S][V];
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    off[j] = s_off[wave][k + j];
-                    if constexpr (VALUED) v[j] = s_val[wave][k + j];
-                    else v[j] = 1.0f;
-                }
-#pragma unroll
-                for (int j = 0; j < U; ++j)
-#pragma unroll
-                    for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
-#pragma unroll
-                for (int j = 0; j < U; ++j)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-#pragma unroll
-                        for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
-            }
-            // Tail (1..U-1 entries): ONE predicated group, so a short row is a single round
-            // trip. It is not inside a loop, so there is no loop-carried register hazard and
-            // the compiler keeps the predicated loads in flight together.
-            const int rem = ke - k;
-            if (rem > 0) {
-                off_t off[U - 1];
-                float v[U - 1];
-                float bv[U - 1][S][V];
-                // LDS reads first, all of them (clamped slot: always inside the tile), THEN the
-                // predicated gathers: with the read inside the predicate every gather waited for
-                // its own LDS round trip (tail of r entries cost r serial LDS latencies).
-#pragma unroll
-                for (int j = 0; j < U - 1; ++j) {
-                    const int kj = k + ((j < rem) ? j : rem - 1);
-                    off[j] = s_off[wave][kj];
-                    if constexpr (VALUED) v[j] = s_val[wave][kj];
-                    else v[j] = 1.0f;
-                }
-#pragma unroll
-                for (int j = 0; j < U - 1; ++j) {
-                    if (j < rem) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < U - 1; ++j) {
-                    if (j < rem) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s)
-#pragma unroll
-                            for (int i = 0; i < V; ++i)
-                                acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
-                    }
-                }
-            }
-            if (be <= tend) break;  // every row of this batch ends inside the resident tile
-            wave_lds_sync();        // all reads of the old tile are issued before it is overwritten
-            t0 = tend;
-            publish_tile();
-            fetch_tile_regs(t0 + kTile);
-            wave_lds_sync();
+        int t0 = wb;
+        if (planned) {  // (after the tile loads are on their way: the three loads of a planned task overlap)
+            if (lane <= kMaxRowsPerWave) s_ptr[wave][lane] = rp_plan;
+            if (lane < kMaxRowsPerWave) s_perm[wave][lane] = pm_plan;
         }
+        publish_tile();
+        fetch_tile_regs(t0 + kTile);
+        wave_lds_sync();
 
-        if (rowok2) {
-            const int crow = (planned && !(a.flags & kFlagDebugIdentityStore)) ? s_perm[wave][r] : row_first + r;
-            float* Crow = a.C + (size_t)crow * (size_t)a.N + col0;
-            const bool nts = (a.flags & kFlagNtStore) != 0;
-            const bool sc1 = (a.flags & kFlagSc1Store) != 0;
-#pragma unroll
+        for (int b = 0; b < nrows; b += G) {
+            const int r = b + g;
+            const bool rowok = r < nrows;
+            int lb = 0, hb = 0;
+            bool rowok2 = rowok;
+            if (rowok) {
+                lb = s_ptr[wave][r];
+                hb = s_ptr[wave][r + 1];
+                if (a.long_row > 0 && hb - lb > a.long_row) {  // left to the long-row pass
+                    if (l == 0 && tile == 0 && a.lr_hdr) {  // one lane registers the row: chunk slots + list entry
+                        const int nch = (hb - lb + a.lr_chunk - 1) / a.lr_chunk;
+                        const int base = atomicAdd(a.lr_hdr + 0, nch);
+                        const int j = atomicAdd(a.lr_hdr + 1, 1);
+                        if (j < a.lr_max_rows && base + nch <= a.lr_max_chunks) {
+                            reinterpret_cast<int4*>(a.lr_rows)[j] = make_int4(row_first + r, base, nch, 0);
+                            for (int c = 0; c < nch; ++c)
+                                reinterpret_cast<int2*>(a.lr_chunks)[base + c] = make_int2(row_first + r, c);
+                        }
+                    }
+                    hb = lb;
+                    rowok2 = false;
+                }
+            }
+            const int be = __builtin_amdgcn_readfirstlane(s_ptr[wave][(b + G < nrows) ? b + G : nrows]);
+            if constexpr (G == 1) {
+                lb = __builtin_amdgcn_readfirstlane(lb);
+                hb = __builtin_amdgcn_readfirstlane(hb);
+            }
+
+            float acc[S][V];
+    #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (colok[s]) {
-                    if (sc1) store_vec_sc1<V>(Crow + s * (W * V), acc[s]);
-                    else if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
-                    else store_vec<V, false>(Crow + s * (W * V), acc[s]);
+    #pragma unroll
+                for (int i = 0; i < V; ++i) acc[s][i] = init;
+
+            for (;;) {
+                const int tend = t0 + kTile;
+                int k = (lb > t0 ? lb : t0) - t0;
+                const int ke = (hb < tend ? hb : tend) - t0;
+                // Full steps: U gathers issued back to back, no predicates.
+                for (; k + U <= ke; k += U) {
+                    off_t off[U];
+                    float v[U];
+                    float bv[U][S][V];
+    #pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        off[j] = s_off[wave][k + j];
+                        if constexpr (VALUED) v[j] = s_val[wave][k + j];
+                        else v[j] = 1.0f;
+                    }
+    #pragma unroll
+                    for (int j = 0; j < U; ++j)
+    #pragma unroll
+                        for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+    #pragma unroll
+                    for (int j = 0; j < U; ++j)
+    #pragma unroll
+                        for (int s = 0; s < S; ++s)
+    #pragma unroll
+                            for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
                 }
+                // Tail (1..U-1 entries): ONE predicated group, so a short row is a single round
+                // trip. It is not inside a loop, so there is no loop-carried register hazard and
+                // the compiler keeps the predicated loads in flight together.
+                const int rem = ke - k;
+                if (rem > 0) {
+                    off_t off[U - 1];
+                    float v[U - 1];
+                    float bv[U - 1][S][V];
+                    // LDS reads first, all of them (clamped slot: always inside the tile), THEN the
+                    // predicated gathers: with the read inside the predicate every gather waited for
+                    // its own LDS round trip (tail of r entries cost r serial LDS latencies).
+    #pragma unroll
+                    for (int j = 0; j < U - 1; ++j) {
+                        const int kj = k + ((j < rem) ? j : rem - 1);
+                        off[j] = s_off[wave][kj];
+                        if constexpr (VALUED) v[j] = s_val[wave][kj];
+                        else v[j] = 1.0f;
+                    }
+    #pragma unroll
+                    for (int j = 0; j < U - 1; ++j) {
+                        if (j < rem) {
+    #pragma unroll
+                            for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+                        }
+                    }
+    #pragma unroll
+                    for (int j = 0; j < U - 1; ++j) {
+                        if (j < rem) {
+    #pragma unroll
+                            for (int s = 0; s < S; ++s)
+    #pragma unroll
+                                for (int i = 0; i < V; ++i)
+                                    acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+                        }
+                    }
+                }
+                if (be <= tend) break;  // every row of this batch ends inside the resident tile
+                wave_lds_sync();        // all reads of the old tile are issued before it is overwritten
+                t0 = tend;
+                publish_tile();
+                fetch_tile_regs(t0 + kTile);
+                wave_lds_sync();
+            }
+
+            if (rowok2) {
+                const int crow = (planned && !(a.flags & kFlagDebugIdentityStore)) ? s_perm[wave][r] : row_first + r;
+                float* Crow = a.C + (size_t)crow * (size_t)a.N + col0;
+                const bool nts = (a.flags & kFlagNtStore) != 0;
+                const bool sc1 = (a.flags & kFlagSc1Store) != 0;
+    #pragma unroll
+                for (int s = 0; s < S; ++s)
+                    if (colok[s]) {
+                        if (sc1) store_vec_sc1<V>(Crow + s * (W * V), acc[s]);
+                        else if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                        else store_vec<V, false>(Crow + s * (W * V), acc[s]);
+                    }
+            }
         }
+
+        if (!has_next) break;
+        wave_lds_sync();  // this task's LDS image is read before the next task overwrites it
+        task_id += task_stride;
+        row_first = n_row_first;
+        nrows = n_nrows;
+        wb = n_wb;
+        we = n_we;
+        rp_plan = n_rp;
+        pm_plan = n_pm;
+        pc = n_pc;
+        pv = n_pv;
+        dnext = dnext2;
     }
 }
 
@@ -1290,7 +1347,16 @@ static hipError_t launch_stream(const SpmmArgs& a, int rpw, hipStream_t st) {
     args.rpw = rpw;
     args.nblk = (int)(((int64_t)a.M + kWaves * rpw - 1) / (kWaves * rpw));
     if (a.tasks) args.nblk = (a.ntasks + kWaves - 1) / kWaves;  // plan mode: one wavefront per task
-    const int64_t nitems = (int64_t)args.nblk * args.ntile;
+    int64_t nitems = (int64_t)args.nblk * args.ntile;
+    if (a.tasks && (a.flags & kFlagPersistentTasks)) {
+        // persistent wavefronts: as many workgroups per XCD as stay resident (8 per CU x 32 CUs), never more than tasks
+        int per_xcd = 256;
+        const int64_t tasks_per_xcd = ((int64_t)a.ntasks + 7) / 8;
+        while (per_xcd > 1 && (int64_t)per_xcd * kWaves > tasks_per_xcd) per_xcd >>= 1;
+        if (a.persist_wgs > 0 && a.persist_wgs < per_xcd) per_xcd = a.persist_wgs;
+        args.nblk = per_xcd;
+        nitems = (int64_t)8 * per_xcd * args.ntile;
+    }
     if (nitems <= 0) return hipSuccess;
     if (nitems > kMaxGridBlocks) return hipErrorInvalidConfiguration;
     // Gather depth U: 8 B-row loads in flight per lane group unless the accumulators are
