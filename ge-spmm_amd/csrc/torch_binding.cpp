@@ -178,6 +178,39 @@ torch::Tensor csr_sddmm(const torch::Tensor& rowptr, const torch::Tensor& colind
     return sddmm_impl(rowptr, "rowptr", true, colind, D1, D2);
 }
 
+// ---- plans (the analysis stage, gespmm_plan_*): the hot call of a training loop, so it gets the short path as well.
+// The Python class (spmm.SpmmPlan) owns the handle and the consistency checks; these two functions only launch.
+torch::Tensor plan_spmm(int64_t handle, const torch::Tensor& dense, const c10::optional<torch::Tensor>& out_opt, int64_t M) {
+    need(dense, "dense", torch::kFloat32, 2);
+    const int64_t N = dense.size(1);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dense.device());
+    torch::Tensor out;
+    if (out_opt.has_value()) {
+        out = *out_opt;
+        need(out, "out", torch::kFloat32, 2);
+        TORCH_CHECK_VALUE(out.size(0) == M && out.size(1) == N && out.device() == dense.device(), "out must be f32[M, N] on the same device");
+    } else {
+        out = torch::empty({M, N}, dense.options());
+    }
+    check_rc(gespmm_plan_spmm_f32(reinterpret_cast<gespmm_plan*>(handle), dense.data_ptr<float>(), out.data_ptr<float>(), N,
+                                  current_stream(dense)),
+             "gespmm_plan_spmm_f32");
+    return out;
+}
+
+torch::Tensor plan_sddmm(int64_t handle, const torch::Tensor& D1, const torch::Tensor& D2, int64_t nnz) {
+    need(D1, "D1", torch::kFloat32, 2);
+    need(D2, "D2", torch::kFloat32, 2);
+    TORCH_CHECK_VALUE(D1.size(1) == D2.size(1), "D1 and D2 must have the same number of columns");
+    same_device(D1, D2);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(D1.device());
+    auto out = torch::empty({nnz}, D1.options());
+    check_rc(gespmm_plan_sddmm_f32(reinterpret_cast<gespmm_plan*>(handle), D1.data_ptr<float>(), D2.data_ptr<float>(),
+                                   out.data_ptr<float>(), D1.size(1), current_stream(D1)),
+             "gespmm_plan_sddmm_f32");
+    return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -194,4 +227,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("csr2csc", &csr2csc, "csr2csc");
     m.def("coo_sddmm", &coo_sddmm, "COO SDDMM");
     m.def("csr_sddmm", &csr_sddmm, "CSR SDDMM");
+    m.def("plan_spmm", &plan_spmm, "SpMM through a gespmm_plan handle", py::arg("handle"), py::arg("dense"),
+          py::arg("out") = py::none(), py::arg("M") = 0);
+    m.def("plan_sddmm", &plan_sddmm, "SDDMM through a gespmm_plan handle");
 }

@@ -48,6 +48,8 @@ def csr_sddmm(rowptr, colind, D1, D2, plan=None):
             raise ValueError("the plan was made for a different (or since modified) pattern")
         if D1.shape[0] != rowptr.numel() - 1:
             raise ValueError("rowptr must have D1.size(0)+1 entries")
+        if _ext is not None and hasattr(_ext, "plan_sddmm"):
+            return _ext.plan_sddmm(plan._handle.value, D1, D2, colind.numel())
         out = torch.empty((colind.numel(),), dtype=torch.float32, device=dev)
         with _on_device(dev):
             rc = lib.gespmm_plan_sddmm_f32(plan._handle, _ptr(D1), _ptr(D2), _ptr(out), D1.shape[1], _stream(dev))
