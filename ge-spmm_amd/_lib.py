@@ -69,6 +69,7 @@ EXPORTS = [
     "gespmm_cluster_rows",
     "gespmm_simulate_l2_hits",
     "gespmm_debug_build_records",
+    "gespmm_debug_build_outer_records",
 ]
 
 PLAN_REORDER_AUTO = 0
@@ -78,6 +79,7 @@ PLAN_KERNEL_AUTO = 0
 PLAN_KERNEL_STREAM = 1
 PLAN_KERNEL_LDS_ROWS = 2
 PLAN_KERNEL_SEG_STREAM = 3
+PLAN_KERNEL_OUTER = 4
 
 
 class LaunchCfg(Structure):

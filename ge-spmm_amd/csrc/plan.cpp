@@ -52,6 +52,11 @@ struct gespmm_plan {
     int32_t ntasks = 0;
     int32_t* d_gtasks = nullptr;  // lane-group tasks of the segmented-stream kernel
     int32_t ngtasks = 0;
+    // task-outer kernel (spmm_outer.hip): one 544-byte record per task
+    int32_t* d_orecs = nullptr;
+    int32_t* d_orec_src = nullptr;
+    int32_t norec = 0;
+    double orec_dup = 0.0;
     // SDDMM through the plan (built on first use): edges in clustered order as COO with the ORIGINAL row ids, the
     // position of every edge in the caller's CSR, and a buffer for the results in clustered order
     int32_t* d_coo_row = nullptr;
@@ -110,11 +115,12 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 }
 
 void free_device(gespmm_plan* p) {
-    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp};
+    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp, p->d_orecs, p->d_orec_src};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = p->d_gtasks = p->d_coo_row = p->d_edge_dst = nullptr;
     p->d_sddmm_tmp = nullptr;
+    p->d_orecs = p->d_orec_src = nullptr;
     p->d_val = nullptr;
     p->ws = nullptr;
 }
@@ -252,6 +258,127 @@ void build_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, const s
     }
 }
 
+__global__ void scatter_outer_values_kernel(const int32_t* __restrict__ rec_src, const float* __restrict__ val,
+                                            int32_t* __restrict__ recs, int64_t nslots) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const int32_t src = rec_src[i];
+    if (src < 0) return;
+    const int64_t rec = i / gespmm::kOutEntries, k = i % gespmm::kOutEntries;
+    reinterpret_cast<float*>(recs)[rec * gespmm::kOutWords + gespmm::kOutOffVal + k] = val[src];
+}
+
+// Records of spmm_outer.hip: consecutive rows of the clustered order are packed (<= 8 rows, <= `target` (<= 64) entries,
+// <= 32 distinct columns) as long as each of them has strictly ascending columns; the record lists the sorted union of the
+// columns and, column by column, the (row, value) pairs that use it. A row with unsorted or repeated columns is a record
+// of its own whose "columns" are its entries in CSR order; a row that does not fit one record is a chain of such records.
+struct OuterBuilder {
+    std::vector<int32_t> recs, src;
+    int64_t entries = 0, distinct = 0;
+    int32_t nrec() const { return (int32_t)(recs.size() / gespmm::kOutWords); }
+    int32_t* open() {
+        recs.resize(recs.size() + gespmm::kOutWords, 0);
+        src.resize(src.size() + gespmm::kOutEntries, -1);
+        return recs.data() + recs.size() - gespmm::kOutWords;
+    }
+};
+
+void build_outer_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci,
+                         const std::vector<int32_t>& src_begin, const std::vector<int32_t>& perm, int target, OuterBuilder& ob) {
+    using namespace gespmm;
+    (void)K;
+    if (target <= 0 || target > kOutEntries) target = kOutEntries;
+    auto set_byte = [](int32_t* rec, int byte_off, int value) { reinterpret_cast<uint8_t*>(rec)[byte_off] = (uint8_t)value; };
+    auto ascending = [&](int64_t r) {
+        for (int32_t p = rp[r] + 1; p < rp[r + 1]; ++p)
+            if (ci[p] <= ci[p - 1]) return false;
+        return true;
+    };
+    std::vector<std::pair<int32_t, int32_t>> cols;  // (column, position in the permuted CSR)
+    int64_t i = 0;
+    while (i < M) {
+        const int32_t deg = rp[i + 1] - rp[i];
+        if (!ascending(i) || deg > kOutDistinct) {
+            // ---- a record (or chain) of its own: entries in CSR order, one "column" slot per entry
+            const size_t first_word = ob.recs.size();
+            int nseg = 0;
+            int32_t p = rp[i];
+            do {
+                int32_t* rec = ob.open();
+                const size_t sb = ob.src.size() - kOutEntries;
+                int n = 0;
+                while (p < rp[i + 1] && n < kOutDistinct) {
+                    rec[kOutOffDcol + n] = ci[p];
+                    set_byte(rec, kOutOffCptrBytes + n, n);
+                    set_byte(rec, kOutOffRowBytes + n, 0);
+                    ob.src[sb + n] = src_begin[i] + (p - rp[i]);
+                    ++n;
+                    ++p;
+                }
+                set_byte(rec, kOutOffCptrBytes + n, n);
+                rec[0] = 1;
+                rec[1] = n;
+                rec[2] = n;
+                rec[3] = 3;
+                rec[kOutOffCrow] = perm[i];
+                ob.entries += n;
+                ob.distinct += n;
+                ++nseg;
+            } while (p < rp[i + 1]);
+            ob.recs[first_word + 3] &= ~1;
+            ob.recs[first_word + (size_t)(nseg - 1) * kOutWords + 3] &= ~2;
+            ++i;
+            continue;
+        }
+        // ---- pack consecutive sorted rows
+        const int64_t first = i;
+        int nrows = 0, nent = 0;
+        cols.clear();
+        while (i < M && nrows < kOutRows) {
+            const int32_t d = rp[i + 1] - rp[i];
+            if (d > kOutDistinct || !ascending(i)) break;
+            if (nrows > 0 && nent + d > target) break;
+            // distinct columns if this row joins: merge count against the sorted union so far
+            std::vector<std::pair<int32_t, int32_t>> trial = cols;
+            for (int32_t p = rp[i]; p < rp[i + 1]; ++p) trial.emplace_back(ci[p], (int32_t)(i - first));
+            std::sort(trial.begin(), trial.end());
+            int nd = 0;
+            for (size_t t = 0; t < trial.size(); ++t)
+                if (t == 0 || trial[t].first != trial[t - 1].first) ++nd;
+            if (nd > kOutDistinct) break;
+            cols.swap(trial);
+            nent += d;
+            ++nrows;
+            ++i;
+        }
+        // cols = (column, row) pairs sorted by column then row: exactly the walk order of the kernel
+        int32_t* rec = ob.open();
+        const size_t sb = ob.src.size() - kOutEntries;
+        int nd = 0;
+        for (size_t t = 0; t < cols.size(); ++t) {
+            if (t == 0 || cols[t].first != cols[t - 1].first) {
+                rec[kOutOffDcol + nd] = cols[t].first;
+                set_byte(rec, kOutOffCptrBytes + nd, (int)t);
+                ++nd;
+            }
+            const int32_t r = cols[t].second;
+            set_byte(rec, kOutOffRowBytes + (int)t, r);
+            // position of (row, column) in the permuted CSR: the row is sorted, so a binary search finds it
+            const int64_t row = first + r;
+            const int32_t* lo = std::lower_bound(ci.data() + rp[row], ci.data() + rp[row + 1], cols[t].first);
+            ob.src[sb + t] = src_begin[row] + (int32_t)(lo - (ci.data() + rp[row]));
+        }
+        set_byte(rec, kOutOffCptrBytes + nd, (int)cols.size());
+        for (int r = 0; r < nrows; ++r) rec[kOutOffCrow + r] = perm[first + r];
+        rec[0] = nrows;
+        rec[1] = nent;
+        rec[2] = nd;
+        rec[3] = 0;
+        ob.entries += nent;
+        ob.distinct += nd;
+    }
+}
+
 template <typename T>
 hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
     const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
@@ -325,6 +452,35 @@ int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int
             *src_out = (int32_t*)malloc(rb.src.size() * 4 + 4);
             if (!*src_out) return GESPMM_ENOMEM;
             std::memcpy(*src_out, rb.src.data(), rb.src.size() * 4);
+        }
+    } catch (const std::bad_alloc&) {
+        return GESPMM_ENOMEM;
+    }
+    return 0;
+}
+
+// The same hook for the records of the task-outer kernel (spmm_outer.hip): nrec x 136 int32, src nrec x 64.
+int gespmm_debug_build_outer_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
+                                     int32_t target, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out) {
+    if (!rowptr || !perm || !recs_out || !nrec_out || M < 0 || K <= 0) return GESPMM_EINVAL;
+    try {
+        std::vector<int32_t> rp((size_t)M + 1, 0), src((size_t)M, 0), pv(perm, perm + M);
+        for (int64_t i = 0; i < M; ++i) rp[i + 1] = rp[i] + (rowptr[perm[i] + 1] - rowptr[perm[i]]);
+        std::vector<int32_t> ci((size_t)rp[M]);
+        for (int64_t i = 0; i < M; ++i) {
+            src[i] = rowptr[perm[i]];
+            std::memcpy(ci.data() + rp[i], colind + src[i], (size_t)(rp[i + 1] - rp[i]) * 4);
+        }
+        OuterBuilder ob;
+        build_outer_records(M, K, rp, ci, src, pv, target, ob);
+        *nrec_out = ob.nrec();
+        *recs_out = (int32_t*)malloc(ob.recs.size() * 4 + 4);
+        if (!*recs_out) return GESPMM_ENOMEM;
+        std::memcpy(*recs_out, ob.recs.data(), ob.recs.size() * 4);
+        if (src_out) {
+            *src_out = (int32_t*)malloc(ob.src.size() * 4 + 4);
+            if (!*src_out) return GESPMM_ENOMEM;
+            std::memcpy(*src_out, ob.src.data(), ob.src.size() * 4);
         }
     } catch (const std::bad_alloc&) {
         return GESPMM_ENOMEM;
@@ -515,6 +671,23 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                     e = hipGetLastError();
                 }
             }
+            // ---- records of the task-outer kernel (short-row matrices without the long-row pass)
+            OuterBuilder ob;
+            if (e == hipSuccess && p->kernel_choice != GESPMM_PLAN_KERNEL_STREAM && p->kernel_choice != GESPMM_PLAN_KERNEL_SEG_STREAM &&
+                p->kernel_choice != GESPMM_PLAN_KERNEL_LDS_ROWS && !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) && K > 0 &&
+                p->kernel_choice == GESPMM_PLAN_KERNEL_OUTER) {  // opt-in: measured level with the batch-stream kernel, not ahead
+                build_outer_records(M, K, rp, ci, src, p->perm_host, (opt && opt->task_entries > 0) ? opt->task_entries : 0, ob);
+                p->norec = ob.nrec();
+                p->orec_dup = ob.distinct > 0 ? (double)ob.entries / (double)ob.distinct : 0.0;
+                e = upload(&p->d_orecs, ob.recs, st);
+                if (e == hipSuccess) e = upload(&p->d_orec_src, ob.src, st);
+                if (e == hipSuccess && p->valued && p->norec > 0) {
+                    const int64_t nslots = (int64_t)p->norec * gespmm::kOutEntries;
+                    hipLaunchKernelGGL(scatter_outer_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
+                                       p->d_orec_src, val, p->d_orecs, nslots);
+                    e = hipGetLastError();
+                }
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors go out of scope
             if (e != hipSuccess) {
                 free_device(p);
@@ -568,7 +741,23 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     // opt-in (GESPMM_PLAN_KERNEL_LDS_ROWS): 118-128 us vs 108-113 us for the batch-stream kernel on the clustered bench
     // graph — its sums are instruction-issue bound at the 8 wavefronts per CU its LDS footprint allows
     if (lds_rows && p->kernel_choice != GESPMM_PLAN_KERNEL_LDS_ROWS) lds_rows = false;
-    if (lds_rows) {
+    const int oV = gespmm::outer_vec_width(N);
+    bool outer = p->reordered && p->d_orecs && p->norec > 0 && oV > 0 && variant_v4 && !lds_rows &&
+                 (reinterpret_cast<uintptr_t>(B) % (4u * oV)) == 0 && (reinterpret_cast<uintptr_t>(C) % (4u * oV)) == 0;
+    if (outer && p->kernel_choice != GESPMM_PLAN_KERNEL_OUTER) outer = false;
+    if (outer) {
+        if (!B || !C) return GESPMM_EINVAL;
+        gespmm::OuterArgs oa;
+        oa.recs = p->d_orecs;
+        oa.B = B;
+        oa.C = C;
+        oa.nrec = p->norec;
+        oa.N = (int32_t)N;
+        oa.ntile = oa.nblk = 0;
+        oa.empty = empty;
+        const bool idx64 = (uint64_t)p->K * (uint64_t)N * 4ull >= (1ull << 32);
+        rc = (int)gespmm::launch_spmm_outer(oa, p->valued, idx64, reduce, reinterpret_cast<hipStream_t>(stream));
+    } else if (lds_rows) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::LdsRowArgs la;
         la.recs = p->d_recs;
@@ -667,6 +856,11 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     if (p->nnz == 0) return 0;
     hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
                        p->d_src_begin, val, p->d_val, (int)p->M, (int)p->nnz);
+    if (p->d_orecs && p->norec > 0) {
+        const int64_t nslots = (int64_t)p->norec * gespmm::kOutEntries;
+        hipLaunchKernelGGL(scatter_outer_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
+                           p->d_orec_src, val, p->d_orecs, nslots);
+    }
     if (p->d_recs && p->nrec > 0) {
         const int64_t nslots = (int64_t)p->nrec * gespmm::kRecEntries;
         hipLaunchKernelGGL(scatter_record_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
@@ -698,7 +892,12 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         const int W = gespmm::ldsrow_group_width(p->N);
         const bool lds = p->d_recs && p->nrec > 0 && W > 0 && p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS &&
                          (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
-        if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
+        const int oV = gespmm::outer_vec_width(p->N);
+        const bool outer = !lds && p->d_orecs && p->norec > 0 && oV > 0 &&
+                           p->kernel_choice == GESPMM_PLAN_KERNEL_OUTER &&
+                           (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
+        if (outer) snprintf(kern, sizeof kern, "kernel=task-outer V=%d records=%d nnz_per_distinct_row=%.2f", oV, p->norec, p->orec_dup);
+        else if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
         else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d max_degree=%d l2_model=%.3f->%.3f "

@@ -136,6 +136,36 @@ struct LdsRowArgs {
 int ldsrow_group_width(int64_t N);  // lanes per row (4..32), 0 if N is not served (N % 4 != 0)
 hipError_t launch_spmm_ldsrow(const LdsRowArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
 
+// spmm_outer.hip — task-outer kernel of clustered plans. A task is one RECORD of 136 words (plan.cpp):
+//   words 0-3      nrows (<= 8), nent (<= 64), ndist (<= 32), flags (bit 0: continues FROM the previous record, bit 1: INTO the next)
+//   words 4-11     C row of each row             } one word load: word 4 + lane, lanes 0..39
+//   words 12-43    the distinct columns, ascending (or, for a row with unsorted / repeated columns, its entries in CSR order)
+//   words 44-107   value of each entry (fp32), entries in (column, row) order
+//   bytes 432-495  row (0..7) of each entry
+//   bytes 496-528  first entry of each distinct column (ndist + 1 values)
+constexpr int kOutRows = 8;
+constexpr int kOutDistinct = 32;
+constexpr int kOutEntries = 64;
+constexpr int kOutWords = 136;
+constexpr int kOutOffCrow = 4;
+constexpr int kOutOffDcol = 12;
+constexpr int kOutOffVal = 44;
+constexpr int kOutOffRowBytes = 108 * 4;
+constexpr int kOutOffCptrBytes = 124 * 4;
+
+struct OuterArgs {
+    const int32_t* recs;
+    const float* B;
+    float* C;
+    int32_t nrec;
+    int32_t N;
+    int32_t ntile;  // filled in by the launcher
+    int32_t nblk;
+    float empty;
+};
+int outer_vec_width(int64_t N);  // floats per lane (1, 2, 4), 0 if this width is not served
+hipError_t launch_spmm_outer(const OuterArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
+
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form
 hipError_t launch_sddmm(const int32_t* rowind_or_rowptr, bool csr, const int32_t* colind,

@@ -114,7 +114,7 @@ class SpmmPlan:
         self.device = dev
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
         kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "lds-rows": _lib.PLAN_KERNEL_LDS_ROWS,
-                "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM}[kernel]
+                "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM, "task-outer": _lib.PLAN_KERNEL_OUTER}[kernel]
         opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern)
         self._handle = ctypes.c_void_p()
         M, K_, N_, nnz, var = self.shape

@@ -282,6 +282,8 @@ typedef struct gespmm_plan_options {
 #define GESPMM_PLAN_KERNEL_AUTO     0  /* LDS-staged rows when the tasks' rows share B rows, else the streaming kernel */
 #define GESPMM_PLAN_KERNEL_STREAM   1  /* batch-stream kernel on the task table */
 #define GESPMM_PLAN_KERNEL_SEG_STREAM 3 /* segmented-stream kernel on a task table per lane group */
+#define GESPMM_PLAN_KERNEL_OUTER 4      /* task-outer kernel: each distinct B row of a task loaded once into registers and applied
+                                          to every row of the task that uses it (N >= 64, no long-row pass) */
 #define GESPMM_PLAN_KERNEL_LDS_ROWS 2  /* distinct B rows of a task fetched once into LDS (N % 4 == 0, no long-row pass) */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,
@@ -326,6 +328,9 @@ double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int
  */
 int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                int32_t task_entries, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out);
+/* The same for the task-outer kernel's records (nrec x 136 int32; src nrec x 64). */
+int gespmm_debug_build_outer_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
+                                     int32_t task_entries, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out);
 
 /*
  * Comparison column, not a product path: the Gunrock app's edge map

@@ -60,11 +60,13 @@ def main():
             plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=False)
             us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
             print("%s N=%d storage-order plan    %8.1f us  frac %.3f" % (name, N, us, abytes / us / 8e6), flush=True)
-            for kernel in ("stream", "seg-stream", "lds-rows"):
+            for kernel in ("stream", "seg-stream", "lds-rows", "task-outer"):
                 if kernel == "lds-rows" and N % 4:
                     continue
                 for te in [int(x) for x in args.entries.split(",")]:
                     if kernel == "lds-rows" and te > 32:
+                        continue
+                    if kernel == "task-outer" and (te > 64 or N < 64):
                         continue
                     t0 = time.time()
                     plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=te, kernel=kernel)
