@@ -1,0 +1,5 @@
+for k in 16 32 64 128 256 512; do
+  for f in 0x20; do
+    python profiles/r02/scripts/fetch_calibration.py --m 232965 --degs 64 --k $k --flags $f --iters 20 2>&1 | grep gathers | awk -v k=$k '{us=$0; sub(/.*: /,"",us); sub(/ us.*/,"",us); n=$0; sub(/.*\| /,"",n); sub(/ gathers.*/,"",n); printf "k=%d (%.3f MB of B) flags=%s: %s us -> %.1f TB/s of gathers\n", k, k*512/1e6, "'$f'", us, n*512/us/1e6}'
+  done
+done
