@@ -639,7 +639,12 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             };
             std::vector<int32_t> tasks, gtasks;
             cut_tasks(budget, true, tasks);
-            cut_tasks(budget / 2 > 16 ? budget / 2 : 16, false, gtasks);
+            // (short rows: 16 entries per lane group — profiles/r02/plan_seg_task_size.log: 139 us at 16, 146 at 24, 150 at 32
+            // on the com-Amazon stand-in)
+            int gbudget = budget / 2 > 16 ? budget / 2 : 16;
+            if (opt && opt->task_entries > 0) gbudget = opt->task_entries / 2 > 4 ? opt->task_entries / 2 : 4;
+            else if (mean < 16) gbudget = 16;
+            cut_tasks(gbudget, false, gtasks);
             p->ngtasks = (int32_t)(gtasks.size() / 4);
             p->ntasks = (int32_t)(tasks.size() / 4);
             e = upload(&p->d_rowptr, rp, st);
@@ -726,6 +731,23 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
     return 0;
 }
 
+// Which streaming kernel a clustered plan launches (AUTO rule + the caller's choice).
+//   segmented-stream (one continuous gather stream per lane group):
+//     * ahead of the batch kernel on clustered matrices with longer rows at one column tile (products-shaped communities,
+//       N = 128: 3.70 vs 4.34 ms; N = 16/32: 1.06 vs 1.41, 1.36 vs 1.69 ms), a tie at N = 64 (plan_products_kernels.log,
+//       plan_seg_widths.log);
+//     * ahead by 2-5 % on short rows at N >= 128 once its lane-group tasks are 16 entries (com-Amazon stand-ins: 139 vs 145 us
+//       at N = 128, 263 vs 268 at 256, 544 vs 557 at 512; plan_seg_task_size.log) — big matrices only: on pubmed / cit-HepTh
+//       sized graphs the batch kernel's larger tasks win (9.5 vs 13.2 us, 30 vs 45 us);
+//   batch-stream otherwise, and whenever long rows are split (run_spmm decides that).
+static bool plan_prefers_segmented(const gespmm_plan* p, int64_t N) {
+    if (p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM) return true;
+    if (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return false;
+    const int64_t mean_deg = p->M > 0 ? p->nnz / p->M : 0;
+    return p->nnz >= (1 << 20) && N % 4 == 0 &&
+           ((mean_deg >= 16 && p->hits_after >= 0.40 && (N <= 32 || (N > 64 && N <= 128))) || (mean_deg < 16 && N >= 128));
+}
+
 static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream) {
     if (!p || N < 0) return GESPMM_EINVAL;
     if (reduce == gespmm::kReduceMax && p->valued) return GESPMM_EINVAL;
@@ -772,16 +794,8 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         const bool idx64 = (uint64_t)p->K * (uint64_t)N * 4ull >= (1ull << 32);
         rc = (int)gespmm::launch_spmm_ldsrow(la, p->valued, idx64, reduce, reinterpret_cast<hipStream_t>(stream));
     } else if (p->reordered) {
-        // segmented-stream kernel where the rows are short and the clustered order hits L2 (its continuous gather stream
-        // hides the mixed hit/miss latencies better); batch-stream kernel otherwise and whenever long rows are split
-        // segmented-stream kernel (one continuous gather stream per lane group): ahead of the batch kernel on
-        // clustered matrices with longer rows at one 128-column tile (products-shaped communities, N = 128: 3.70 vs
-        // 4.34 ms), behind it on short rows (com-Amazon-shaped: 118 vs 108 us) and at the other tile widths
-        // (profiles/r02/plan_products_kernels.log)
-        const int64_t mean_deg = p->M > 0 ? p->nnz / p->M : 0;
-        const bool seg = p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM ||
-                         (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean_deg >= 16 && p->hits_after >= 0.40 && N > 64 &&
-                          N <= 128 && N % 4 == 0);
+        // (which streaming kernel: plan_prefers_segmented)
+        const bool seg = plan_prefers_segmented(p, N);
         static const int dbg_wgs = getenv("GESPMM_PERSIST_WGS") ? atoi(getenv("GESPMM_PERSIST_WGS")) : 0;  // experiments only
         gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg, dbg_wgs};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
@@ -880,7 +894,8 @@ int gespmm_plan_get_order(const gespmm_plan* p, int32_t* perm_host) {
 int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
     if (!p || !out || capacity <= 0) return GESPMM_EINVAL;
     char what[256] = "";
-    gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags | (p->reordered ? (GESPMM_FLAG_BATCH_STREAM | GESPMM_FLAG_NO_SLAB_BLOCKED) : 0)};
+    const bool seg = p->reordered && p->d_gtasks && plan_prefers_segmented(p, p->N);
+    gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags | (p->reordered ? ((seg ? GESPMM_FLAG_SEG_STREAM : GESPMM_FLAG_BATCH_STREAM) | GESPMM_FLAG_NO_SLAB_BLOCKED) : 0)};
     gespmm_describe_launch(p->M, p->K, p->N, p->nnz, p->variant, &cfg, what, sizeof what);
     int n;
     if (p->reordered) {
@@ -900,9 +915,9 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         else if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
         else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity,
-                     "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d max_degree=%d l2_model=%.3f->%.3f "
+                     "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "
                      "analysis=%.3fs (clustering %.3fs) | %s",
-                     p->stats.levels, lv, p->ntasks, p->task_entries, p->max_degree, p->hits_before, p->hits_after,
+                     p->stats.levels, lv, p->ntasks, p->task_entries, p->ngtasks, p->max_degree, p->hits_before, p->hits_after,
                      p->analysis_seconds, p->cluster_seconds, kern);
     } else {
         n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.3fs | %s",
