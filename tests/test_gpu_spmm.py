@@ -516,3 +516,34 @@ def test_extension_and_ctypes_bindings_agree(pkg, oracle, bundled):
                      (lambda: _ext.ext.csr_spmm_no_edge_value(rp, ci, B, 17), RuntimeError)):
         with pytest.raises(exc):
             bad()
+
+
+def test_very_short_rows_take_the_segmented_kernel_and_keep_the_bits(pkg, oracle):
+    """Mean degree <= 3 on a big matrix (road-network-like): AUTO picks the segmented-stream kernel (select.cpp);
+    the bits are the oracle's, empty rows included."""
+    import ctypes
+
+    from gespmm_amd import _lib
+
+    def describe(M, K, N, nnz):
+        buf = ctypes.create_string_buffer(256)
+        assert _lib.lib.gespmm_describe_launch(M, K, N, nnz, -1, None, buf, 256) > 0
+        return buf.value.decode()
+
+    rng = np.random.default_rng(11)
+    M = K = 70001
+    deg = rng.integers(0, 5, size=M)  # 0..4 entries, mean 2
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, K, size=nnz).astype(np.int32)
+    for r in rng.integers(0, M, size=2000):  # sorted or not must not matter; sort a few rows only
+        colind[rowptr[r]:rowptr[r + 1]].sort()
+    G = {"rowptr": rowptr, "colind": colind, "M": M, "K": K, "nnz": nnz}
+    val = oracle.hash_val(nnz, seed=3)
+    for N in (128, 100, 256):
+        what = describe(M, K, N, nnz)
+        assert "segmented-stream" in what, what
+        B = oracle.hash_B(K, N, seed=2)
+        assert_bits_equal(run(pkg, G, B, val), oracle.spmm(rowptr, colind, val, B, "fma"), "short rows N=%d valued" % N)
+        assert_bits_equal(run(pkg, G, B, None), oracle.spmm(rowptr, colind, None, B, "golden"), "short rows N=%d" % N)
