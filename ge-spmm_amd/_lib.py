@@ -32,7 +32,6 @@ FLAG_NO_SLAB_BLOCKED = 0x800
 FLAG_ALLOW_REASSOCIATION = 0x1000
 FLAG_REUSE_SPLIT = 0x2000
 FLAG_SHALLOW_UNROLL = 0x10
-FLAG_PERSISTENT_TASKS = 0x40000
 
 # Every symbol include/gespmm.h declares; tests check the library exports all of them.
 EXPORTS = [

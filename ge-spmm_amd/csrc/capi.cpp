@@ -120,7 +120,6 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.ntasks = pl ? pl->ntasks : 0;
     a.gtasks = pl ? pl->gtasks : nullptr;
     a.ngtasks = pl ? pl->ngtasks : 0;
-    a.persist_wgs = pl ? pl->persist_wgs : 0;
 
     hipError_t e;
     a.rpw = sel.geo.rows_per_group;

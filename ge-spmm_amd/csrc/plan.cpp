@@ -796,8 +796,7 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     } else if (p->reordered) {
         // (which streaming kernel: plan_prefers_segmented)
         const bool seg = plan_prefers_segmented(p, N);
-        static const int dbg_wgs = getenv("GESPMM_PERSIST_WGS") ? atoi(getenv("GESPMM_PERSIST_WGS")) : 0;  // experiments only
-        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg, dbg_wgs};
+        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
                               p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
     } else {

@@ -13,7 +13,6 @@ struct PlanLaunch {
     const int32_t* gtasks; // int4 per lane-group task of the segmented-stream kernel (device), may be NULL
     int32_t ngtasks;
     bool prefer_segmented; // launch the segmented-stream kernel when the geometry allows it
-    int32_t persist_wgs;   // persistent batch-stream kernel: workgroups per XCD (0 = library default)
 };
 
 int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,

@@ -31,9 +31,6 @@ constexpr int kFlagSlabBlocked = 0x400;   // == GESPMM_FLAG_SLAB_BLOCKED (force 
 constexpr int kFlagNoSlabBlocked = 0x800; // == GESPMM_FLAG_NO_SLAB_BLOCKED
 constexpr int kFlagReuseSplit = 0x2000;   // == GESPMM_FLAG_REUSE_SPLIT
 constexpr int kFlagAllowReassoc = 0x1000; // == GESPMM_FLAG_ALLOW_REASSOCIATION
-constexpr int kFlagDebugIdentityStore = 0x4000;  // experiments only: plan mode writes C in processing order (WRONG rows)
-constexpr int kFlagSc1Store = 0x8000;     // == GESPMM_FLAG_SC1_STORE: C stores do not stay in the XCD's L2
-constexpr int kFlagPersistentTasks = 0x40000;  // == GESPMM_FLAG_PERSISTENT_TASKS (plans: persistent wavefronts, cross-task prefetch)
 constexpr int kFlagSegStream = 0x80;     // == GESPMM_FLAG_SEG_STREAM (force the segmented-stream kernel)
 
 struct SpmmArgs {
@@ -67,7 +64,6 @@ struct SpmmArgs {
     // the same for the segmented-stream kernel, whose unit of work is a lane GROUP: group q works on gtasks[q]
     const int32_t* gtasks;
     int32_t ngtasks;
-    int32_t persist_wgs;  // persistent mode: workgroups per XCD (0 = as many as stay resident)
 };
 
 // Launch geometry resolved by the host-side selector (select.cpp).
@@ -90,6 +86,9 @@ struct Geometry {
 hipError_t launch_spmm_naive(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_stream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 hipError_t launch_spmm_segstream(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+// spmm_stream_plan.hip: the same two kernels on a plan's task table (a.tasks / a.gtasks + a.perm)
+hipError_t launch_spmm_stream_planned(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
+hipError_t launch_spmm_segstream_planned(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 // The two paths below need a temporary: the caller's (ext_ws, 16-byte aligned, >= *_workspace_bytes) or,
 // when that is absent or too small, a stream-ordered block from the library's pool (workspace.h).
 size_t longrows_workspace_bytes(int64_t nnz, int64_t N, int long_row);

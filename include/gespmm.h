@@ -158,9 +158,6 @@ typedef struct gespmm_launch_cfg {
                                              wrote for the SAME rowptr/colind/N/cfg (cache-blocked path): skip the scan. The caller
                                              vouches that the graph did not change; ignored on every other path */
 #define GESPMM_FLAG_ALLOW_REASSOCIATION 0x1000 /* AUTO may pick the parallel-reduction variant (N <= 16, dense rows) */
-#define GESPMM_FLAG_PERSISTENT_TASKS 0x40000 /* plans only (gespmm_plan_options.flags): the batch-stream kernel runs as persistent
-                                             wavefronts that fetch the next task's description and first CSR tile while the
-                                             current task is summed */
 #define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (default for group >= 32) */
 
 int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const float* val,

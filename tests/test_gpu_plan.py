@@ -50,29 +50,6 @@ def test_clustered_plan_bits_equal_oracle(pkg, oracle, bundled, graph):
         del plan
 
 
-def test_persistent_wavefronts_keep_the_bits(pkg, oracle, bundled):
-    """GESPMM_FLAG_PERSISTENT_TASKS: the batch-stream kernel as persistent wavefronts that prefetch the next task — an
-    execution-order change only."""
-    from gespmm_amd import _lib, graphs, spmm
-
-    for G, widths in ((bundled["pubmed"], (32, 128, 260, 512)), (edge_case_csr(seed=2), (7, 64, 132))):
-        rp, ci = _dev(G["rowptr"]), _dev(G["colind"])
-        val_h = oracle.hash_val(G["nnz"], seed=9)
-        for N in widths:
-            B_h = oracle.hash_B(G["K"], N, seed=N)
-            for te in (0, 8, 40):
-                plan = spmm.SpmmPlan(rp, ci, G["K"], N, values=_dev(val_h), reorder=True, task_entries=te, kernel="stream",
-                                     flags=_lib.FLAG_PERSISTENT_TASKS)
-                got = plan.run(None, _dev(B_h)).cpu().numpy()
-                assert np.array_equal(bits(got), bits(oracle.spmm(G["rowptr"], G["colind"], val_h, B_h, "fma"))), (N, te)
-    g = graphs.rmat_shard(16, 16, 0, 1, seed=3, device="cuda")  # hub rows: long-row registration from persistent wavefronts
-    val = torch.rand(g["nnz"], device="cuda") - 0.5
-    B = torch.rand(g["K"], 64, device="cuda") - 0.5
-    a = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 64, values=val, reorder=True, kernel="stream", flags=_lib.FLAG_PERSISTENT_TASKS)
-    b = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 64, values=val, reorder=True, kernel="stream")
-    assert torch.equal(a.run(None, B).view(torch.int32), b.run(None, B).view(torch.int32))
-
-
 def test_values_edited_in_place_are_picked_up(pkg, oracle, bundled):
     from gespmm_amd import spmm
 
@@ -150,6 +127,7 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     plan = spmm.SpmmPlan(rp, ci, M, 128, values=val)
     d = plan.describe()
     assert d.startswith("order=clustered"), d
+    assert "kernel=segmented-stream" in d and "group_tasks=" in d, d  # short rows at N >= 128 (plan_prefers_segmented)
     B = (torch.randint(0, 100, (M, 128), device="cuda", dtype=torch.int32) - 50).float() / 100
     got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
     ref = spmm.csr_spmm(rp, ci, val, B)
@@ -157,6 +135,8 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     # structureless stand-in: whatever AUTO decides, the bits stay
     g2 = graphs.synthetic_graph("com-amazon-like", seed=42, device="cuda")
     plan2 = spmm.SpmmPlan(g2["rowptr"], g2["colind"], M, 128, values=val)
+    assert "kernel=segmented-stream" in plan2.describe(), plan2.describe()
+    assert "kernel=batch-stream" in spmm.SpmmPlan(g2["rowptr"], g2["colind"], M, 32, values=val).describe()
     got2 = spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B, plan=plan2)
     assert torch.equal(got2.view(torch.int32), spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B).view(torch.int32))
     # N = 32 and 512 through plans of their own
