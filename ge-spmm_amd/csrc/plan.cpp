@@ -389,10 +389,12 @@ hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
 }
 
 // Non-zeros per wavefront task. Storage-order launches take ~12 KB of gathered B per task (select.cpp);
-// clustered plans take ~32 KB (64 entries at N = 128; profiles/r02/plan_task_size.log), see the caller for the L2-hit case.
+// clustered plans take ~24 KB (48 entries at N = 128, 32 at N >= 256, 96 at N <= 64: profiles/r02/plan_task_size_final.log — at
+// N = 128 anything from 40 to 80 entries runs within 1 %, and the smaller task keeps fewer rows in flight per XCD, i.e. less
+// fabric traffic for the same time), see the caller for the L2-hit case.
 int default_task_entries(int64_t N) {
     const int64_t row_bytes = 4 * (N < 256 ? N : 256);
-    int64_t t = (32 << 10) / (row_bytes > 0 ? row_bytes : 4);
+    int64_t t = (24 << 10) / (row_bytes > 0 ? row_bytes : 4);
     if (t < 32) t = 32;
     if (t > 96) t = 96;  // narrow rows (N = 32: 128-byte rows) are latency-bound per row pair: the plain path's 96 entries
     return (int)t;
@@ -732,20 +734,19 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
 }
 
 // Which streaming kernel a clustered plan launches (AUTO rule + the caller's choice).
-//   segmented-stream (one continuous gather stream per lane group):
-//     * ahead of the batch kernel on clustered matrices with longer rows at one column tile (products-shaped communities,
-//       N = 128: 3.70 vs 4.34 ms; N = 16/32: 1.06 vs 1.41, 1.36 vs 1.69 ms), a tie at N = 64 (plan_products_kernels.log,
-//       plan_seg_widths.log);
-//     * ahead by 2-5 % on short rows at N >= 128 once its lane-group tasks are 16 entries (com-Amazon stand-ins: 139 vs 145 us
-//       at N = 128, 263 vs 268 at 256, 544 vs 557 at 512; plan_seg_task_size.log) — big matrices only: on pubmed / cit-HepTh
-//       sized graphs the batch kernel's larger tasks win (9.5 vs 13.2 us, 30 vs 45 us);
-//   batch-stream otherwise, and whenever long rows are split (run_spmm decides that).
+//   segmented-stream (one continuous gather stream per lane group): ahead of the batch kernel on clustered matrices with
+//     longer rows at one column tile (products-shaped communities, N = 128: 3.95 vs 4.37 ms; N = 16: 1.06 vs 1.17 ms; N = 32:
+//     1.35 vs 1.38), behind at N = 64 (2.25 vs 2.03);
+//   batch-stream otherwise — on short rows the two are within 2 % of each other at N >= 128 (com-Amazon stand-ins: 138.5 vs
+//     140.1 us at 128, 267.7 vs 261.8 at 256, 574.6 vs 570.4 at 512) and the batch kernel is far ahead below (N = 64: 61 vs 91 us)
+//     and on small graphs (pubmed N = 128: 9.6 vs 13.2 us) — and whenever long rows are split (run_spmm decides that).
+//   (profiles/r02/plan_seg_widths.log; an earlier version of the planned batch kernel carried runtime plan / persistent-task
+//   branches and lost 5 % to the segmented kernel on short rows — see plain_path_regression.log.)
 static bool plan_prefers_segmented(const gespmm_plan* p, int64_t N) {
     if (p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM) return true;
     if (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return false;
     const int64_t mean_deg = p->M > 0 ? p->nnz / p->M : 0;
-    return p->nnz >= (1 << 20) && N % 4 == 0 &&
-           ((mean_deg >= 16 && p->hits_after >= 0.40 && (N <= 32 || (N > 64 && N <= 128))) || (mean_deg < 16 && N >= 128));
+    return p->nnz >= (1 << 20) && N % 4 == 0 && mean_deg >= 16 && p->hits_after >= 0.40 && (N <= 32 || (N > 64 && N <= 128));
 }
 
 static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream) {

@@ -127,7 +127,7 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     plan = spmm.SpmmPlan(rp, ci, M, 128, values=val)
     d = plan.describe()
     assert d.startswith("order=clustered"), d
-    assert "kernel=segmented-stream" in d and "group_tasks=" in d, d  # short rows at N >= 128 (plan_prefers_segmented)
+    assert "kernel=batch-stream" in d and "group_tasks=" in d, d  # short rows: batch kernel (plan_prefers_segmented)
     B = (torch.randint(0, 100, (M, 128), device="cuda", dtype=torch.int32) - 50).float() / 100
     got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
     ref = spmm.csr_spmm(rp, ci, val, B)
@@ -135,8 +135,7 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     # structureless stand-in: whatever AUTO decides, the bits stay
     g2 = graphs.synthetic_graph("com-amazon-like", seed=42, device="cuda")
     plan2 = spmm.SpmmPlan(g2["rowptr"], g2["colind"], M, 128, values=val)
-    assert "kernel=segmented-stream" in plan2.describe(), plan2.describe()
-    assert "kernel=batch-stream" in spmm.SpmmPlan(g2["rowptr"], g2["colind"], M, 32, values=val).describe()
+    assert "kernel=batch-stream" in plan2.describe(), plan2.describe()
     got2 = spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B, plan=plan2)
     assert torch.equal(got2.view(torch.int32), spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B).view(torch.int32))
     # N = 32 and 512 through plans of their own
