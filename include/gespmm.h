@@ -158,7 +158,8 @@ typedef struct gespmm_launch_cfg {
                                              wrote for the SAME rowptr/colind/N/cfg (cache-blocked path): skip the scan. The caller
                                              vouches that the graph did not change; ignored on every other path */
 #define GESPMM_FLAG_ALLOW_REASSOCIATION 0x1000 /* AUTO may pick the parallel-reduction variant (N <= 16, dense rows) */
-#define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (default for group >= 32) */
+#define GESPMM_FLAG_SEG_STREAM     0x80 /* force the segmented-stream kernel (AUTO takes it for short rows over an L2-resident B and
+                                           for mean degree <= 3; ignored where long rows are split) */
 
 int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const float* val,
                             const float* B, float* C,
@@ -276,7 +277,7 @@ typedef struct gespmm_plan_options {
     int32_t kernel;        /* GESPMM_PLAN_KERNEL_*: which kernel a clustered plan launches */
 } gespmm_plan_options;
 
-#define GESPMM_PLAN_KERNEL_AUTO     0  /* LDS-staged rows when the tasks' rows share B rows, else the streaming kernel */
+#define GESPMM_PLAN_KERNEL_AUTO     0  /* batch-stream kernel on the task table; segmented-stream for products-shaped rows */
 #define GESPMM_PLAN_KERNEL_STREAM   1  /* batch-stream kernel on the task table */
 #define GESPMM_PLAN_KERNEL_SEG_STREAM 3 /* segmented-stream kernel on a task table per lane group */
 #define GESPMM_PLAN_KERNEL_OUTER 4      /* task-outer kernel: each distinct B row of a task loaded once into registers and applied
