@@ -202,8 +202,8 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     // split. The segmented kernel keeps the short-row, L2-resident-B corner (58 vs 68 us,
     // kernel_generations_cache_regimes.log) and is otherwise opt-in (GESPMM_FLAG_SEG_STREAM).
     // ... and very short rows (mean degree <= 3: road-network-like), where the batch kernel spends a dependent round trip per
-    // row pair and the continuous stream runs at copy speed (M = 335 k, N = 128, every row 1 / 2 / 3 entries: 64 / 76 / 99 us vs
-    // 92 / 103 / 106 us; degrees 1..8 mixed, mean 2.75: 92 vs 112 us; profiles/r02/low_degree_floor.log)
+    // row pair and the continuous stream runs at copy speed (M = 335 k, N = 128, every row 1 / 2 / 3 entries: 64-69 / 76 / 98 us vs
+    // 79-82 / 91 / 101 us; degrees 1..8 mixed, mean 2.75: 92 vs 102 us; profiles/r02/low_degree_floor.log)
     g.segmented = ((flags & kFlagSegStream) != 0 || (b_resident && g.group >= 32 && avg_deg <= 12) ||
                    (g.group >= 32 && avg_deg <= 3 && M >= (1 << 16))) &&
                   !g.split_long_rows && !(g.strips == 2 && g.vec < 4);
