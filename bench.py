@@ -548,6 +548,9 @@ def run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, mak
 
     L = 64
     kernel_s = wall / args.steps
+    # the same graph on ONE MI355X (one-rank RCCL runs of this mode, profiles/r02/bench_rmat{22,24,26}_torchrun1.log): what a
+    # strong-scaling efficiency of this line is relative to (the driver's N = 1 line is the com-Amazon BENCH workload)
+    one_gpu_ms = {(22, 256): 8.59, (24, 256): 36.48, (26, 256): 155.82}.get((scale, N))
     return {
         "metric": "SpMM GFLOP/s (= 2*nnz*N/t), CSR x dense fp32, N=%d" % N,
         "value": value,
@@ -586,6 +589,10 @@ def run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, mak
             "amortised_over_L": {"L": L, "gflops": 2.0 * nnz_total * N * L / (exchange_ms / 1e3 + L * kernel_s) / 1e9,
                                  "note": "one replication of B reused by L products (layers x epochs of a static feature matrix)"},
         },
+        "strong_scaling_reference": None if one_gpu_ms is None else {
+            "one_gpu_ms_per_step": one_gpu_ms, "one_gpu_gflops": 2.0 * nnz_total * N / one_gpu_ms / 1e6,
+            "speedup_vs_one_gpu": one_gpu_ms / (kernel_s * 1e3),
+            "source": "profiles/r02/bench_rmat%d_torchrun1.log (same graph, same kernel path, one rank)" % scale},
         "cpu_baseline": None,
         "verified_vs_oracle": verified,
     }
