@@ -94,7 +94,7 @@ def test_fuzz_plans_against_plain_calls(pkg):
     from gespmm_amd import _lib, spmm
 
     rng = np.random.RandomState(5)
-    for case in range(40):
+    for case in range(60):
         M = int(rng.randint(1, 3000))
         K = int(rng.randint(1, 3000))
         deg = rng.geometric(0.2, size=M) - 1
@@ -108,8 +108,12 @@ def test_fuzz_plans_against_plain_calls(pkg):
         val = torch.rand(colind.size, device="cuda") - 0.5
         B = torch.rand(K, N, device="cuda") - 0.5
         # hub rows: the plan would switch the long-row pass on (a re-association); pin both sides to the strict chain
+        # (also through the 64-bit-offset, non-temporal-store, 4-deep-unroll and no-XCD-remap instantiations of the planned kernels)
+        extra = int(rng.choice([0, _lib.FLAG_FORCE_IDX64, _lib.FLAG_NT_STORE, _lib.FLAG_SHALLOW_UNROLL, _lib.FLAG_NO_XCD_REMAP,
+                                _lib.FLAG_FORCE_IDX64 | _lib.FLAG_SHALLOW_UNROLL]))
         plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=int(rng.choice([0, 16, 64])),
-                             flags=_lib.FLAG_STRICT_ORDER, kernel=str(rng.choice(["auto", "stream", "lds-rows", "seg-stream", "task-outer"])))
+                             flags=_lib.FLAG_STRICT_ORDER | extra,
+                             kernel=str(rng.choice(["auto", "stream", "lds-rows", "seg-stream", "task-outer"])))
         got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
         ref = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_STRICT_ORDER})
         assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (case, M, K, N)
