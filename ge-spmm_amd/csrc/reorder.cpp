@@ -33,6 +33,10 @@
 #include <cstring>
 #include <numeric>
 #include <thread>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 #include <vector>
 
 namespace gespmm {
@@ -62,23 +66,50 @@ struct Level {
     std::vector<int32_t> twin;     // levels >= 1: per column node, the row node that carried the same label (-1: none)
 };
 
+// Worker t of a parallel region runs on the t-th CPU of the calling thread's 8-CPU neighbourhood (one L3 / memory-local
+// group on the hosts this runs on), when the process is allowed there: on a 256-CPU box unpinned workers land on other
+// sockets' cores, read the graph through the interconnect and are SLOWER than one thread (193 ms on one thread, 257 on two,
+// 182 on 32; pinned: profiles/r02/cluster_time.log). A hint only: failures are ignored, results never depend on it.
+inline void pin_near(int base_cpu, int t) {
+#if defined(__linux__)
+    if (base_cpu < 0) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET((base_cpu & ~7) + (t & 7), &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+#else
+    (void)base_cpu;
+    (void)t;
+#endif
+}
+
 template <typename F>
 void parallel_for(int64_t n, int threads, F&& body) {
     if (threads <= 1 || n < 4096) {
         body(0, n, 0);
         return;
     }
+#if defined(__linux__)
+    const int base_cpu = sched_getcpu();
+#else
+    const int base_cpu = -1;
+#endif
     std::vector<std::thread> pool;
     const int64_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
+    for (int t = 1; t < threads; ++t) {
         const int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
         if (lo >= hi) break;
-        pool.emplace_back([&, lo, hi, t]() { body(lo, hi, t); });
+        pool.emplace_back([&, lo, hi, t]() {
+            pin_near(base_cpu, t);
+            body(lo, hi, t);
+        });
     }
+    body(0, std::min(n, chunk), 0);  // the caller is worker 0 (and stays where it is)
     for (auto& th : pool) th.join();
 }
 
-// Transpose an adjacency (n_from nodes -> n_to nodes) by counting sort.
+// Transpose an adjacency (n_from nodes -> n_to nodes) by counting sort. (Serial on purpose: a version in which every worker
+// owned a range of destination nodes and scanned all entries measured level with this one — profiles/r02/cluster_time.log.)
 void transpose(const Adj& a, int32_t n_from, int32_t n_to, Adj& out) {
     out.ptr.assign((size_t)n_to + 1, 0);
     const int64_t ne = a.ptr[n_from];
@@ -140,21 +171,41 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
     if (nnz < 0 || (nnz > 0 && !colind)) return -1;
     int threads = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
-    if (threads > 32) threads = 32;
+    if (threads > 8) threads = 8;  // one L3 neighbourhood (parallel_for pins there); more only adds remote traffic
 
     // ---- level 0: the matrix (entries outside [0, K) are ignored; duplicates simply weigh twice)
     Level lv;
     lv.R = (int32_t)M;
     lv.C = (int32_t)K;
     lv.rows.ptr.resize((size_t)M + 1);
-    lv.rows.idx.reserve((size_t)nnz);
-    lv.rows.ptr[0] = 0;
-    for (int64_t r = 0; r < M; ++r) {
-        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
-            const int32_t c = colind[p];
-            if (c >= 0 && c < K) lv.rows.idx.push_back(c);
+    {
+        std::vector<char> bad_t((size_t)threads, 0);
+        parallel_for(nnz, threads, [&](int64_t lo, int64_t hi, int t) {
+            char bad = 0;
+            for (int64_t p = lo; p < hi; ++p) bad |= (char)((uint32_t)colind[p] >= (uint64_t)K);
+            bad_t[t] = bad;
+        });
+        bool bad = rowptr[0] != 0;
+        for (char b : bad_t) bad = bad || b;
+        if (!bad) {  // the usual case: a straight copy
+            lv.rows.idx.resize((size_t)nnz);
+            parallel_for(M + 1, threads, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t r = lo; r < hi; ++r) lv.rows.ptr[r] = rowptr[r];
+            });
+            parallel_for(nnz, threads, [&](int64_t lo, int64_t hi, int) {
+                std::memcpy(lv.rows.idx.data() + lo, colind + lo, (size_t)(hi - lo) * sizeof(int32_t));
+            });
+        } else {
+            lv.rows.idx.reserve((size_t)nnz);
+            lv.rows.ptr[0] = 0;
+            for (int64_t r = 0; r < M; ++r) {
+                for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+                    const int32_t c = colind[p];
+                    if (c >= 0 && c < K) lv.rows.idx.push_back(c);
+                }
+                lv.rows.ptr[r + 1] = (int64_t)lv.rows.idx.size();
+            }
         }
-        lv.rows.ptr[r + 1] = (int64_t)lv.rows.idx.size();
     }
     transpose(lv.rows, lv.R, lv.C, lv.cols);
     lv.rweight.assign((size_t)M, 1);
@@ -255,27 +306,47 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
             if (cid[L] >= 0) nx.twin[cid[L]] = rid[L];
         nx.rows.ptr.assign((size_t)R2 + 1, 0);
         {
-            std::vector<int64_t> a2((size_t)C2, 0);
-            std::vector<int32_t> t2;
-            for (int32_t n = 0; n < R2; ++n) {
-                t2.clear();
-                for (int64_t m = mptr[n]; m < mptr[n + 1]; ++m) {
-                    const int32_t r = members[m];
-                    for (int64_t e = lv.rows.ptr[r]; e < lv.rows.ptr[r + 1]; ++e) {
-                        const int32_t cl = clab[lv.rows.idx[e]];
-                        if (cl < 0) continue;
-                        const int32_t cn = cid[cl];
-                        if (nx.twin[cn] == n) continue;  // a cluster's edges to its own columns
-                        if (a2[cn] == 0) t2.push_back(cn);
-                        a2[cn] += lv.rows.w.empty() ? 1 : lv.rows.w[e];
+            // every worker merges the rows of a contiguous range of new nodes into its own buffers (dense accumulator over
+            // the new column nodes + list of touched ones, entries in first-touch order); the buffers are then laid end to
+            // end in node order — the same adjacency whatever the number of workers
+            std::vector<std::vector<int32_t>> idx_t((size_t)threads), w_t((size_t)threads);
+            std::vector<int64_t> lo_t((size_t)threads, 0), hi_t((size_t)threads, 0);
+            parallel_for(R2, threads, [&](int64_t lo, int64_t hi, int t) {
+                lo_t[t] = lo;
+                hi_t[t] = hi;
+                std::vector<int64_t> a2((size_t)C2, 0);
+                std::vector<int32_t> t2;
+                auto& oi = idx_t[t];
+                auto& ow = w_t[t];
+                for (int64_t n = lo; n < hi; ++n) {
+                    t2.clear();
+                    for (int64_t m = mptr[n]; m < mptr[n + 1]; ++m) {
+                        const int32_t r = members[m];
+                        for (int64_t e = lv.rows.ptr[r]; e < lv.rows.ptr[r + 1]; ++e) {
+                            const int32_t cl = clab[lv.rows.idx[e]];
+                            if (cl < 0) continue;
+                            const int32_t cn = cid[cl];
+                            if (nx.twin[cn] == (int32_t)n) continue;  // a cluster's edges to its own columns
+                            if (a2[cn] == 0) t2.push_back(cn);
+                            a2[cn] += lv.rows.w.empty() ? 1 : lv.rows.w[e];
+                        }
                     }
+                    for (int32_t cn : t2) {
+                        oi.push_back(cn);
+                        ow.push_back((int32_t)std::min<int64_t>(a2[cn], 0x7fffffff));
+                        a2[cn] = 0;
+                    }
+                    nx.rows.ptr[(size_t)n + 1] = (int64_t)t2.size();  // degree for now, prefix-summed below
                 }
-                for (int32_t cn : t2) {
-                    nx.rows.idx.push_back(cn);
-                    nx.rows.w.push_back((int32_t)std::min<int64_t>(a2[cn], 0x7fffffff));
-                    a2[cn] = 0;
-                }
-                nx.rows.ptr[(size_t)n + 1] = (int64_t)nx.rows.idx.size();
+            });
+            for (int32_t n = 0; n < R2; ++n) nx.rows.ptr[(size_t)n + 1] += nx.rows.ptr[n];
+            nx.rows.idx.resize((size_t)nx.rows.ptr[R2]);
+            nx.rows.w.resize((size_t)nx.rows.ptr[R2]);
+            for (int t = 0; t < threads; ++t) {
+                if (idx_t[t].empty()) continue;
+                const int64_t at = nx.rows.ptr[lo_t[t]];
+                std::memcpy(nx.rows.idx.data() + at, idx_t[t].data(), idx_t[t].size() * sizeof(int32_t));
+                std::memcpy(nx.rows.w.data() + at, w_t[t].data(), w_t[t].size() * sizeof(int32_t));
             }
         }
         transpose(nx.rows, nx.R, nx.C, nx.cols);
