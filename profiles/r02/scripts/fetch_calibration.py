@@ -18,6 +18,7 @@ ap.add_argument("--degs", default="", help="comma list: row i has degs[i % len] 
 ap.add_argument("--graph", default="", help="a bench graph (gespmm_amd.graphs) instead of the synthetic pattern")
 ap.add_argument("--k", type=int, default=0, help="with --degs: columns drawn from 0..k-1 (B has k rows; small k = all gathers hit L2)")
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--rpw", type=int, default=0, help="rows per wavefront / lane group (launch cfg)")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--m", type=int, default=334863)
 ap.add_argument("--n", type=int, default=128)
@@ -66,12 +67,12 @@ if gathers is None:
     C = torch.empty((M, N), device=dev)
     gathers = M * d
 for _ in range(5):
-    spmm.csr_spmm(rp, ci, val, B, out=C, cfg=({"flags": args.flags} if args.flags else None))
+    spmm.csr_spmm(rp, ci, val, B, out=C, cfg=({"flags": args.flags, "rows_per_wave": args.rpw} if (args.flags or args.rpw) else None))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 e0.record()
 for _ in range(args.iters):
-    spmm.csr_spmm(rp, ci, val, B, out=C, cfg=({"flags": args.flags} if args.flags else None))
+    spmm.csr_spmm(rp, ci, val, B, out=C, cfg=({"flags": args.flags, "rows_per_wave": args.rpw} if (args.flags or args.rpw) else None))
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / args.iters * 1e3
