@@ -394,37 +394,60 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
             wave_lds_sync();
         }
         const int cnt = ge - k;
-        const int t = k - tbase;
+        const int t = k - tbase;  // a multiple of U: tiles hold whole steps
         off_t off[U];
         float v[U];
         float bv[U][S][V];
-        // Straight-line issue of all U gathers: slots past the end of the stream re-read the
-        // last valid entry (same cache line, no extra memory traffic) instead of being
-        // branched around — control flow around the loads makes the compiler serialise
-        // them with s_waitcnt vmcnt(0). Predicates apply only when the values are consumed.
+        if (cnt >= U) {
+            // Full step: the U tile slots are read with constant offsets (no per-slot clamping: ~4 instead of ~9 VALU
+            // instructions per gather, which is what the kernel is short of when the B rows come from L2) ...
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int tj = t + ((j < cnt) ? j : cnt - 1);
-            off[j] = s_off[wave][g][tj];
-            if constexpr (VALUED) v[j] = s_val[wave][g][tj];
-            else v[j] = 1.0f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
-        }
-        if (cnt >= U && k + U <= rend) {
-            // every entry of the step belongs to the current row (rend = its CSR end and the
-            // previous entry already did): long rows run without boundary checks
+            for (int j = 0; j < U; ++j) {
+                off[j] = s_off[wave][g][t + j];
+                if constexpr (VALUED) v[j] = s_val[wave][g][t + j];
+                else v[j] = 1.0f;
+            }
 #pragma unroll
             for (int j = 0; j < U; ++j)
 #pragma unroll
-                for (int s = 0; s < S; ++s)
+                for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+            if (k + U <= rend) {
+                // ... and every entry belongs to the current row (rend = its CSR end and the previous entry already
+                // did): long rows run without boundary checks
 #pragma unroll
-                    for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+                for (int j = 0; j < U; ++j)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    while (k + j >= rend) flush_row();  // rows ending before this entry (incl. empty ones)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[s][i] = combine<RED, VALUED>(acc[s][i], v[j], bv[j][s][i]);
+                }
+            }
         } else {
+            // Last step of the stream: straight-line issue of all U gathers, slots past the end re-read the last valid
+            // entry (same cache line, no extra memory traffic) instead of being branched around — control flow around
+            // the individual loads makes the compiler serialise them with s_waitcnt vmcnt(0). Predicates apply only when
+            // the values are consumed.
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int tj = t + ((j < cnt) ? j : cnt - 1);
+                off[j] = s_off[wave][g][tj];
+                if constexpr (VALUED) v[j] = s_val[wave][g][tj];
+                else v[j] = 1.0f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) load_vec<V>(bv[j][s], Bbase + (off_t)(off[j] + cbytes[s]));
+            }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 if (j < cnt) {
-                    while (k + j >= rend) flush_row();  // rows ending before this entry (incl. empty ones)
+                    while (k + j >= rend) flush_row();
 #pragma unroll
                     for (int s = 0; s < S; ++s)
 #pragma unroll
