@@ -554,14 +554,13 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
             off_t off[U];
             float v[U];
             float bv[U][S][V];
+            if (cnt >= U) {  // full step: tile slots at constant offsets, U gathers back to back
 #pragma unroll
-            for (int j = 0; j < U; ++j) {  // LDS reads are unconditional (clamped slot)
-                const int tj = t + ((j < cnt) ? j : cnt - 1);
-                off[j] = s_off[wave][g][tj];
-                if constexpr (VALUED) v[j] = s_val[wave][g][tj];
-                else v[j] = 1.0f;
-            }
-            if (cnt >= U) {  // full step: U gathers back to back
+                for (int j = 0; j < U; ++j) {
+                    off[j] = s_off[wave][g][t + j];
+                    if constexpr (VALUED) v[j] = s_val[wave][g][t + j];
+                    else v[j] = 1.0f;
+                }
 #pragma unroll
                 for (int j = 0; j < U; ++j)
 #pragma unroll
@@ -573,7 +572,14 @@ __global__ __launch_bounds__(kThreads) void spmm_slab_kernel(SpmmArgs a) {
 #pragma unroll
                         for (int k2 = 0; k2 < V; ++k2)
                             acc[s][k2] = combine<RED, VALUED>(acc[s][k2], v[j], bv[j][s][k2]);
-            } else {  // last step of the segment: only the cnt live gathers are issued
+            } else {  // last step of the segment: only the cnt live gathers are issued (LDS reads unconditional, clamped slot)
+#pragma unroll
+                for (int j = 0; j < U - 1; ++j) {
+                    const int tj = t + ((j < cnt) ? j : cnt - 1);
+                    off[j] = s_off[wave][g][tj];
+                    if constexpr (VALUED) v[j] = s_val[wave][g][tj];
+                    else v[j] = 1.0f;
+                }
 #pragma unroll
                 for (int j = 0; j < U - 1; ++j) {
                     if (j < cnt) {
