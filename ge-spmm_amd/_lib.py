@@ -22,6 +22,7 @@ NUM_VARIANTS = 6
 
 FLAG_NO_XCD_REMAP = 0x1
 FLAG_NT_STORE = 0x2
+FLAG_SC1_STORE = 0x8000
 FLAG_FORCE_IDX64 = 0x4
 FLAG_BATCH_STREAM = 0x20
 FLAG_SEG_STREAM = 0x80

@@ -53,6 +53,25 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[V]) {
     else *reinterpret_cast<T*>(p) = v;
 }
 
+// Store with system scope (`sc1`): the line is written through instead of staying in the XCD's L2. C is written once and never
+// read by the launch, and in the cache-resident regimes every C line kept in L2 evicts a B row somebody is about to reuse:
+// 512-byte rows gathered from a 2 MB table while 1 GB of rows is written run at 25.5 TB/s with plain stores, 27.1 with `nt`,
+// 31.3 with `sc1` (31.9 without any store; profiles/r02/l2_gather_steps.log).
+template <int V>
+__device__ __forceinline__ void store_vec_sc1(float* p, const float (&src)[V]) {
+    using T = typename VecT<V>::type;
+    T v;
+    if constexpr (V == 1) {
+        v = src[0];
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = src[i];
+        if constexpr (V == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
 // Workgroup id -> work item id such that XCD x (which receives ids == x mod 8)
 // gets a contiguous slice of the item range. Bijective for every n.
 __device__ __forceinline__ int xcd_contiguous(int bid, int n) {

@@ -231,10 +231,12 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
                 if constexpr (PLANNED) crow = s_perm[wave][r];
                 float* Crow = a.C + (size_t)crow * (size_t)a.N + col0;
                 const bool nts = (a.flags & kFlagNtStore) != 0;
+                const bool sc1 = (a.flags & kFlagSc1Store) != 0;
     #pragma unroll
                 for (int s = 0; s < S; ++s)
                     if (colok[s]) {
-                        if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                        if (sc1) store_vec_sc1<V>(Crow + s * (W * V), acc[s]);
+                        else if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
                         else store_vec<V, false>(Crow + s * (W * V), acc[s]);
                     }
             }
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
     const off_t rowbytes = (off_t)a.N * 4u;
     const float init = (RED == kReduceMax) ? a.empty : 0.0f;
     const bool nts = (a.flags & kFlagNtStore) != 0;
+    const bool sc1 = (a.flags & kFlagSc1Store) != 0;
 
     // Per-group tile stream.
     int pc[E];
@@ -376,7 +379,8 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if (colok[s]) {
-                if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
+                if (sc1) store_vec_sc1<V>(Crow + s * (W * V), acc[s]);
+                else if (nts) store_vec<V, true>(Crow + s * (W * V), acc[s]);
                 else store_vec<V, false>(Crow + s * (W * V), acc[s]);
             }
 #pragma unroll

@@ -109,7 +109,7 @@ def test_fuzz_plans_against_plain_calls(pkg):
         B = torch.rand(K, N, device="cuda") - 0.5
         # hub rows: the plan would switch the long-row pass on (a re-association); pin both sides to the strict chain
         # (also through the 64-bit-offset, non-temporal-store, 4-deep-unroll and no-XCD-remap instantiations of the planned kernels)
-        extra = int(rng.choice([0, _lib.FLAG_FORCE_IDX64, _lib.FLAG_NT_STORE, _lib.FLAG_SHALLOW_UNROLL, _lib.FLAG_NO_XCD_REMAP,
+        extra = int(rng.choice([0, _lib.FLAG_FORCE_IDX64, _lib.FLAG_NT_STORE, _lib.FLAG_SC1_STORE, _lib.FLAG_SHALLOW_UNROLL, _lib.FLAG_NO_XCD_REMAP,
                                 _lib.FLAG_FORCE_IDX64 | _lib.FLAG_SHALLOW_UNROLL]))
         plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=int(rng.choice([0, 16, 64])),
                              flags=_lib.FLAG_STRICT_ORDER | extra,

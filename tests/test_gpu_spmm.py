@@ -111,7 +111,7 @@ def test_explicit_geometries_and_flags(pkg, oracle, bundled):
         B = oracle.hash_B(G["K"], N, seed=N)
         ref_v = oracle.spmm(G["rowptr"], G["colind"], val, B, "fma")
         ref_u = oracle.spmm(G["rowptr"], G["colind"], None, B, "golden")
-        all_flags = (0, _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_NT_STORE, _lib.FLAG_FORCE_IDX64, _lib.FLAG_SEG_STREAM,
+        all_flags = (0, _lib.FLAG_NO_XCD_REMAP, _lib.FLAG_NT_STORE, _lib.FLAG_SC1_STORE, _lib.FLAG_FORCE_IDX64, _lib.FLAG_SEG_STREAM,
                      _lib.FLAG_SHALLOW_UNROLL, _lib.FLAG_BATCH_STREAM,
                      _lib.FLAG_BATCH_STREAM | _lib.FLAG_SHALLOW_UNROLL | _lib.FLAG_FORCE_IDX64,
                      _lib.FLAG_NT_STORE | _lib.FLAG_FORCE_IDX64 | _lib.FLAG_NO_XCD_REMAP | _lib.FLAG_SHALLOW_UNROLL)
