@@ -86,6 +86,70 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ buf, const u
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc;
 }
 
+// Short-lived wavefronts, as the library launches them: every wavefront does only `steps` steps (two 64-entry rows = 16 steps),
+// behind a dependent prologue (a "row pointer" load whose value is needed to address the first tile), and stores its rows.
+template <int STORE>
+__global__ __launch_bounds__(256) void kshort(const float4* __restrict__ buf, const unsigned* __restrict__ offs, const float* __restrict__ vals,
+                                              const int* __restrict__ ptrs, int steps, float4* __restrict__ out) {
+    constexpr int U = 8;
+    __shared__ unsigned s_off[4][2][32];
+    __shared__ float s_val[4][2][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, l = lane & 31;
+    const int gw = blockIdx.x * 4 + wave;
+    const char* base = reinterpret_cast<const char*>(buf);
+    size_t meta = (size_t)ptrs[gw & 0xffff] + ((size_t)gw * 64) % (1 << 20);  // dependent: pointer first, then the tile
+    meta %= (1 << 20);
+    unsigned po = __builtin_nontemporal_load(offs + meta + lane);
+    float pv = __builtin_nontemporal_load(vals + meta + lane);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int it = 0; it < steps; ++it) {
+        float4 v[U];
+        float w[U];
+        const int t = (it & 3) * U;
+        if ((it & 3) == 0) {
+            s_off[wave][g][l] = po; s_val[wave][g][l] = pv;
+            meta = (meta + 64) % (1 << 20);
+            po = __builtin_nontemporal_load(offs + meta + lane);
+            pv = __builtin_nontemporal_load(vals + meta + lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            w[j] = s_val[wave][g][t + j];
+            v[j] = *reinterpret_cast<const float4*>(base + s_off[wave][g][t + j] + l * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            acc.x = __builtin_fmaf(w[j], v[j].x, acc.x); acc.y = __builtin_fmaf(w[j], v[j].y, acc.y);
+            acc.z = __builtin_fmaf(w[j], v[j].z, acc.z); acc.w = __builtin_fmaf(w[j], v[j].w, acc.w);
+        }
+        if ((it & 7) == 7) {
+            float4* dst = out + ((size_t)(gw * 2 + g) * (steps / 8) + it / 8) % (1 << 21) * 32 + l;
+            f4 val = {acc.x, acc.y, acc.z, acc.w};
+            if (STORE == 0) *dst = acc;
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+            acc = make_float4(0, 0, 0, 0);
+        }
+    }
+}
+
+template <int STORE>
+static void run_short(const float4* buf, const unsigned* offs, const float* vals, const int* ptrs, float4* out, int steps, const char* name) {
+    const long total_steps = 2048L * 8 * 2048;  // same gather volume as run<>
+    const int wgs = (int)(total_steps / (4L * steps));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kshort<STORE>, dim3(wgs), dim3(256), 0, 0, buf, offs, vals, ptrs, steps, out);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double bytes = (double)wgs * 4 * steps * 8 * 1024.0;
+    printf("short  %-64s %7.3f ms  %6.2f TB/s  (%d workgroups x %d steps)\n", name, ms, bytes / ms / 1e9, wgs, steps);
+}
+
 template <int MODE, int OUTROWS_LOG2 = 21, int STORE = 0>
 static void run(const float4* buf, const unsigned* offs, const float* vals, int rows, float4* out, const char* name) {
     const int wgs = 256 * 8, steps = 2048;
@@ -122,5 +186,8 @@ int main() {
     run<4, 21, 2>(buf, offs, vals, rows, out, "  MODE 4 (1 GB of output), sc1 store");
     run<4, 21, 3>(buf, offs, vals, rows, out, "  MODE 4 (1 GB of output), sc0 sc1 store");
     run<4, 21, 4>(buf, offs, vals, rows, out, "  MODE 4 (1 GB of output), sc0 sc1 nt store");
+    int* ptrs; hipMalloc(&ptrs, 65536 * 4); hipMemset(ptrs, 0, 65536 * 4);
+    for (int steps : {16, 32, 64, 256, 2048}) run_short<1>(buf, offs, vals, ptrs, out, steps, "short-lived wavefronts, sc1 stores");
+    run_short<0>(buf, offs, vals, ptrs, out, 16, "short-lived wavefronts, plain stores");
     return 0;
 }
