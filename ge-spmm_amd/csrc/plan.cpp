@@ -389,12 +389,12 @@ hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
 }
 
 // Non-zeros per wavefront task. Storage-order launches take ~12 KB of gathered B per task (select.cpp);
-// clustered plans take ~24 KB (48 entries at N = 128, 32 at N >= 256, 96 at N <= 64: profiles/r02/plan_task_size_final.log — at
-// N = 128 anything from 40 to 80 entries runs within 1 %, and the smaller task keeps fewer rows in flight per XCD, i.e. less
-// fabric traffic for the same time), see the caller for the L2-hit case.
+// clustered plans take ~20 KB (40 entries at N = 128, 32 at N >= 256, 80 at N = 64: profiles/r02/plan_task_size_final.log — at
+// N = 128 anything from 40 to 80 entries runs within 1 %, and the smaller task keeps fewer rows in flight per XCD: fabric bytes
+// 1.48x algorithmic at 40 entries, 1.54x at 48, 1.62x at 56, plan_task_size_traffic.log), see the caller for the L2-hit case.
 int default_task_entries(int64_t N) {
     const int64_t row_bytes = 4 * (N < 256 ? N : 256);
-    int64_t t = (24 << 10) / (row_bytes > 0 ? row_bytes : 4);
+    int64_t t = (20 << 10) / (row_bytes > 0 ? row_bytes : 4);
     if (t < 32) t = 32;
     if (t > 96) t = 96;  // narrow rows (N = 32: 128-byte rows) are latency-bound per row pair: the plain path's 96 entries
     return (int)t;

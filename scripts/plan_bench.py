@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--only-plan", action="store_true", help="one clustered plan per graph at the default task size (for rocprofv3)")
+    ap.add_argument("--task-entries", type=int, default=0, help="with --only-plan: task size (0 = default)")
     args = ap.parse_args()
     import torch
 
@@ -50,7 +51,7 @@ def main():
             C = torch.empty((M, N), device=dev)
             abytes = 4 * (M + 1) + 8 * nnz + 4 * K * N + 4 * M * N
             if args.only_plan:
-                plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=args.kernel)
+                plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=args.kernel, task_entries=args.task_entries)
                 us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
                 print("%s N=%d clustered plan %.1f us  frac %.3f | %s" % (name, N, us, abytes / us / 8e6, plan.describe()), flush=True)
                 continue
