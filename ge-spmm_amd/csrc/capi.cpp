@@ -105,7 +105,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.N = (int32_t)N;
     a.nblk = 0;
     a.ntile = 0;
-    a.flags = flags;
+    a.flags = flags | (sel.geo.sc1_store ? gespmm::kFlagSc1Store : 0);
     a.empty = empty;
     a.long_row = 0;
     a.lr_hdr = nullptr;
@@ -260,12 +260,13 @@ int gespmm_describe_launch(int64_t M, int64_t K, int64_t N, int64_t nnz, int var
         if ((flags & gespmm::kFlagSegStream) && !g.split_long_rows) seg = true;
         char tail[64] = "";
         if (!seg && g.split_long_rows) snprintf(tail, sizeof tail, " long_rows>%d chunk=%d", g.long_row_threshold, gespmm::kLongRowChunk);
+        const char* st = (g.sc1_store || (flags & gespmm::kFlagSc1Store)) ? " c_stores=sc1" : "";
         if (seg)
-            n = snprintf(out, (size_t)capacity, "variant=%d kernel=segmented-stream V=%d S=%d W=%d rows_per_group=%d %s",
-                         sel.variant, g.vec, g.strips, g.group, g.rows_per_group, idx);
+            n = snprintf(out, (size_t)capacity, "variant=%d kernel=segmented-stream V=%d S=%d W=%d rows_per_group=%d %s%s",
+                         sel.variant, g.vec, g.strips, g.group, g.rows_per_group, idx, st);
         else
-            n = snprintf(out, (size_t)capacity, "variant=%d kernel=batch-stream V=%d S=%d W=%d rows_per_wave=%d %s%s",
-                         sel.variant, g.vec, g.strips, g.group, g.rows_per_wave, idx, tail);
+            n = snprintf(out, (size_t)capacity, "variant=%d kernel=batch-stream V=%d S=%d W=%d rows_per_wave=%d %s%s%s",
+                         sel.variant, g.vec, g.strips, g.group, g.rows_per_wave, idx, tail, st);
     }
     if (n < 0) return GESPMM_EINVAL;
     return n < capacity ? n : (int)capacity - 1;

@@ -82,6 +82,7 @@ struct Geometry {
     bool split_long_rows;  // run the long-row pass
     int long_row_threshold;  // rows with more entries than this go to the long-row pass
     int reduce;   // kReduceSum / kReduceMax
+    bool sc1_store;  // C stored with system scope (B is L2-resident and C is not: keep C lines out of the L2)
 };
 
 hipError_t launch_spmm_naive(const SpmmArgs& a, const Geometry& geo, hipStream_t st);

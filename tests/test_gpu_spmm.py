@@ -547,3 +547,22 @@ def test_very_short_rows_take_the_segmented_kernel_and_keep_the_bits(pkg, oracle
         B = oracle.hash_B(K, N, seed=2)
         assert_bits_equal(run(pkg, G, B, val), oracle.spmm(rowptr, colind, val, B, "fma"), "short rows N=%d valued" % N)
         assert_bits_equal(run(pkg, G, B, None), oracle.spmm(rowptr, colind, None, B, "golden"), "short rows N=%d" % N)
+
+
+def test_l2_resident_b_with_large_c_keeps_the_bits(pkg, oracle):
+    """Many rows over a small B (K = 2048: sampled-neighbour / bipartite shapes): AUTO writes C with system-scope stores
+    (select.cpp sc1_store); a store flavour never changes a bit."""
+    rng = np.random.default_rng(3)
+    M, K = 40000, 2048
+    deg = rng.integers(0, 12, size=M)
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, K, size=nnz).astype(np.int32)
+    G = {"rowptr": rowptr, "colind": colind, "M": M, "K": K, "nnz": nnz}
+    val = oracle.hash_val(nnz, seed=5)
+    for N in (64, 128):
+        B = oracle.hash_B(K, N, seed=N)
+        ref = oracle.spmm(rowptr, colind, val, B, "fma")
+        assert_bits_equal(run(pkg, G, B, val), ref, "small B, N=%d" % N)
+        assert_bits_equal(run(pkg, G, B, val, cfg={"flags": 0x20}), ref, "small B, batch kernel, N=%d" % N)
