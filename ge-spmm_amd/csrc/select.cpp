@@ -207,10 +207,11 @@ int resolve_geometry(int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, 
     g.segmented = ((flags & kFlagSegStream) != 0 || (b_resident && g.group >= 32 && avg_deg <= 12) ||
                    (g.group >= 32 && avg_deg <= 3 && M >= (1 << 16))) &&
                   !g.split_long_rows && !(g.strips == 2 && g.vec < 4);
-    // B small enough to live in the L2s while C streams through them: C lines written with plain stores evict B rows (the BENCH
-    // graph's rows over a 1 MB B: 81 -> 65 us with system-scope stores, 4 MB: 86 -> 82; profiles/r02/l2_resident_store_scope.log).
-    // Neutral everywhere else (exp_sc1_stores.py), so only this corner takes it.
-    g.sc1_store = b_resident && (uint64_t)M * (uint64_t)N * 4ull > (8ull << 20);
+    // System-scope C stores (GESPMM_FLAG_SC1_STORE) stay opt-in: with B L2-resident and C not, they help when the reuse of B is
+    // skewed (the BENCH graph's rows folded onto a 1 MB B: 81 -> 65 us; 4 MB: 86 -> 82) and cost when it is uniform and store-heavy
+    // (uniform degree 6 over the same B: 54.5 -> 61.9 us; 73.7 -> 75.6) — profiles/r02/l2_resident_store_scope.log. The host
+    // cannot tell the two apart without reading the matrix.
+    g.sc1_store = false;
     out->variant = variant;
     out->geo = g;
     return 0;

@@ -212,8 +212,8 @@ def test_describe_launch_pins_the_selection_rules(pkg):
     assert describe(1 << 26, 1 << 26, 256, 1 << 30).startswith("variant=3 kernel=batch-stream V=4 S=1 W=64")
     assert "idx64" in describe(1 << 26, 1 << 26, 256, 1 << 30)
     assert "kernel=segmented-stream" in describe(2048, 2048, 128, 10000)      # short rows, B resident in L2
-    assert describe(300000, 2048, 128, 1500000).endswith("c_stores=sc1")       # B in L2, C not: C written through
-    assert "c_stores" not in describe(2048, 2048, 128, 10000) and "c_stores" not in describe(amazon[0], amazon[1], 128, amazon[3])
+    assert "c_stores" not in describe(300000, 2048, 128, 1500000)              # system-scope C stores are opt-in ...
+    assert describe(300000, 2048, 128, 1500000, flags=0x8000).endswith("c_stores=sc1")  # ... GESPMM_FLAG_SC1_STORE
     assert "kernel=segmented-stream" in describe(1 << 20, 1 << 20, 128, 3 << 20)   # road-network-like: mean degree 3
     assert "kernel=batch-stream" in describe(1 << 20, 1 << 20, 128, 4 << 20)       # mean degree 4: batch kernel
     assert "kernel=batch-stream" in describe(1 << 15, 1 << 20, 128, 3 << 15)       # small matrix: batch kernel

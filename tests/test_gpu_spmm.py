@@ -550,8 +550,8 @@ def test_very_short_rows_take_the_segmented_kernel_and_keep_the_bits(pkg, oracle
 
 
 def test_l2_resident_b_with_large_c_keeps_the_bits(pkg, oracle):
-    """Many rows over a small B (K = 2048: sampled-neighbour / bipartite shapes): AUTO writes C with system-scope stores
-    (select.cpp sc1_store); a store flavour never changes a bit."""
+    """Many rows over a small B (K = 2048: sampled-neighbour / bipartite shapes), with and without system-scope C stores
+    (GESPMM_FLAG_SC1_STORE): a store flavour never changes a bit."""
     rng = np.random.default_rng(3)
     M, K = 40000, 2048
     deg = rng.integers(0, 12, size=M)
@@ -566,3 +566,5 @@ def test_l2_resident_b_with_large_c_keeps_the_bits(pkg, oracle):
         ref = oracle.spmm(rowptr, colind, val, B, "fma")
         assert_bits_equal(run(pkg, G, B, val), ref, "small B, N=%d" % N)
         assert_bits_equal(run(pkg, G, B, val, cfg={"flags": 0x20}), ref, "small B, batch kernel, N=%d" % N)
+        assert_bits_equal(run(pkg, G, B, val, cfg={"flags": 0x8000}), ref, "small B, sc1 stores, N=%d" % N)
+        assert_bits_equal(run(pkg, G, B, val, cfg={"flags": 0x8020}), ref, "small B, batch kernel, sc1 stores, N=%d" % N)
