@@ -148,7 +148,9 @@ typedef struct gespmm_launch_cfg {
 #define GESPMM_FLAG_NO_XCD_REMAP   0x1  /* plain blockIdx -> row-block mapping */
 #define GESPMM_FLAG_NT_STORE       0x2  /* non-temporal stores of C */
 #define GESPMM_FLAG_SC1_STORE      0x8000 /* streaming kernels: C stored with system scope (written through instead of kept in the
-                                            XCD's L2). The cache-blocked path always does; elsewhere measured neutral (±1 %) */
+                                            XCD's L2). Neutral where B exceeds the L2s; with B L2-resident and C not, +20 % when the
+                                            reuse of B is skewed, -13 % when it is uniform (profiles/r02/l2_resident_store_scope.log).
+                                            The cache-blocked path always stores this way */
 #define GESPMM_FLAG_FORCE_IDX64    0x4  /* 64-bit B offsets even when K*N*4 < 2^32 */
 #define GESPMM_FLAG_SHALLOW_UNROLL 0x10 /* gather 4 instead of 8 B rows per step (fewer VGPRs) */
 #define GESPMM_FLAG_BATCH_STREAM   0x20 /* force the batch-stream kernel (rows walked 64/group at a time) */
