@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ buf, const u
 
 // Short-lived wavefronts, as the library launches them: every wavefront does only `steps` steps (two 64-entry rows = 16 steps),
 // behind a dependent prologue (a "row pointer" load whose value is needed to address the first tile), and stores its rows.
-template <int STORE>
+template <int STORE, int PERIOD = 8>
 __global__ __launch_bounds__(256) void kshort(const float4* __restrict__ buf, const unsigned* __restrict__ offs, const float* __restrict__ vals,
                                               const int* __restrict__ ptrs, int steps, float4* __restrict__ out) {
     constexpr int U = 8;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void kshort(const float4* __restrict__ buf, co
             acc.x = __builtin_fmaf(w[j], v[j].x, acc.x); acc.y = __builtin_fmaf(w[j], v[j].y, acc.y);
             acc.z = __builtin_fmaf(w[j], v[j].z, acc.z); acc.w = __builtin_fmaf(w[j], v[j].w, acc.w);
         }
-        if ((it & 7) == 7) {
-            float4* dst = out + ((size_t)(gw * 2 + g) * (steps / 8) + it / 8) % (1 << 21) * 32 + l;
+        if ((it % PERIOD) == PERIOD - 1) {
+            float4* dst = out + ((size_t)(gw * 2 + g) * (steps / PERIOD) + it / PERIOD) % (1 << 21) * 32 + l;
             f4 val = {acc.x, acc.y, acc.z, acc.w};
             if (STORE == 0) *dst = acc;
             else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void kshort(const float4* __restrict__ buf, co
     }
 }
 
-template <int STORE>
+template <int STORE, int PERIOD = 8>
 static void run_short(const float4* buf, const unsigned* offs, const float* vals, const int* ptrs, float4* out, int steps, const char* name) {
     const long total_steps = 2048L * 8 * 2048;  // same gather volume as run<>
     const int wgs = (int)(total_steps / (4L * steps));
@@ -143,7 +143,7 @@ static void run_short(const float4* buf, const unsigned* offs, const float* vals
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kshort<STORE>, dim3(wgs), dim3(256), 0, 0, buf, offs, vals, ptrs, steps, out);
+        hipLaunchKernelGGL((kshort<STORE, PERIOD>), dim3(wgs), dim3(256), 0, 0, buf, offs, vals, ptrs, steps, out);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
     const double bytes = (double)wgs * 4 * steps * 8 * 1024.0;
@@ -189,5 +189,9 @@ int main() {
     int* ptrs; hipMalloc(&ptrs, 65536 * 4); hipMemset(ptrs, 0, 65536 * 4);
     for (int steps : {16, 32, 64, 256, 2048}) run_short<1>(buf, offs, vals, ptrs, out, steps, "short-lived wavefronts, sc1 stores");
     run_short<0>(buf, offs, vals, ptrs, out, 16, "short-lived wavefronts, plain stores");
+    run_short<0, 1>(buf, offs, vals, ptrs, out, 16, "short-lived, a row stored EVERY step (8-entry rows), plain stores");
+    run_short<1, 1>(buf, offs, vals, ptrs, out, 16, "short-lived, a row stored EVERY step (8-entry rows), sc1 stores");
+    run_short<0, 1>(buf, offs, vals, ptrs, out, 2048, "persistent, a row stored EVERY step, plain stores");
+    run_short<1, 1>(buf, offs, vals, ptrs, out, 2048, "persistent, a row stored EVERY step, sc1 stores");
     return 0;
 }
