@@ -85,7 +85,8 @@ inline void pin_near(int base_cpu, int t) {
 
 template <typename F>
 void parallel_for(int64_t n, int threads, F&& body) {
-    if (threads <= 1 || n < 4096) {
+    if (threads > 1 && n < (int64_t)threads * 32768) threads = (int)(n / 32768);  // a worker must be worth its spawn: small graphs run on one thread (pubmed 12 vs 17 ms)
+    if (threads <= 1) {
         body(0, n, 0);
         return;
     }
