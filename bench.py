@@ -324,6 +324,28 @@ def main():
                 extra["%s_sweep_valued" % pname] = sweep
                 del g3, val3, plan3
 
+            # ---- BASELINE configs[4] on ONE GPU at a size that takes seconds: the RMAT graph of the multi-GPU mode (scale 24 =
+            #      2^28 entries, N = 256; `--gpus N` with N > 1 runs scale 26 sharded), so the driver's one-GPU record holds an RMAT line
+            torch.cuda.empty_cache()
+            g5 = graphs.rmat_shard(24, 16, 0, 1, seed=42, device=dev)
+            val5 = torch.rand(g5["nnz"], device=dev) - 0.5
+            B5 = make_B(g5["K"], 256)
+            C5 = torch.empty((g5["M"], 256), dtype=torch.float32, device=dev)
+            plan5 = spmm.SpmmPlan(g5["rowptr"], g5["colind"], g5["K"], 256, variant=args.variant, values=val5, reorder=False)
+
+            def st5():
+                spmm.csr_spmm(g5["rowptr"], g5["colind"], val5, B5, variant=args.variant, out=C5, plan=plan5)
+            for _ in range(2):
+                st5()
+            med5 = statistics.median(kernel_times_us(st5, 5))
+            ab5 = algorithmic_bytes(g5["M"], g5["K"], 256, g5["nnz"], True)
+            extra["rmat-24_N256_valued"] = {
+                "kernel_us": med5, "gflops": 2.0 * g5["nnz"] * 256 / med5 / 1e3, "achieved_GBs": ab5 / med5 / 1e3,
+                "frac": ab5 / med5 / 1e3 / HBM_PEAK_GBS, "nnz": g5["nnz"], "gather_GBs": 4.0 * g5["nnz"] * 256 / med5 / 1e3,
+                "plan": plan5.describe(),
+                "note": "hub rows through the long-row pass (tolerance-checked re-association); B is 17 GB: every gather comes from HBM"}
+            del g5, val5, B5, C5, plan5
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baselines(graphs, torch, g, val, N, graph, quick=args.no_extra)
