@@ -324,6 +324,16 @@ def main():
                 extra["%s_sweep_valued" % pname] = sweep
                 del g3, val3, plan3
 
+            # ---- BASELINE configs[0] and [3]: the small graphs (launch-latency territory), unweighted as the reference's driver and
+            #      its GCN run them; plain call and plan
+            for sname, sN in (("cit-hepth-like", 32), ("pubmed-like", 128)):
+                gsm = graphs.synthetic_graph(sname, seed=42, device=dev)
+                vsm = torch.rand(gsm["nnz"], device=dev) - 0.5
+                rs = measure_graph(gsm, vsm, sN, False, use_plan=True, samples=MIN_KERNEL_SAMPLES)
+                rs["plain_call_kernel_us"] = measure_graph(gsm, vsm, sN, False, use_plan=False, samples=MIN_KERNEL_SAMPLES)["kernel_us"]
+                extra["%s_N%d_unweighted" % (sname, sN)] = rs
+                del gsm, vsm
+
             # ---- BASELINE configs[4] on ONE GPU at a size that takes seconds: the RMAT graph of the multi-GPU mode (scale 24 =
             #      2^28 entries, N = 256; `--gpus N` with N > 1 runs scale 26 sharded), so the driver's one-GPU record holds an RMAT line
             torch.cuda.empty_cache()
