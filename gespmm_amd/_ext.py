@@ -2,7 +2,7 @@
 recipe and loader.
 
 `build()` compiles it in-tree with plain g++ against the torch headers (the file has no
-device code; it only calls the C ABI of libgespmm.so) into ge-spmm_amd/lib/, next to
+device code; it only calls the C ABI of libgespmm.so) into gespmm_amd/lib/, next to
 libgespmm.so. `ext` is the imported module, or None when it has not been built — the
 callers then use the ctypes binding of the same C ABI (`_lib.py`), never a CPU path.
 """

@@ -107,7 +107,7 @@ def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "gespmm_amd: %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C ge-spmm_amd/csrc`). There is no CPU fallback." % LIB_PATH
+            "(or `make -C gespmm_amd/csrc`). There is no CPU fallback." % LIB_PATH
         )
     lib = ctypes.CDLL(LIB_PATH)
     p = c_void_p

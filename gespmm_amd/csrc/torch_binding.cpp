@@ -7,7 +7,7 @@
 // result with torch::empty on the input's device (spmm_kernel.cu:183,434) and calls the C
 // ABI of include/gespmm.h on the CURRENT torch HIP stream (the reference launches on the
 // legacy default stream). Built with plain g++ against the torch headers (no device code
-// in this file); ge-spmm_amd/spmm.py uses it when present and falls back to the ctypes
+// in this file); gespmm_amd/spmm.py uses it when present and falls back to the ctypes
 // binding of the same C ABI otherwise.
 
 #include <torch/extension.h>
@@ -61,7 +61,7 @@ torch::Tensor spmm_impl(const torch::Tensor& rowptr, const torch::Tensor& colind
     auto out = torch::empty({M, N}, dense.options());
     // Scratch for the two paths that need it (dense-graph cache blocking, long-row pass) comes from
     // torch's caching allocator: no driver allocation per call, and legal under torch.cuda.graph.
-    // A caller-kept workspace (ge-spmm_amd/spmm.py: SpmmPlan) is used as is.
+    // A caller-kept workspace (gespmm_amd/spmm.py: SpmmPlan) is used as is.
     gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, (int32_t)flags};
     const int64_t ws_bytes = gespmm_csr_spmm_workspace_bytes(M, K, N, nnz, (int)variant, &cfg);
     TORCH_CHECK(ws_bytes >= 0, "gespmm_csr_spmm_workspace_bytes failed: ", gespmm_error_string((int)ws_bytes));

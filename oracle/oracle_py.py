@@ -1,7 +1,7 @@
 """ctypes access to oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
 
 May be imported by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke();
-never by the product package (ge-spmm_amd/). See the header of gespmm_oracle.c.
+never by the product package (gespmm_amd/). See the header of gespmm_oracle.c.
 """
 import ctypes
 import os

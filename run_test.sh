@@ -8,7 +8,7 @@
 # is not run. Build first:  python -c "import __graft_entry__ as g; g.build()"
 device=${1:-0}
 here="$(cd "$(dirname "$0")" && pwd)"
-drv="$here/ge-spmm_amd/lib/spmm_test"
+drv="$here/gespmm_amd/lib/spmm_test"
 rm -f spmm_test_out.out
 echo "data,K=128-rocsparse-gflops,K=128-gespmm-gflops,K=256-rocsparse-gflops,K=256-gespmm-gflops,K=512-rocsparse-gflops,K=512-gespmm-gflops," >> spmm_test_out.out
 for i in ./data/snap/*/; do

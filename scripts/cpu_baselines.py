@@ -9,7 +9,7 @@ import torch
 import gespmm_amd
 from gespmm_amd import graphs
 
-drv = os.path.join(ROOT, "ge-spmm_amd", "lib", "spmm_test")
+drv = os.path.join(ROOT, "gespmm_amd", "lib", "spmm_test")
 for name, ncols in (("cit-hepth-like", "32"), ("cit-hepth-like", "128"), ("pubmed", "128"), ("com-amazon-like", "128")):
     if name == "pubmed":
         path = os.path.join(ROOT, "tests", "golden", "pubmed.mtx")

@@ -25,7 +25,7 @@ for name in names:
     with open(out, "a") as f:
         f.write(os.path.basename(path) + ",")
     for method in ("-1",):
-        r = subprocess.run([os.path.join(ROOT, "ge-spmm_amd", "lib", "spmm_test"), path, "0", "--out", out,
+        r = subprocess.run([os.path.join(ROOT, "gespmm_amd", "lib", "spmm_test"), path, "0", "--out", out,
                             "--seed", "1", "--method", method], capture_output=True, text=True)
         print(r.stdout.strip()); print(r.stderr.strip()[-500:])
     with open(out, "a") as f:

@@ -17,10 +17,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # Build artefacts normally exist (driver runs __graft_entry__.build() first; the
     # .so files travel to the GPU box). Build only what is missing.
-    lib = os.path.join(ROOT, "ge-spmm_amd", "lib", "libgespmm.so")
-    drv = os.path.join(ROOT, "ge-spmm_amd", "lib", "spmm_test")
+    lib = os.path.join(ROOT, "gespmm_amd", "lib", "libgespmm.so")
+    drv = os.path.join(ROOT, "gespmm_amd", "lib", "spmm_test")
     if not (os.path.exists(lib) and os.path.exists(drv)):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "ge-spmm_amd", "csrc"), "-j8", "all"], check=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "gespmm_amd", "csrc"), "-j8", "all"], check=True)
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
 

@@ -100,7 +100,7 @@ def test_no_cpu_fallback(pkg):
 
 def test_product_never_touches_the_oracle():
     """The product package and its C sources may not reference oracle/ in any way."""
-    pkg_dir = os.path.join(ROOT, "ge-spmm_amd")
+    pkg_dir = os.path.join(ROOT, "gespmm_amd")
     for base, _, files in os.walk(pkg_dir):
         if os.sep + "lib" in base:
             continue

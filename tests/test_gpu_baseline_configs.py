@@ -19,7 +19,7 @@ import torch
 from helpers import GOLDEN, ROOT, bits
 
 pytestmark = pytest.mark.gpu
-DRIVER = os.path.join(ROOT, "ge-spmm_amd", "lib", "spmm_test")
+DRIVER = os.path.join(ROOT, "gespmm_amd", "lib", "spmm_test")
 
 
 def _exact_reference(rp, ci, vi, Bi, chunk=8):

@@ -9,7 +9,7 @@ import pytest
 from helpers import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
-DRIVER = os.path.join(ROOT, "ge-spmm_amd", "lib", "spmm_test")
+DRIVER = os.path.join(ROOT, "gespmm_amd", "lib", "spmm_test")
 
 
 def test_reference_command_line_and_csv(tmp_path):
