@@ -20,10 +20,15 @@ What is produced and where it comes from:
       hand-made MatrixMarket edge cases with HAND-WRITTEN expected COO (derived from the
       readMtx rules in util/util.hpp:104-333, not from running any code here).
   spmm_checksums.json
-      regression vectors: checksums + 64 sampled outputs of the oracle on the bundled
-      matrices (unweighted golden loop and valued fma chain). These are produced by
-      THIS repo's oracle — they pin the oracle against drift, not against the reference
-      (which ships no SpMM vectors).
+      checksums + 64 sampled outputs on the bundled matrices:
+        "unweighted_golden", "valued_golden"  OUTPUTS OF THE REFERENCE ITSELF RUN HERE —
+            oracle/_ref/libref_host.so = readMtx (util.hpp:57-333), COO->CSR
+            (spmm_test.cu:558-581) and the CPU golden loop (spmm_test.cu:596-604) compiled
+            from /root/reference by oracle/make_ref.sh; this script only feeds them B / val.
+        "valued_fma"  the oracle's restatement of the reference's DEVICE arithmetic (one
+            fused multiply-add per non-zero). The reference's kernels themselves, compiled
+            for gfx950 (oracle/_ref/libref_kernels.so), are compared with it on the GPU
+            (tests/test_gpu_ref_kernels.py) — a CPU cannot produce this column from them.
 cora.mtx / citeseer.mtx / pubmed.mtx are the reference's bundled data files
 (data/misc/, MIT licence), copied byte for byte as input fixtures.
 """
@@ -145,6 +150,10 @@ def sample_positions(M, N, count=64, seed=12345):
 
 def main():
     import oracle_py as o
+    import ref_py as r
+
+    if not r.available():
+        r.build()
 
     ka = {"xlsx": xlsx_facts("/root/reference/matrix_id_info.xlsx"), "survey": SURVEY_FACTS,
           "provenance": "see docstring of tests/golden/make_golden.py"}
@@ -162,16 +171,20 @@ def main():
 
     sums = {}
     for g in ("cora", "citeseer", "pubmed"):
-        coo = o.read_mtx(os.path.join(HERE, g + ".mtx"))
-        indptr, indices, _ = o.coo_to_csr(coo["nrows"], coo["row"], coo["col"])
+        coo = r.read_mtx(os.path.join(HERE, g + ".mtx"))  # the reference's loader
+        coo["nnz"] = coo["nvals"]
+        indptr, indices, ones = r.coo_to_csr(coo["nrows"], coo["ncols"], coo["row"], coo["col"])
         val = o.hash_val(coo["nnz"], seed=7)
         sums[g] = {}
         for N in N_LIST:
             B = o.hash_B(coo["ncols"], N, seed=1)
             pos = sample_positions(coo["nrows"], N)
             entry = {}
-            for mode, v in (("unweighted_golden", None), ("valued_fma", val)):
-                C = o.spmm(indptr, indices, v, B, mode="golden" if v is None else "fma")
+            for mode, v in (("unweighted_golden", None), ("valued_golden", val), ("valued_fma", val)):
+                if mode == "valued_fma":
+                    C = o.spmm(indptr, indices, v, B, mode="fma")
+                else:  # the reference's own loop
+                    C = r.golden(indptr, indices, ones if v is None else v, B)
                 entry[mode] = {
                     "sum": float(C.astype(np.float64).sum()),
                     "sumsq": float((C.astype(np.float64) ** 2).sum()),
@@ -181,6 +194,8 @@ def main():
             sums[g][str(N)] = entry
     with open(os.path.join(HERE, "spmm_checksums.json"), "w") as f:
         json.dump({"B": "oracle_py.hash_B(K, N, seed=1)", "val": "oracle_py.hash_val(nnz, seed=7)",
+                   "provenance": "unweighted_golden / valued_golden: reference lines via oracle/_ref "
+                                 "(see make_golden.py); valued_fma: oracle restatement",
                    "graphs": sums}, f, indent=0, sort_keys=True)
     print("golden fixtures written to", HERE)
 

@@ -277,3 +277,109 @@ def test_c5_row_shards_through_hip_equal_unsharded_bits(pkg, bundled, graph):
     whole_d = spmm.csr_spmm(rp, ci, val, B)
     scale = spmm.csr_spmm(rp, ci, val.abs(), B.abs(), cfg=cfg)
     assert torch.all((whole_d - whole).abs() <= 1e-4 * torch.maximum(whole.abs(), scale) + 1e-12)
+
+
+# ----------------------------------------------------------------------------- C5 at its own size (one GPU)
+
+def _int_dense(K, N, mult, device):
+    """Deterministic integer-valued B in [-4, 4], filled in row chunks (no K x N temporaries)."""
+    B = torch.empty((K, N), dtype=torch.float32, device=device)
+    j = torch.arange(N, device=device, dtype=torch.int64).unsqueeze(0)
+    step = 1 << 20
+    for k0 in range(0, K, step):
+        k = torch.arange(k0, min(k0 + step, K), device=device, dtype=torch.int64).unsqueeze(1)
+        B[k0:k0 + step] = ((((k * mult + j * 40503 + 12345) >> 7) % 9) - 4).float()
+    return B
+
+
+def _sub_csr(rp, ci, r0, r1):
+    e0, e1 = int(rp[r0]), int(rp[r1])
+    return (rp[r0:r1 + 1] - e0).contiguous(), ci[e0:e1]
+
+
+def _exact_rows(rp_s, ci_s, v_s, B, chunk=8):
+    """int64 index_add over a row block of A against the full B, column chunks (integer inputs)."""
+    m = rp_s.numel() - 1
+    N = B.shape[1]
+    rows = torch.repeat_interleave(torch.arange(m, device=B.device), (rp_s[1:] - rp_s[:-1]).long())
+    cil = ci_s.long()
+    out = torch.empty((m, N), dtype=torch.float32, device=B.device)
+    for c0 in range(0, N, chunk):
+        contrib = B[cil, c0:c0 + chunk].long()
+        if v_s is not None:
+            contrib = contrib * v_s.long().unsqueeze(1)
+        acc = torch.zeros((m, contrib.shape[1]), dtype=torch.int64, device=B.device)
+        acc.index_add_(0, rows, contrib)
+        out[:, c0:c0 + chunk] = acc.float()
+        del contrib, acc
+    return out
+
+
+@pytest.mark.parametrize("scale", (24, 26))
+def test_c5_rmat_at_full_scale_n256(pkg, scale):
+    """BASELINE configs[4] at its own size on ONE device: RMAT scale 26 (2^30 entries, B and C 64 GiB each)
+    x N = 256 when the device has the memory (MI355X: 288 GB), scale 24 always. 64-bit offsets into B
+    (K*N = 2^34), the long-row pass on (hub rows of 10^5..10^6 entries). Size-independent properties:
+      * integer-valued A and B make every association exact -> sampled row blocks AND the longest rows
+        must equal an independent int64 computation bit for bit (valued and unweighted);
+      * A . 1 = row degree for every row (unweighted, all columns);
+      * float values: the longest rows within 1e-4 * sum|a.b| of a float64 reference (north_star's bar,
+        scaled as SURVEY.md section 8 c4 prescribes), short rows bit-exact against the fma chain in CSR order."""
+    from gespmm_amd import graphs, spmm
+
+    N = 256
+    need = (2 * (1 << scale) * N * 4) + 16 * (1 << scale) * 12 + (8 << 30)
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    if free < need:
+        pytest.skip("scale %d needs %.0f GiB, device has %.0f GiB free" % (scale, need / 2**30, free / 2**30))
+    g = graphs.rmat_shard(scale, 16, 0, 1, seed=42, device="cuda")
+    rp, ci, M, K = g["rowptr"], g["colind"], g["M"], g["K"]
+    nnz = int(ci.numel())
+    assert nnz == 16 << scale and M == K == 1 << scale
+    deg = (rp[1:] - rp[:-1])
+    hubs = torch.topk(deg, 8).indices.tolist()
+    assert int(deg.max()) > 2048 * 16, "the long-row pass must be in play"
+    blocks = [(0, 2048), (M // 3, M // 3 + 2048), (M - 2048, M)] + [(h, h + 1) for h in hubs]
+
+    B = _int_dense(K, N, 2654435761, "cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    vi = torch.randint(-2, 3, (nnz,), generator=gen, device="cuda", dtype=torch.int32).float()
+    C = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    # unweighted, then integer-valued
+    for v in (None, vi):
+        if v is None:
+            spmm.csr_spmm_no_edge_value(rp, ci, B, out=C)
+        else:
+            spmm.csr_spmm(rp, ci, v, B, out=C)
+        for r0, r1 in blocks:
+            rp_s, ci_s = _sub_csr(rp, ci, r0, r1)
+            v_s = None if v is None else v[int(rp[r0]):int(rp[r1])]
+            ref = _exact_rows(rp_s, ci_s, v_s, B)
+            assert torch.equal(C[r0:r1], ref), ("scale %d rows %d..%d valued=%s" % (scale, r0, r1, v is not None))
+            del ref
+    # float values: hubs by tolerance, a short-row block bit-exact vs a sequential fp32 fma chain is covered
+    # at small sizes; here: |C - float64 reference| <= 1e-4 * sum|a.b| on the sampled rows
+    vf = (torch.rand(nnz, generator=gen, device="cuda") - 0.5)
+    spmm.csr_spmm(rp, ci, vf, B, out=C)
+    for r0, r1 in blocks:
+        rp_s, ci_s = _sub_csr(rp, ci, r0, r1)
+        v_s = vf[int(rp[r0]):int(rp[r1])].double()
+        rows = torch.repeat_interleave(torch.arange(r1 - r0, device="cuda"), (rp_s[1:] - rp_s[:-1]).long())
+        for c0 in range(0, N, 32):
+            contrib = B[ci_s.long(), c0:c0 + 32].double() * v_s.unsqueeze(1)
+            ref = torch.zeros((r1 - r0, 32), dtype=torch.float64, device="cuda").index_add_(0, rows, contrib)
+            scale_abs = torch.zeros_like(ref).index_add_(0, rows, contrib.abs())
+            err = (C[r0:r1, c0:c0 + 32].double() - ref).abs()
+            assert torch.all(err <= 1e-4 * torch.maximum(ref.abs(), scale_abs) + 1e-12), (scale, r0, c0)
+            del contrib, ref, scale_abs, err
+    # A . 1 = degree, every row, every column
+    B.fill_(1.0)
+    spmm.csr_spmm_no_edge_value(rp, ci, B, out=C)
+    want = deg.float().unsqueeze(1)
+    step = 1 << 22
+    for r0 in range(0, M, step):
+        assert torch.equal(C[r0:r0 + step], want[r0:r0 + step].expand(-1, N)), "A.1 != degree in rows %d.." % r0
+    del B, C, vi, vf
+    torch.cuda.empty_cache()

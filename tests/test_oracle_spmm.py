@@ -27,8 +27,8 @@ def test_committed_vectors(oracle, bundled, checksums, g):
         if g == "pubmed" and N == 512:
             continue  # 90 MFLOP through the literal loop: covered by cora/citeseer
         B = oracle.hash_B(G["K"], N, seed=1)
-        for mode, v in (("unweighted_golden", None), ("valued_fma", val)):
-            C = oracle.spmm(G["rowptr"], G["colind"], v, B, mode="golden" if v is None else "fma")
+        for mode, v in (("unweighted_golden", None), ("valued_golden", val), ("valued_fma", val)):
+            C = oracle.spmm(G["rowptr"], G["colind"], v, B, mode="fma" if mode == "valued_fma" else "golden")
             exp = checksums[g][str(N)][mode]
             assert int(np.bitwise_xor.reduce(bits(C).ravel())) == exp["xor"], (g, N, mode)
             assert float(C.astype(np.float64).sum()) == exp["sum"]
