@@ -70,11 +70,16 @@ EXPORTS = [
     "gespmm_simulate_l2_hits",
     "gespmm_debug_build_records",
     "gespmm_debug_build_outer_records",
+    "gespmm_device_cluster_rows",
+    "gespmm_device_l2_model",
+    "gespmm_plan_debug_tasks",
 ]
 
 PLAN_REORDER_AUTO = 0
 PLAN_REORDER = 1
 PLAN_NO_REORDER = 2
+PLAN_ANALYSIS_DEVICE = 0
+PLAN_ANALYSIS_HOST = 1
 PLAN_KERNEL_AUTO = 0
 PLAN_KERNEL_STREAM = 1
 PLAN_KERNEL_LDS_ROWS = 2
@@ -89,7 +94,7 @@ class LaunchCfg(Structure):
 
 class PlanOptions(Structure):
     _fields_ = [("reorder", c_int32), ("task_entries", c_int32), ("row_floor", c_int32), ("threads", c_int32),
-                ("flags", c_int32), ("kernel", c_int32)]
+                ("flags", c_int32), ("kernel", c_int32), ("analysis", c_int32)]
 
 
 class Coo(Structure):
@@ -172,6 +177,12 @@ def _load():
     lib.gespmm_plan_destroy.argtypes = [p]
     lib.gespmm_cluster_rows.restype = c_int
     lib.gespmm_cluster_rows.argtypes = [p, p, c_int64, c_int64, c_int32, p, p, p]
+    lib.gespmm_device_cluster_rows.restype = c_int
+    lib.gespmm_device_cluster_rows.argtypes = [p, p, c_int64, c_int64, c_int64, p, p, p, p]
+    lib.gespmm_device_l2_model.restype = ctypes.c_double
+    lib.gespmm_device_l2_model.argtypes = [p, p, c_int64, c_int64, c_int64, p, c_int32, c_int64, c_int64, c_int32, p]
+    lib.gespmm_plan_debug_tasks.restype = c_int
+    lib.gespmm_plan_debug_tasks.argtypes = [p, c_int32, p, c_int64]
     lib.gespmm_simulate_l2_hits.restype = ctypes.c_double
     lib.gespmm_simulate_l2_hits.argtypes = [p, p, c_int64, c_int64, p, c_int32, c_int64]
     lib.gespmm_row_partition.restype = c_int

@@ -28,6 +28,7 @@
 
 #include "../../include/gespmm.h"
 #include "plan.h"
+#include "plan_device.h"
 #include "reorder.h"
 #include "select.h"
 #include "spmm_kernels.h"
@@ -69,7 +70,9 @@ struct gespmm_plan {
     int32_t nrec = 0;
     double rec_dup = 0.0;          // non-zeros per distinct B row, averaged over the records
     int kernel_choice = 0;         // GESPMM_PLAN_KERNEL_*
-    std::vector<int32_t> perm_host;
+    std::vector<int32_t> perm_host;  // filled by the host analysis, or on demand (gespmm_plan_get_order)
+    int analysis = 0;                // GESPMM_PLAN_ANALYSIS_*
+    double model_seconds = 0.0;
     void* ws = nullptr;
     int64_t ws_bytes = 0;
     bool split_ready = false;
@@ -400,6 +403,46 @@ int default_task_entries(int64_t N) {
     return (int)t;
 }
 
+// Records of the two opt-in kernels (LDS-staged rows, task-outer), cut on the host from the row-permuted matrix and uploaded.
+hipError_t build_and_upload_records(gespmm_plan* p, const gespmm_plan_options* opt, const std::vector<int32_t>& rp,
+                                    const std::vector<int32_t>& ci, const std::vector<int32_t>& src, const float* val,
+                                    hipStream_t st) {
+    hipError_t e = hipSuccess;
+    const int64_t M = p->M, K = p->K;
+    const int target = (opt && opt->task_entries > 0) ? opt->task_entries : 0;
+    if (p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS || K <= 0) return e;  // not for matrices that need the long-row pass
+    if (p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS) {
+        RecordBuilder rb;
+        build_records(M, K, rp, ci, src, p->perm_host, target, rb);
+        p->nrec = rb.nrec();
+        p->rec_dup = rb.distinct > 0 ? (double)rb.entries / (double)rb.distinct : 0.0;
+        e = upload(&p->d_recs, rb.recs, st);
+        if (e == hipSuccess) e = upload(&p->d_rec_src, rb.src, st);
+        if (e == hipSuccess && p->valued && p->nrec > 0) {
+            const int64_t nslots = (int64_t)p->nrec * gespmm::kRecEntries;
+            hipLaunchKernelGGL(scatter_record_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
+                               p->d_rec_src, val, p->d_recs, nslots);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // rb goes out of scope
+    } else if (p->kernel_choice == GESPMM_PLAN_KERNEL_OUTER) {  // opt-in: measured level with the batch-stream kernel, not ahead
+        OuterBuilder ob;
+        build_outer_records(M, K, rp, ci, src, p->perm_host, target, ob);
+        p->norec = ob.nrec();
+        p->orec_dup = ob.distinct > 0 ? (double)ob.entries / (double)ob.distinct : 0.0;
+        e = upload(&p->d_orecs, ob.recs, st);
+        if (e == hipSuccess) e = upload(&p->d_orec_src, ob.src, st);
+        if (e == hipSuccess && p->valued && p->norec > 0) {
+            const int64_t nslots = (int64_t)p->norec * gespmm::kOutEntries;
+            hipLaunchKernelGGL(scatter_outer_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
+                               p->d_orec_src, val, p->d_orecs, nslots);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // ob goes out of scope
+    }
+    return e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,6 +533,71 @@ int gespmm_debug_build_outer_records(const int32_t* rowptr, const int32_t* colin
     return 0;
 }
 
+// The device analysis by itself (DEVICE rowptr / colind, HOST outputs) — what tests compare with gespmm_cluster_rows.
+int gespmm_device_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
+                               int32_t* perm_out_host, int32_t* levels_out, int32_t* clusters_out /* [16] */, void* stream) {
+    if (M < 0 || K < 0 || nnz < 0 || (M > 0 && (!rowptr || !perm_out_host)) || (nnz > 0 && !colind)) return GESPMM_EINVAL;
+    if (M == 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int32_t max_deg = 0, bad = 0;
+    hipError_t e = gespmm::device_validate_csr(rowptr, colind, M, K, nnz, &max_deg, &bad, st);
+    if (e != hipSuccess) return (int)e;
+    if (bad) return GESPMM_EINVAL;
+    int32_t* d_perm = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&d_perm), (size_t)M * 4);
+    if (e != hipSuccess) return (int)e;
+    gespmm::ClusterOptions opt;
+    gespmm::ClusterStats stats;
+    e = gespmm::device_cluster_rows(M, K, nnz, rowptr, colind, opt, d_perm, &stats, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(perm_out_host, d_perm, (size_t)M * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_perm);
+    if (e != hipSuccess) return (int)e;
+    if (levels_out) *levels_out = stats.levels;
+    if (clusters_out)
+        for (int i = 0; i < 16; ++i) clusters_out[i] = stats.clusters[i];
+    return 0;
+}
+
+// The device L2 model by itself: DEVICE rowptr / colind, perm_host (HOST, may be NULL = storage order). Returns the
+// modelled hit rate, or a negative value on error.
+double gespmm_device_l2_model(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
+                              const int32_t* perm_host, int32_t slices, int64_t window_rows, int64_t max_entries_per_slice,
+                              int32_t samples_per_slice, void* stream) {
+    if (M <= 0 || K <= 0 || nnz <= 0 || !rowptr || !colind || slices < 1 || slices > 16 || window_rows < 1) return -1.0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    double hits = -1.0;
+    hipError_t e = hipSuccess;
+    int32_t *d_perm = nullptr, *rp = nullptr, *ci = nullptr, *src = nullptr;
+    if (perm_host) {
+        e = hipMalloc(reinterpret_cast<void**>(&d_perm), (size_t)M * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&rp), ((size_t)M + 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ci), (size_t)nnz * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&src), (size_t)M * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_perm, perm_host, (size_t)M * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = gespmm::device_permute_csr(M, nnz, rowptr, colind, d_perm, rp, ci, src, st);
+    }
+    if (e == hipSuccess)
+        e = gespmm::device_l2_model(M, K, nnz, perm_host ? rp : rowptr, perm_host ? ci : colind, slices, window_rows,
+                                    max_entries_per_slice, samples_per_slice > 0 ? samples_per_slice : 8192, &hits, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    for (void* q : {(void*)d_perm, (void*)rp, (void*)ci, (void*)src})
+        if (q) (void)hipFree(q);
+    return e == hipSuccess ? hits : -1.0;
+}
+
+// Test hook: the task table of a clustered plan (which = 0: wavefront tasks, 1: lane-group tasks) as int4 records in
+// HOST memory; returns the number of tasks (<= capacity are copied) or a negative error.
+int gespmm_plan_debug_tasks(const gespmm_plan* p, int32_t which, int32_t* out_host, int64_t capacity) {
+    if (!p || which < 0 || which > 1) return GESPMM_EINVAL;
+    if (!p->reordered) return 0;
+    const int32_t n = which ? p->ngtasks : p->ntasks;
+    const int32_t* d = which ? p->d_gtasks : p->d_tasks;
+    const int64_t take = n < capacity ? n : capacity;
+    if (take > 0 && out_host && hipMemcpy(out_host, d, (size_t)take * 16, hipMemcpyDeviceToHost) != hipSuccess) return GESPMM_EINVAL;
+    return n;
+}
+
 int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
                        int64_t K, int64_t nnz, int64_t N, int variant, const gespmm_plan_options* opt, void* stream) {
     if (!out) return GESPMM_EINVAL;
@@ -522,28 +630,39 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
     }
     int user_flags = opt ? opt->flags : 0;
 
+    const int analysis = opt ? opt->analysis : GESPMM_PLAN_ANALYSIS_DEVICE;
+    if (analysis != GESPMM_PLAN_ANALYSIS_DEVICE && analysis != GESPMM_PLAN_ANALYSIS_HOST) {
+        delete p;
+        return GESPMM_EINVAL;
+    }
+    p->analysis = analysis;
+    const bool on_host = analysis == GESPMM_PLAN_ANALYSIS_HOST;
+
     try {
-        // ---- the matrix comes to the host once
-        std::vector<int32_t> h_rowptr((size_t)M + 1, 0), h_colind((size_t)nnz);
-        if (M > 0) e = hipMemcpyAsync(h_rowptr.data(), rowptr, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(h_colind.data(), colind, (size_t)nnz * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        // ---- one pass over the matrix on the device: rowptr monotone and consistent with nnz, every column index
+        //      inside [0, K) (the kernels trust them), the longest row
+        int32_t max_deg = 0, bad = 0;
+        e = gespmm::device_validate_csr(rowptr, colind, M, K, nnz, &max_deg, &bad, st);
         if (e != hipSuccess) {
             delete p;
             return (int)e;
         }
-        if (M > 0 && (h_rowptr[0] != 0 || h_rowptr[M] != nnz)) {
+        if (bad) {
             delete p;
-            return GESPMM_EINVAL;  // rowptr does not describe nnz entries
+            return GESPMM_EINVAL;  // rowptr does not describe nnz entries, or a column index is outside [0, K)
         }
-        int32_t max_deg = 0;
-        for (int64_t r = 0; r < M; ++r) {
-            const int32_t d = h_rowptr[r + 1] - h_rowptr[r];
-            if (d < 0) {
+        // ---- host analysis only (GESPMM_PLAN_ANALYSIS_HOST): the matrix comes to the host once
+        std::vector<int32_t> h_rowptr, h_colind;
+        if (on_host) {
+            h_rowptr.assign((size_t)M + 1, 0);
+            h_colind.resize((size_t)nnz);
+            if (M > 0) e = hipMemcpyAsync(h_rowptr.data(), rowptr, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(h_colind.data(), colind, (size_t)nnz * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
                 delete p;
-                return GESPMM_EINVAL;
+                return (int)e;
             }
-            if (d > max_deg) max_deg = d;
         }
         p->max_degree = max_deg;
         // long-row pass: decided by the longest row (the plain entry points have to guess)
@@ -569,10 +688,91 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
         bool reorder = false;
         if (reorder_mode == GESPMM_PLAN_REORDER) reorder = stream_family && M > 1 && nnz > 0;
         else if (reorder_mode == GESPMM_PLAN_REORDER_AUTO)
-            // B beyond the L2s (below that every order hits), enough rows to cluster, not so many entries that
-            // the host analysis takes minutes
+            // B beyond the L2s (below that every order hits), enough rows to cluster
             reorder = stream_family && M >= (1 << 14) && nnz >= M && b_bytes > (8ll << 20) && mean <= 96 &&
                       nnz <= (1ll << 28);
+        // the model of the XCD L2s: window = B rows that 3 MiB hold; matrices beyond 2^25 non-zeros: the first 2^22
+        // non-zeros of each of the 8 slices are the sample
+        const int64_t model_sample = nnz <= (1ll << 25) ? 0 : (1ll << 22);
+        const int64_t model_rowb = 4 * (N < tile_cols ? N : tile_cols);
+        const int64_t model_window = (3ll << 20) / (model_rowb > 0 ? model_rowb : 4);
+
+        if (reorder && !on_host) {
+            // ==================================================================== analysis on the device
+            const auto tc = std::chrono::steady_clock::now();
+            e = hipMalloc(reinterpret_cast<void**>(&p->d_perm), (size_t)M * 4);
+            gespmm::ClusterOptions copt;
+            if (e == hipSuccess) e = gespmm::device_cluster_rows(M, K, nnz, rowptr, colind, copt, p->d_perm, &p->stats, st);
+            p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_rowptr), ((size_t)M + 1) * 4);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_colind), (size_t)(nnz > 0 ? nnz : 1) * 4);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_src_begin), (size_t)M * 4);
+            if (e == hipSuccess)
+                e = gespmm::device_permute_csr(M, nnz, rowptr, colind, p->d_perm, p->d_rowptr, p->d_colind, p->d_src_begin, st);
+            const auto tm = std::chrono::steady_clock::now();
+            if (e == hipSuccess)
+                e = gespmm::device_l2_model(M, K, nnz, rowptr, colind, 8, model_window, model_sample, 8192, &p->hits_before, st);
+            if (e == hipSuccess)
+                e = gespmm::device_l2_model(M, K, nnz, p->d_rowptr, p->d_colind, 8, model_window, model_sample, 8192,
+                                            &p->hits_after, st);
+            p->model_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tm).count();
+            if (e != hipSuccess) {
+                free_device(p);
+                delete p;
+                return (int)e;
+            }
+            if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && p->hits_after < p->hits_before + 0.05) {
+                reorder = false;  // the storage order is as good: keep it and pay nothing per launch
+                (void)hipFree(p->d_perm);
+                (void)hipFree(p->d_rowptr);
+                (void)hipFree(p->d_colind);
+                (void)hipFree(p->d_src_begin);
+                p->d_perm = p->d_rowptr = p->d_colind = p->d_src_begin = nullptr;
+            }
+        }
+        if (reorder && !on_host) {
+            // ---- task tables (same greedy cut as the host path), values, optional records
+            int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
+            if (!(opt && opt->task_entries > 0) && budget < 5 * mean) budget = (int)(5 * mean < 512 ? 5 * mean : 512);
+            const int floor_opt = opt ? opt->row_floor : 0;
+            const int64_t row_floor = floor_opt < 0 ? 0 : (floor_opt > 0 ? floor_opt : 8);
+            p->task_entries = budget;
+            int gbudget = budget / 2 > 16 ? budget / 2 : 16;
+            if (opt && opt->task_entries > 0) gbudget = opt->task_entries / 2 > 4 ? opt->task_entries / 2 : 4;
+            else if (mean < 16) gbudget = 16;
+            e = gespmm::device_cut_tasks(M, p->d_rowptr, budget, row_floor, &p->d_tasks, &p->ntasks, st);
+            if (e == hipSuccess) e = gespmm::device_cut_tasks(M, p->d_rowptr, gbudget, 0, &p->d_gtasks, &p->ngtasks, st);
+            if (e == hipSuccess && p->valued) e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(nnz > 0 ? nnz : 1) * 4);
+            if (e == hipSuccess && p->valued && nnz > 0) {
+                hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
+                                   p->d_src_begin, val, p->d_val, (int)M, (int)nnz);
+                e = hipGetLastError();
+            }
+            p->kernel_choice = opt ? opt->kernel : GESPMM_PLAN_KERNEL_AUTO;
+            const bool want_recs = (p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS || p->kernel_choice == GESPMM_PLAN_KERNEL_OUTER) &&
+                                   !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) && K > 0;
+            if (e == hipSuccess && want_recs) {
+                // the two opt-in record kernels cut their records on the host: the permuted matrix travels once
+                std::vector<int32_t> rp((size_t)M + 1), ci((size_t)nnz), src((size_t)M);
+                p->perm_host.resize((size_t)M);
+                e = hipMemcpyAsync(rp.data(), p->d_rowptr, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(ci.data(), p->d_colind, (size_t)nnz * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(src.data(), p->d_src_begin, (size_t)M * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(p->perm_host.data(), p->d_perm, (size_t)M * 4, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e == hipSuccess) e = build_and_upload_records(p, opt, rp, ci, src, val, st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                free_device(p);
+                delete p;
+                return (int)e;
+            }
+            p->reordered = true;
+            if (p->hits_after >= 0.40 && N <= 128 && mean <= 8 && nnz >= (1 << 20) && !(opt && opt->flags & 0x20000))
+                p->launch_flags |= GESPMM_FLAG_SHALLOW_UNROLL;  // see the host branch below
+            reorder = false;  // done: skip the host branch
+        }
 
         if (reorder) {
             const auto tc = std::chrono::steady_clock::now();
@@ -590,12 +790,8 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             // A model of the XCD L2s says whether the new order is worth having (graphs whose storage order is
             // already local, or that have no structure to find, keep their order and pay nothing per launch).
             {
-                // (matrices beyond 2^25 non-zeros: the first 2^22 non-zeros of each of the 8 slices are the sample)
-                const int64_t sample = nnz <= (1ll << 25) ? 0 : (1ll << 22);
-                const int64_t rowb = 4 * (N < tile_cols ? N : tile_cols);
-                const int64_t window = (3ll << 20) / (rowb > 0 ? rowb : 4);
-                p->hits_before = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), nullptr, 8, window, sample);
-                p->hits_after = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), p->perm_host.data(), 8, window, sample);
+                p->hits_before = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), nullptr, 8, model_window, model_sample);
+                p->hits_after = gespmm::simulate_l2_hits(M, K, h_rowptr.data(), h_colind.data(), p->perm_host.data(), 8, model_window, model_sample);
                 if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && p->hits_after < p->hits_before + 0.05) reorder = false;
             }
         }
@@ -661,40 +857,8 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                                    p->d_src_begin, val, p->d_val, (int)M, (int)nnz);
                 e = hipGetLastError();
             }
-            // ---- records of the LDS-staged-rows kernel (not for matrices that need the long-row pass)
             p->kernel_choice = opt ? opt->kernel : GESPMM_PLAN_KERNEL_AUTO;
-            RecordBuilder rb;
-            if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS && !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) &&
-                K > 0) {
-                build_records(M, K, rp, ci, src, p->perm_host, (opt && opt->task_entries > 0) ? opt->task_entries : 0, rb);
-                p->nrec = rb.nrec();
-                p->rec_dup = rb.distinct > 0 ? (double)rb.entries / (double)rb.distinct : 0.0;
-                e = upload(&p->d_recs, rb.recs, st);
-                if (e == hipSuccess) e = upload(&p->d_rec_src, rb.src, st);
-                if (e == hipSuccess && p->valued && p->nrec > 0) {
-                    const int64_t nslots = (int64_t)p->nrec * gespmm::kRecEntries;
-                    hipLaunchKernelGGL(scatter_record_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
-                                       p->d_rec_src, val, p->d_recs, nslots);
-                    e = hipGetLastError();
-                }
-            }
-            // ---- records of the task-outer kernel (short-row matrices without the long-row pass)
-            OuterBuilder ob;
-            if (e == hipSuccess && p->kernel_choice != GESPMM_PLAN_KERNEL_STREAM && p->kernel_choice != GESPMM_PLAN_KERNEL_SEG_STREAM &&
-                p->kernel_choice != GESPMM_PLAN_KERNEL_LDS_ROWS && !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS) && K > 0 &&
-                p->kernel_choice == GESPMM_PLAN_KERNEL_OUTER) {  // opt-in: measured level with the batch-stream kernel, not ahead
-                build_outer_records(M, K, rp, ci, src, p->perm_host, (opt && opt->task_entries > 0) ? opt->task_entries : 0, ob);
-                p->norec = ob.nrec();
-                p->orec_dup = ob.distinct > 0 ? (double)ob.entries / (double)ob.distinct : 0.0;
-                e = upload(&p->d_orecs, ob.recs, st);
-                if (e == hipSuccess) e = upload(&p->d_orec_src, ob.src, st);
-                if (e == hipSuccess && p->valued && p->norec > 0) {
-                    const int64_t nslots = (int64_t)p->norec * gespmm::kOutEntries;
-                    hipLaunchKernelGGL(scatter_outer_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
-                                       p->d_orec_src, val, p->d_orecs, nslots);
-                    e = hipGetLastError();
-                }
-            }
+            if (e == hipSuccess) e = build_and_upload_records(p, opt, rp, ci, src, val, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors go out of scope
             if (e != hipSuccess) {
                 free_device(p);
@@ -885,7 +1049,9 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
 
 int gespmm_plan_get_order(const gespmm_plan* p, int32_t* perm_host) {
     if (!p || (p->M > 0 && !perm_host)) return GESPMM_EINVAL;
-    if (p->reordered) std::memcpy(perm_host, p->perm_host.data(), (size_t)p->M * 4);
+    if (p->reordered && p->perm_host.size() != (size_t)p->M) {  // device analysis: the order lives on the device
+        if (hipMemcpy(perm_host, p->d_perm, (size_t)p->M * 4, hipMemcpyDeviceToHost) != hipSuccess) return GESPMM_EINVAL;
+    } else if (p->reordered) std::memcpy(perm_host, p->perm_host.data(), (size_t)p->M * 4);
     else
         for (int64_t i = 0; i < p->M; ++i) perm_host[i] = (int32_t)i;
     return p->reordered ? 1 : 0;
@@ -916,9 +1082,9 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "
-                     "analysis=%.3fs (clustering %.3fs) | %s",
+                     "analysis=%.4fs on the %s (clustering %.4fs) | %s",
                      p->stats.levels, lv, p->ntasks, p->task_entries, p->ngtasks, p->max_degree, p->hits_before, p->hits_after,
-                     p->analysis_seconds, p->cluster_seconds, kern);
+                     p->analysis_seconds, p->analysis == GESPMM_PLAN_ANALYSIS_HOST ? "host" : "device", p->cluster_seconds, kern);
     } else {
         n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.3fs | %s",
                      p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, what);

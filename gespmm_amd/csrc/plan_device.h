@@ -1,0 +1,41 @@
+// plan_device.h — the plan's analysis stage ON THE DEVICE (plan_device.hip): validation, row clustering
+// (the algorithm of reorder.cpp, same labels), L2 model, row-permuted copy, task tables. All pointers are
+// DEVICE pointers unless named *_host; everything is ordered on `st`; the functions synchronise `st` where
+// they need a count on the host (a handful of times per call).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "reorder.h"
+
+namespace gespmm {
+
+// rowptr[0] == 0, rowptr non-decreasing, rowptr[M] == nnz, every colind in [0, K). *bad_host: 0 = fine,
+// 1 = rowptr malformed, 2 = a column index out of range. *max_degree_host: longest row.
+hipError_t device_validate_csr(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
+                               int32_t* max_degree_host, int32_t* bad_host, hipStream_t st);
+
+// Multi-level label propagation of reorder.cpp on the device: perm[i] = original row processed at position i.
+// Same rules (snapshot half-sweeps, size caps, hash tie-breaks, twins), hence the same order as cluster_rows().
+hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr, const int32_t* colind,
+                               const ClusterOptions& opt, int32_t* perm, ClusterStats* stats_host, hipStream_t st);
+
+// rowptr_p[M+1], colind_p[nnz], src_begin[M] of the matrix with its rows in `perm` order.
+hipError_t device_permute_csr(int64_t M, int64_t nnz, const int32_t* rowptr, const int32_t* colind, const int32_t* perm,
+                              int32_t* rowptr_p, int32_t* colind_p, int32_t* src_begin, hipStream_t st);
+
+// The L2 model of simulate_l2_hits() (rows of `rowptr`/`colind` in storage order — pass the permuted copy to
+// judge an order): `slices` parts of equal non-zero count, an LRU of `window` B rows each; an unbiased estimate
+// from `samples_per_slice` stratified accesses per slice whose LRU stack distance is computed exactly
+// (all accesses when a slice has fewer). max_entries_per_slice > 0: only the head of every slice is modelled.
+hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr, const int32_t* colind, int slices,
+                           int64_t window, int64_t max_entries_per_slice, int samples_per_slice, double* hits_host,
+                           hipStream_t st);
+
+// Greedy task cutting of plan.cpp (a task = consecutive rows, <= kMaxRowsPerWave of them, cost <= budget, at least
+// one row; cost of a row = max(entries, row_floor)). *tasks = int4 {first row, #rows, CSR begin, CSR end} per task,
+// allocated with hipMalloc (caller frees).
+hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, int64_t budget, int64_t row_floor, int32_t** tasks,
+                            int32_t* ntasks_host, hipStream_t st);
+
+}  // namespace gespmm

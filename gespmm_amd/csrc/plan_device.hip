@@ -1,0 +1,1257 @@
+// plan_device.hip — the plan's analysis stage on the device.
+//
+// Round 2 built plans on the host (plan.cpp copied the matrix over PCIe and ran reorder.cpp there): 0.17 s for a
+// com-Amazon-sized graph, 4-6 s for a products-sized one, which the reference's own protocols (200 timed launches,
+// spmm_test.cu:714; 200 epochs, gcn_custom.py:134) never amortise. The same analysis as device passes:
+//
+//   validation          one pass over rowptr / colind (monotone, in range, longest row)
+//   row clustering      the multi-level label propagation of reorder.cpp, rule for rule (snapshot half-sweeps, size
+//                       caps, hash tie-breaks, twins), so the order is IDENTICAL to cluster_rows() on the host —
+//                       tests/test_gpu_plan_device.py compares the two permutations entry by entry:
+//                         * a half-sweep = "heaviest label among my neighbours" per node, by degree class:
+//                             1..8      8 lanes per node,  all-pairs match through lane shuffles
+//                             9..64     64 lanes per node, all-pairs match through lane shuffles
+//                             65..2048  one wavefront per node, open-addressing hash table in LDS
+//                             > 2048    one workgroup per node, dense accumulator over the label space in HBM
+//                           (integer weights: sums do not depend on the order of the additions);
+//                         * contraction = relabel (scan), merged adjacency = radix sort of (cluster, column-cluster)
+//                           pairs + run sums, transposed adjacency = one more stable sort (rocPRIM);
+//                         * final order = stable sorts by the labels of each level, finest first.
+//   L2 model            LRU stack distances: previous use of every column through one sort, then the exact number
+//                       of distinct columns in between for a stratified sample of accesses (early exit at the
+//                       window) — an unbiased estimate of simulate_l2_hits() to +-0.5 points
+//   permuted copy       scan of the permuted degrees + one gather pass
+//   task tables         the greedy cut of plan.cpp, parallel: next[] per row, per-block exit tables, one short
+//                       serial walk over blocks, per-block marking, scan
+//
+// No reference counterpart (the reference has no analysis stage; see plan.cpp).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+#include "plan_device.h"
+#include "spmm_kernels.h"
+#include "workspace.h"
+
+namespace gespmm {
+
+namespace {
+
+#define GESPMM_TRY(expr)                       \
+    do {                                       \
+        hipError_t e__ = (expr);               \
+        if (e__ != hipSuccess) return e__;     \
+    } while (0)
+
+// Stream-ordered temporaries from the library's pool, all released when the object goes out of scope.
+struct Scratch {
+    hipStream_t st;
+    std::vector<void*> blocks;
+    explicit Scratch(hipStream_t s) : st(s) {}
+    ~Scratch() { release_all(); }
+    void release_all() {
+        for (void* b : blocks) (void)workspace_free(b, st);
+        blocks.clear();
+    }
+    template <typename T>
+    hipError_t get(T** out, int64_t count) {
+        void* p = nullptr;
+        hipError_t e = workspace_alloc(&p, (size_t)(count > 0 ? count : 1) * sizeof(T), st);
+        if (e != hipSuccess) return e;
+        blocks.push_back(p);
+        *out = reinterpret_cast<T*>(p);
+        return hipSuccess;
+    }
+    void release(void* p) {
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i] == p) {
+                (void)workspace_free(p, st);
+                blocks.erase(blocks.begin() + (long)i);
+                return;
+            }
+    }
+};
+
+inline int bits_for(int64_t n) {  // bits that hold every value in [0, n)
+    int b = 1;
+    while (b < 62 && ((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
+
+__device__ inline uint32_t mix32(uint32_t x) {  // == reorder.cpp
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+// row owning CSR position p: ptr[lo] <= p < ptr[lo + 1]
+__device__ inline int owner_of(const int32_t* __restrict__ ptr, int n, int p) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------ validation
+
+__global__ void k_validate(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t M, int64_t K,
+                           int64_t nnz, int32_t* __restrict__ out /* {bad, max_degree} */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0, deg = 0;
+    if (i < M) {
+        const int a = rowptr[i], b = rowptr[i + 1];
+        deg = b - a;
+        if (deg < 0) bad |= 1;
+        if (i == 0 && a != 0) bad |= 1;
+        if (i == M - 1 && (int64_t)b != nnz) bad |= 1;
+    }
+    if (i < nnz && (uint32_t)colind[i] >= (uint64_t)K) bad |= 2;
+    for (int o = 32; o > 0; o >>= 1) {
+        bad |= __shfl_xor(bad, o);
+        deg = max(deg, __shfl_xor(deg, o));
+    }
+    if (lane_id() == 0) {
+        if (bad) atomicOr(&out[0], bad);
+        if (deg > 0) atomicMax(&out[1], deg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+
+__global__ void k_iota(int32_t* __restrict__ a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (int32_t)i;
+}
+
+__global__ void k_fill(int32_t* __restrict__ a, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+// out[i] = first position u in sorted keys[0..n) with keys[u] >= i, for i in [0, nseg]
+__global__ void k_lower_bound_ptr(const int32_t* __restrict__ keys, int n, int nseg, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nseg) return;
+    int lo = 0, hi = n;  // first index with keys[idx] >= i
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < i) lo = mid + 1;
+        else hi = mid;
+    }
+    out[i] = lo;
+}
+
+__global__ void k_gather_rows_of(const int32_t* __restrict__ ptr, int n, const int32_t* __restrict__ pos, int cnt,
+                                 int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = owner_of(ptr, n, pos[i]);
+}
+
+__global__ void k_gather2(const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b,
+                          const int32_t* __restrict__ index, int cnt, int32_t* __restrict__ out_a,
+                          int32_t* __restrict__ out_b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int j = index[i];
+    out_a[i] = src_a[j];
+    out_b[i] = src_b[j];
+}
+
+// ------------------------------------------------------------------------------------------------ label propagation
+
+// One side of a bipartite level on the device: node -> (neighbour on the other side, weight).
+struct DAdj {
+    const int32_t* ptr = nullptr;  // [n + 1]
+    const int32_t* idx = nullptr;
+    const int32_t* w = nullptr;    // nullptr: all ones
+};
+
+constexpr int kBins = 4;  // degree classes 1..8, 9..64, 65..2048, > 2048
+constexpr int kHashSlots = 4096;
+__device__ inline int bin_of(int d) { return d <= 8 ? 0 : (d <= 64 ? 1 : (d <= 2048 ? 2 : 3)); }
+
+// lists[b * n + ...] = nodes of class b (order irrelevant: every node's result depends only on the snapshot)
+__global__ void k_bin_nodes(const int32_t* __restrict__ ptr, const int32_t* __restrict__ twin, int n,
+                            int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = -1;
+    if (i < n) {
+        const int d = ptr[i + 1] - ptr[i];
+        if (d > 0 && !(twin && twin[i] >= 0)) b = bin_of(d);
+    }
+    const int lane = lane_id();
+    for (int k = 0; k < kBins; ++k) {
+        const unsigned long long mask = __ballot(b == k);
+        if (mask == 0) continue;
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counts[k], __popcll(mask));
+        base = __shfl(base, leader);
+        if (b == k) lists[(int64_t)k * n + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+struct LpArgs {
+    DAdj adj;                    // adjacency of the side that moves
+    const int32_t* nbr_label;    // labels of the other side (snapshot)
+    const int32_t* cur;          // labels of this side (snapshot)
+    int32_t* next;
+    const int32_t* size;         // rows side: original rows owned by each label (snapshot); nullptr on the column side
+    const int32_t* rweight;      // rows side: original rows owned by each node
+    long long cap;
+    uint32_t seed;
+    int skip_half;               // rows side, twins, not the last sweep: half of the nodes sit this sweep out
+    const int32_t* list;
+    const int32_t* count;
+    const int32_t* done;
+};
+
+__device__ inline bool sits_out(const LpArgs& a, int node) {
+    return a.skip_half && (mix32((uint32_t)node * 0x85ebca6bu ^ a.seed) & 1u);
+}
+
+// nodes outside every class (no neighbours / twins): columns with a twin carry their cluster's label, the rest keep theirs
+__global__ void k_lp_default(const int32_t* __restrict__ cur, const int32_t* __restrict__ twin,
+                             const int32_t* __restrict__ rlab, int n, int32_t* __restrict__ next,
+                             const int32_t* __restrict__ done) {
+    if (*done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    next[i] = (twin && twin[i] >= 0) ? rlab[twin[i]] : cur[i];
+}
+
+// (weight, hash, label) butterfly maximum inside a group of G lanes: larger weight wins, then the smaller hash
+template <int G>
+__device__ inline void best_of_group(long long& bt, uint32_t& bh, int& bL) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const long long ot = __shfl_xor(bt, o, G);
+        const uint32_t oh = (uint32_t)__shfl_xor((int)bh, o, G);
+        const int oL = __shfl_xor(bL, o, G);
+        if (ot > bt || (ot == bt && ot >= 0 && oh < bh)) {
+            bt = ot;
+            bh = oh;
+            bL = oL;
+        }
+    }
+}
+
+// degree <= G: one entry per lane, every lane sums the weights of the lanes that carry its label
+template <int G, bool ROWS>
+__global__ void __launch_bounds__(256) k_lp_small(LpArgs a) {
+    if (*a.done) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = tid / G, l = tid % G;
+    const bool active = g < *a.count;
+    const int node = active ? a.list[g] : 0;
+    const int beg = active ? a.adj.ptr[node] : 0, end = active ? a.adj.ptr[node + 1] : 0;
+    const int e = beg + l;
+    int L = -1, wt = 0;
+    if (e < end) {
+        L = a.nbr_label[a.adj.idx[e]];
+        wt = (L >= 0) ? (a.adj.w ? a.adj.w[e] : 1) : 0;
+    }
+    long long tot = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int Lj = __shfl(L, j, G);
+        const int wj = __shfl(wt, j, G);
+        tot += (Lj == L) ? wj : 0;
+    }
+    const int own = active ? a.cur[node] : -1;
+    long long own_w = (L >= 0 && L == own) ? tot : 0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) own_w = max(own_w, __shfl_xor(own_w, o, G));
+    bool cand = L >= 0 && L != own && tot > own_w;  // the own label keeps every tie it is part of
+    if (ROWS && cand) cand = (long long)a.size[L] + a.rweight[node] <= a.cap;
+    long long bt = cand ? tot : -1;
+    uint32_t bh = mix32((uint32_t)L ^ a.seed);
+    int bL = L;
+    best_of_group<G>(bt, bh, bL);
+    if (active && l == 0) a.next[node] = (ROWS && sits_out(a, node)) ? own : (bt >= 0 ? bL : own);
+}
+
+// 64 < degree <= 2048: one wavefront per node, label -> weight in an LDS hash table
+template <bool ROWS>
+__global__ void __launch_bounds__(64) k_lp_wave(LpArgs a) {
+    __shared__ int s_key[kHashSlots];
+    __shared__ unsigned long long s_wt[kHashSlots];
+    if (*a.done) return;
+    const int g = blockIdx.x;
+    if (g >= *a.count) return;
+    const int node = a.list[g];
+    const int lane = threadIdx.x;
+    const int own = a.cur[node];
+    if (ROWS && sits_out(a, node)) {
+        if (lane == 0) a.next[node] = own;
+        return;
+    }
+    const int beg = a.adj.ptr[node], end = a.adj.ptr[node + 1];
+    int T = 128;
+    while (T < 2 * (end - beg)) T <<= 1;
+    for (int s = lane; s < T; s += 64) {
+        s_key[s] = -1;
+        s_wt[s] = 0ull;
+    }
+    __syncthreads();
+    for (int e = beg + lane; e < end; e += 64) {
+        const int L = a.nbr_label[a.adj.idx[e]];
+        if (L < 0) continue;
+        const unsigned long long wt = (unsigned long long)(a.adj.w ? a.adj.w[e] : 1);
+        int slot = (int)(mix32((uint32_t)L) & (uint32_t)(T - 1));
+        for (;;) {
+            const int prev = atomicCAS(&s_key[slot], -1, L);
+            if (prev == -1 || prev == L) {
+                atomicAdd(&s_wt[slot], wt);
+                break;
+            }
+            slot = (slot + 1) & (T - 1);
+        }
+    }
+    __syncthreads();
+    long long own_w = 0;
+    if (own >= 0) {
+        int slot = (int)(mix32((uint32_t)own) & (uint32_t)(T - 1));
+        for (;;) {
+            const int k = s_key[slot];
+            if (k == own) {
+                own_w = (long long)s_wt[slot];
+                break;
+            }
+            if (k == -1) break;
+            slot = (slot + 1) & (T - 1);
+        }
+    }
+    long long bt = -1;
+    uint32_t bh = 0;
+    int bL = -1;
+    const int rw = ROWS ? a.rweight[node] : 0;
+    for (int s = lane; s < T; s += 64) {
+        const int L = s_key[s];
+        if (L < 0 || L == own) continue;
+        const long long t = (long long)s_wt[s];
+        if (t <= own_w) continue;
+        if (ROWS && (long long)a.size[L] + rw > a.cap) continue;
+        const uint32_t h = mix32((uint32_t)L ^ a.seed);
+        if (t > bt || (t == bt && h < bh)) {
+            bt = t;
+            bh = h;
+            bL = L;
+        }
+    }
+    best_of_group<64>(bt, bh, bL);
+    if (lane == 0) a.next[node] = bt >= 0 ? bL : own;
+}
+
+// degree > 2048: a workgroup per node, weights accumulated in a dense array over the label space (one array per
+// workgroup, zero on entry and zero again on exit); all accesses through L2 atomics / device-scope loads
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_lp_dense(LpArgs a, unsigned long long* __restrict__ acc_all, int64_t nlabels) {
+    __shared__ long long s_t[256];
+    __shared__ uint32_t s_h[256];
+    __shared__ int s_L[256];
+    if (*a.done) return;
+    unsigned long long* acc = acc_all + (int64_t)blockIdx.x * nlabels;
+    const int cnt = *a.count;
+    const int tid = threadIdx.x;
+    for (int g = blockIdx.x; g < cnt; g += gridDim.x) {
+        const int node = a.list[g];
+        const int own = a.cur[node];
+        if (ROWS && sits_out(a, node)) {
+            if (tid == 0) a.next[node] = own;
+            continue;
+        }
+        const int beg = a.adj.ptr[node], end = a.adj.ptr[node + 1];
+        for (int e = beg + tid; e < end; e += 256) {
+            const int L = a.nbr_label[a.adj.idx[e]];
+            if (L >= 0) atomicAdd(&acc[L], (unsigned long long)(a.adj.w ? a.adj.w[e] : 1));
+        }
+        __threadfence();
+        __syncthreads();
+        const long long own_w =
+            own >= 0 ? (long long)__hip_atomic_load(&acc[own], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        long long bt = -1;
+        uint32_t bh = 0;
+        int bL = -1;
+        const int rw = ROWS ? a.rweight[node] : 0;
+        for (int e = beg + tid; e < end; e += 256) {
+            const int L = a.nbr_label[a.adj.idx[e]];
+            if (L < 0 || L == own) continue;
+            const long long t = (long long)__hip_atomic_load(&acc[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t <= own_w) continue;
+            if (ROWS && (long long)a.size[L] + rw > a.cap) continue;
+            const uint32_t h = mix32((uint32_t)L ^ a.seed);
+            if (t > bt || (t == bt && h < bh)) {
+                bt = t;
+                bh = h;
+                bL = L;
+            }
+        }
+        s_t[tid] = bt;
+        s_h[tid] = bh;
+        s_L[tid] = bL;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const long long ot = s_t[tid + o];
+                const uint32_t oh = s_h[tid + o];
+                if (ot > s_t[tid] || (ot == s_t[tid] && ot >= 0 && oh < s_h[tid])) {
+                    s_t[tid] = ot;
+                    s_h[tid] = oh;
+                    s_L[tid] = s_L[tid + o];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) a.next[node] = s_t[0] >= 0 ? s_L[0] : own;
+        for (int e = beg + tid; e < end; e += 256) {
+            const int L = a.nbr_label[a.adj.idx[e]];
+            if (L >= 0) __hip_atomic_store(&acc[L], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+__global__ void k_sizes(const int32_t* __restrict__ rlab, const int32_t* __restrict__ rweight, int R,
+                        int32_t* __restrict__ size, const int32_t* __restrict__ done) {
+    if (*done) return;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) atomicAdd(&size[rlab[r]], rweight[r]);
+}
+
+__global__ void k_zero_if_running(int32_t* __restrict__ a, int n, const int32_t* __restrict__ done) {
+    if (*done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = 0;
+}
+
+__global__ void k_commit(int32_t* __restrict__ cur, const int32_t* __restrict__ next, int n, int32_t* __restrict__ changed,
+                         const int32_t* __restrict__ done) {
+    if (*done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int ch = 0;
+    if (i < n) {
+        const int v = next[i];
+        ch = v != cur[i];
+        cur[i] = v;
+    }
+    if (changed) {
+        const unsigned long long m = __ballot(ch);
+        if (m && lane_id() == (__ffsll((long long)m) - 1)) atomicAdd(changed, __popcll(m));
+    }
+}
+
+// fewer than 0.25 % of the row nodes moved: the level's remaining sweeps are skipped (reorder.cpp)
+__global__ void k_check_done(int32_t* __restrict__ changed, int R, int32_t* __restrict__ done) {
+    if (*done == 0 && (long long)(*changed) * 400 < R) *done = 1;
+    *changed = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ contraction
+
+__global__ void k_mark_used(const int32_t* __restrict__ rlab, int R, const int32_t* __restrict__ clab, int C,
+                            int32_t* __restrict__ used_r, int32_t* __restrict__ used_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) used_r[rlab[i]] = 1;
+    if (i < C) {
+        const int L = clab[i];
+        if (L >= 0) used_c[L] = 1;
+    }
+}
+
+__global__ void k_make_ids(const int32_t* __restrict__ used, const int32_t* __restrict__ pos, int R,
+                           int32_t* __restrict__ ids) {
+    const int L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L < R) ids[L] = used[L] ? pos[L] : -1;
+}
+
+__global__ void k_relabel(int32_t* __restrict__ node_of_row, const int32_t* __restrict__ rlab,
+                          const int32_t* __restrict__ rid, int64_t M, int32_t* __restrict__ level_lab) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int v = rid[rlab[node_of_row[i]]];
+    node_of_row[i] = v;
+    level_lab[i] = v;
+}
+
+__global__ void k_new_weights(const int32_t* __restrict__ rlab, const int32_t* __restrict__ rid,
+                              const int32_t* __restrict__ rweight, int R, int32_t* __restrict__ rweight2) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) atomicAdd(&rweight2[rid[rlab[r]]], rweight[r]);
+}
+
+__global__ void k_new_twin(const int32_t* __restrict__ rid, const int32_t* __restrict__ cid, int R,
+                           int32_t* __restrict__ twin2) {
+    const int L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L < R && cid[L] >= 0) twin2[cid[L]] = rid[L];
+}
+
+// one (new row node, new column node) key per edge of the level; edges that vanish (unlabelled column, a cluster's
+// edge to its own twin) get the sentinel row R2 and sort behind everything
+__global__ void k_emit_edges(DAdj rows, int R, int E, const int32_t* __restrict__ rlab, const int32_t* __restrict__ clab,
+                             const int32_t* __restrict__ rid, const int32_t* __restrict__ cid,
+                             const int32_t* __restrict__ twin2, int R2, int shift, unsigned long long* __restrict__ keys,
+                             int32_t* __restrict__ vals) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int r = owner_of(rows.ptr, R, e);
+    const int cl = clab[rows.idx[e]];
+    unsigned long long key = (unsigned long long)R2 << shift;
+    if (cl >= 0) {
+        const int n = rid[rlab[r]], cn = cid[cl];
+        if (twin2[cn] != n) key = ((unsigned long long)n << shift) | (unsigned long long)cn;
+    }
+    keys[e] = key;
+    vals[e] = rows.w ? rows.w[e] : 1;
+}
+
+__global__ void k_heads(const unsigned long long* __restrict__ keys, int E, int32_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    if (i == E) flags[i] = 0;
+}
+
+// every run of equal keys becomes one weighted edge (weight clamped to int32 as on the host)
+__global__ void k_run_sums(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
+                           const int32_t* __restrict__ flags, const int32_t* __restrict__ uid, int E, int R2, int shift,
+                           int32_t* __restrict__ n_of, int32_t* __restrict__ idx2, int32_t* __restrict__ w2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E || !flags[i]) return;
+    const unsigned long long key = keys[i];
+    const int n = (int)(key >> shift);
+    if (n >= R2) return;  // the sentinel run
+    long long s = 0;
+    int j = i;
+    do {
+        s += vals[j];
+        ++j;
+    } while (j < E && !flags[j]);
+    const int u = uid[i];
+    n_of[u] = n;
+    idx2[u] = (int)(key & ((1ull << shift) - 1ull));
+    w2[u] = (int32_t)(s < 0x7fffffffLL ? s : 0x7fffffffLL);
+}
+
+// ------------------------------------------------------------------------------------------------ order, copy
+
+__global__ void k_gather_keys(const int32_t* __restrict__ lab, const int32_t* __restrict__ order, int64_t M,
+                              int32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) keys[i] = lab[order[i]];
+}
+
+__global__ void k_perm_degrees(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, int64_t M,
+                               int32_t* __restrict__ deg /* [M + 1] */, int32_t* __restrict__ src_begin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) {
+        const int r = perm[i];
+        const int b = rowptr[r];
+        deg[i] = rowptr[r + 1] - b;
+        src_begin[i] = b;
+    } else if (i == M) {
+        deg[i] = 0;
+    }
+}
+
+__global__ void k_copy_entries(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ src_begin,
+                               const int32_t* __restrict__ colind, int M, int nnz, int32_t* __restrict__ colind_p) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const int lo = owner_of(rowptr_p, M, p);
+    colind_p[p] = colind[src_begin[lo] + (p - rowptr_p[lo])];
+}
+
+// ------------------------------------------------------------------------------------------------ L2 model
+
+struct SliceInfo {
+    int32_t begin[17];  // first modelled CSR position of slice s
+    int32_t end[17];    // one past the last modelled position
+};
+
+__global__ void k_slice_bounds(const int32_t* __restrict__ rowptr, int M, int nnz, int slices, long long cap,
+                               SliceInfo* __restrict__ out) {
+    const int s = threadIdx.x;
+    if (s >= slices) return;
+    // cut s = smallest row count j (>= 1 for s >= 1) with rowptr[j] >= nnz * s / slices (simulate_l2_hits)
+    auto cut = [&](int k) -> int {
+        if (k <= 0) return 0;
+        if (k >= slices) return M;
+        const long long target = (long long)nnz * k / slices;
+        int lo = 1, hi = M;  // first j in [1, M] with rowptr[j] >= target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rowptr[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    const int r0 = cut(s), r1 = cut(s + 1);
+    const int b = rowptr[r0];
+    int e = rowptr[r1];
+    if (cap > 0 && (long long)e - b > cap) {
+        // whole rows until `cap` entries have been seen: first row boundary at or beyond b + cap
+        int lo = r0, hi = r1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)rowptr[mid] - b < cap) lo = mid + 1;
+            else hi = mid;
+        }
+        e = rowptr[lo];
+    }
+    out->begin[s] = b;
+    out->end[s] = e;
+}
+
+__global__ void k_model_keys(const int32_t* __restrict__ colind, const SliceInfo* __restrict__ info, int slices,
+                             int posbits, int64_t total, unsigned long long* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // i-th modelled access overall -> slice, position
+    int64_t off = i;
+    int s = 0;
+    while (s < slices - 1 && off >= info->end[s] - info->begin[s]) {
+        off -= info->end[s] - info->begin[s];
+        ++s;
+    }
+    const int p = info->begin[s] + (int)off;
+    keys[i] = ((unsigned long long)(uint32_t)colind[p] << posbits) | (unsigned long long)p;
+}
+
+// prev[p] = position of the previous access to the same column (any slice; the consumer checks the slice), -1 if none
+__global__ void k_model_prev(const unsigned long long* __restrict__ sorted, int64_t total, int posbits,
+                             int32_t* __restrict__ prev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const unsigned long long k = sorted[i];
+    const unsigned long long mask = (1ull << posbits) - 1ull;
+    const int p = (int)(k & mask);
+    int pv = -1;
+    if (i > 0) {
+        const unsigned long long q = sorted[i - 1];
+        if ((q >> posbits) == (k >> posbits)) pv = (int)(q & mask);
+    }
+    prev[p] = pv;
+}
+
+// One wavefront per sampled access p: hit iff the column was used before in this slice at position a and fewer than
+// `window` DISTINCT columns were used in (a, p) — an access q in between is a first use there iff prev[q] < a.
+__global__ void __launch_bounds__(64) k_model_sample(const int32_t* __restrict__ prev, const SliceInfo* __restrict__ info,
+                                                     int slices, int samples, long long window,
+                                                     int32_t* __restrict__ hits /* [slices] */,
+                                                     int32_t* __restrict__ taken /* [slices] */) {
+    const int s = blockIdx.y;
+    const int k = blockIdx.x;
+    const int b = info->begin[s], e = info->end[s];
+    const long long len = (long long)e - b;
+    if (len <= 0) return;
+    const long long n = len < samples ? len : samples;
+    if (k >= n) return;
+    const int p = b + (int)(((2 * (long long)k + 1) * len) / (2 * n));
+    const int lane = threadIdx.x;
+    const int a = prev[p];
+    int hit = 0;
+    if (a >= b) {
+        if ((long long)p - a - 1 < window) hit = 1;  // fewer accesses than the window holds
+        else {
+            long long distinct = 0;
+            hit = 1;
+            for (int q = a + 1 + lane; q - lane < p; q += 64) {
+                const int first = (q < p) && (prev[q] < a);
+                distinct += __popcll(__ballot(first));
+                if (distinct >= window) {
+                    hit = 0;
+                    break;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&taken[s], 1);
+        if (hit) atomicAdd(&hits[s], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ task cutting
+
+constexpr int kCutBlock = 4096;  // rows per block of the parallel greedy cut
+
+__global__ void k_row_costs(const int32_t* __restrict__ rp, int64_t M, long long row_floor, long long* __restrict__ cost) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) {
+        const long long d = rp[i + 1] - rp[i];
+        cost[i] = d > row_floor ? d : row_floor;
+    } else if (i == M) {
+        cost[i] = 0;
+    }
+}
+
+// next[i] = row after the last row of the task that starts at row i
+__global__ void k_task_next(const long long* __restrict__ P /* exclusive prefix of the costs, [M + 1] */, int64_t M,
+                            long long budget, int32_t* __restrict__ next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    int64_t hi = i + kMaxRowsPerWave < M ? i + kMaxRowsPerWave : M;
+    int64_t j = i + 1;
+    // largest j in [i + 1, hi] with P[j] - P[i] <= budget (P is non-decreasing)
+    int64_t lo = i + 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (P[mid] - P[i] <= budget) lo = mid;
+        else hi = mid - 1;
+    }
+    j = lo;
+    next[i] = (int32_t)j;
+}
+
+// A chain enters a block within its first kMaxRowsPerWave rows (a task never has more rows): exit row of the chain
+// for each of those entry points.
+__global__ void __launch_bounds__(64) k_task_exits(const int32_t* __restrict__ next, int64_t M,
+                                                   int32_t* __restrict__ exits /* [nblk][kMaxRowsPerWave] */) {
+    const int64_t b0 = (int64_t)blockIdx.x * kCutBlock;
+    const int64_t b1 = b0 + kCutBlock < M ? b0 + kCutBlock : M;
+    const int t = threadIdx.x;
+    if (t >= kMaxRowsPerWave) return;
+    int64_t cur = b0 + t;
+    if (cur >= b1) {
+        exits[(int64_t)blockIdx.x * kMaxRowsPerWave + t] = (int32_t)cur;
+        return;
+    }
+    while (cur < b1) cur = next[cur];
+    exits[(int64_t)blockIdx.x * kMaxRowsPerWave + t] = (int32_t)cur;
+}
+
+__global__ void k_task_entries(const int32_t* __restrict__ exits, int64_t nblk, int32_t* __restrict__ entry) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t cur = 0;
+    for (int64_t b = 0; b < nblk; ++b) {
+        entry[b] = (int32_t)cur;  // first task start inside block b (always within its first kMaxRowsPerWave rows)
+        cur = exits[b * kMaxRowsPerWave + (cur - b * kCutBlock)];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_task_mark(const int32_t* __restrict__ next, const int32_t* __restrict__ entry,
+                                                  int64_t M, int32_t* __restrict__ flags /* zeroed, [M + 1] */) {
+    if (threadIdx.x != 0) return;
+    const int64_t b0 = (int64_t)blockIdx.x * kCutBlock;
+    const int64_t b1 = b0 + kCutBlock < M ? b0 + kCutBlock : M;
+    int64_t cur = entry[blockIdx.x];
+    while (cur < b1) {
+        flags[cur] = 1;
+        cur = next[cur];
+    }
+}
+
+__global__ void k_task_write(const int32_t* __restrict__ flags, const int32_t* __restrict__ tid_of,
+                             const int32_t* __restrict__ next, const int32_t* __restrict__ rp, int64_t M,
+                             int32_t* __restrict__ tasks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M || !flags[i]) return;
+    const int j = next[i];
+    int4 t;
+    t.x = (int)i;
+    t.y = j - (int)i;
+    t.z = rp[i];
+    t.w = rp[j];
+    reinterpret_cast<int4*>(tasks)[tid_of[i]] = t;
+}
+
+// ------------------------------------------------------------------------------------------------ host-side glue
+
+template <typename T>
+hipError_t exclusive_scan(Scratch& sc, const T* in, T* out, int64_t n, hipStream_t st) {
+    size_t bytes = 0;
+    GESPMM_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), (size_t)n, rocprim::plus<T>(), st));
+    char* tmp = nullptr;
+    GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
+    GESPMM_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, T(0), (size_t)n, rocprim::plus<T>(), st));
+    sc.release(tmp);
+    return hipSuccess;
+}
+
+template <typename KeyT>
+hipError_t sort_pairs(Scratch& sc, const KeyT* kin, KeyT* kout, const int32_t* vin, int32_t* vout, int64_t n, int bits,
+                      hipStream_t st) {
+    size_t bytes = 0;
+    GESPMM_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
+    char* tmp = nullptr;
+    GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
+    GESPMM_TRY(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
+    sc.release(tmp);
+    return hipSuccess;
+}
+
+hipError_t sort_keys64(Scratch& sc, const unsigned long long* kin, unsigned long long* kout, int64_t n, int bits,
+                       hipStream_t st) {
+    size_t bytes = 0;
+    GESPMM_TRY(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
+    char* tmp = nullptr;
+    GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
+    GESPMM_TRY(rocprim::radix_sort_keys(tmp, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
+    sc.release(tmp);
+    return hipSuccess;
+}
+
+template <typename T>
+hipError_t fetch(T* host, const T* dev, int64_t count, hipStream_t st) {
+    GESPMM_TRY(hipMemcpyAsync(host, dev, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, st));
+    return hipStreamSynchronize(st);
+}
+
+struct DLevel {
+    int32_t R = 0, C = 0;
+    int64_t E = 0;
+    DAdj rows, cols;
+    const int32_t* rweight = nullptr;
+    const int32_t* twin = nullptr;  // nullptr at level 0
+    std::vector<void*> owned;       // buffers of this level (released when the next level replaces it)
+};
+
+// transposed adjacency: stable sort of the entries by column node keeps the row nodes ascending inside a column
+hipError_t build_cols(Scratch& sc, DLevel& lv, const int32_t* n_of /* nullptr: rows.ptr decides (level 0) */,
+                      hipStream_t st) {
+    const int64_t E = lv.E;
+    int32_t *iota = nullptr, *keys_out = nullptr, *order = nullptr, *cidx = nullptr, *cw = nullptr, *cptr = nullptr;
+    GESPMM_TRY(sc.get(&iota, E));
+    GESPMM_TRY(sc.get(&keys_out, E));
+    GESPMM_TRY(sc.get(&order, E));
+    GESPMM_TRY(sc.get(&cidx, E));
+    GESPMM_TRY(sc.get(&cptr, (int64_t)lv.C + 1));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(E)), dim3(256), 0, st, iota, E);
+    GESPMM_TRY(sort_pairs<int32_t>(sc, lv.rows.idx, keys_out, iota, order, E, bits_for(lv.C), st));
+    if (n_of) {
+        GESPMM_TRY(sc.get(&cw, E));
+        hipLaunchKernelGGL(k_gather2, dim3(grid_for(E)), dim3(256), 0, st, n_of, lv.rows.w, order, (int)E, cidx, cw);
+    } else {
+        hipLaunchKernelGGL(k_gather_rows_of, dim3(grid_for(E)), dim3(256), 0, st, lv.rows.ptr, lv.R, order, (int)E, cidx);
+    }
+    hipLaunchKernelGGL(k_lower_bound_ptr, dim3(grid_for((int64_t)lv.C + 1)), dim3(256), 0, st, keys_out, (int)E, lv.C,
+                       cptr);
+    GESPMM_TRY(hipGetLastError());
+    sc.release(iota);
+    sc.release(keys_out);
+    sc.release(order);
+    lv.cols.ptr = cptr;
+    lv.cols.idx = cidx;
+    lv.cols.w = cw;
+    lv.owned.push_back(cptr);
+    lv.owned.push_back(cidx);
+    if (cw) lv.owned.push_back(cw);
+    return hipSuccess;
+}
+
+template <bool ROWS>
+hipError_t launch_half_sweep(const LpArgs& base, const int32_t* lists, const int32_t* counts_dev,
+                             const int32_t* counts_host, int n_side, unsigned long long* acc, int acc_wgs,
+                             int64_t nlabels, hipStream_t st) {
+    LpArgs a = base;
+    for (int b = 0; b < kBins; ++b) {
+        const int cnt = counts_host[b];
+        if (cnt == 0) continue;
+        a.list = lists + (int64_t)b * n_side;
+        a.count = counts_dev + b;
+        if (b == 0) hipLaunchKernelGGL((k_lp_small<8, ROWS>), dim3(grid_for((int64_t)cnt * 8)), dim3(256), 0, st, a);
+        else if (b == 1) hipLaunchKernelGGL((k_lp_small<64, ROWS>), dim3(grid_for((int64_t)cnt * 64)), dim3(256), 0, st, a);
+        else if (b == 2) hipLaunchKernelGGL((k_lp_wave<ROWS>), dim3((unsigned)cnt), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_lp_dense<ROWS>), dim3((unsigned)std::min(cnt, acc_wgs)), dim3(256), 0, st, a, acc, nlabels);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// ====================================================================================================================
+
+hipError_t device_validate_csr(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
+                               int32_t* max_degree_host, int32_t* bad_host, hipStream_t st) {
+    Scratch sc(st);
+    int32_t* out = nullptr;
+    GESPMM_TRY(sc.get(&out, 2));
+    GESPMM_TRY(hipMemsetAsync(out, 0, 8, st));
+    const int64_t n = std::max<int64_t>(M, nnz);
+    if (n > 0) hipLaunchKernelGGL(k_validate, dim3(grid_for(n)), dim3(256), 0, st, rowptr, colind, M, K, nnz, out);
+    GESPMM_TRY(hipGetLastError());
+    int32_t h[2] = {0, 0};
+    GESPMM_TRY(fetch(h, out, 2, st));
+    *bad_host = h[0];
+    *max_degree_host = h[1];
+    return hipSuccess;
+}
+
+hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr, const int32_t* colind,
+                               const ClusterOptions& opt, int32_t* perm, ClusterStats* stats, hipStream_t st) {
+    if (stats) *stats = ClusterStats{};
+    if (M <= 0) return hipSuccess;
+    Scratch sc(st);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
+    GESPMM_TRY(hipGetLastError());
+    if (nnz <= 0) return hipSuccess;
+
+    auto release_level = [&](DLevel& l) {
+        for (void* p : l.owned) sc.release(p);
+        l.owned.clear();
+    };
+
+    // ---- level 0: the matrix itself (rows = the caller's CSR), its transpose, unit weights
+    DLevel lv;
+    lv.R = (int32_t)M;
+    lv.C = (int32_t)K;
+    lv.E = nnz;
+    lv.rows.ptr = rowptr;
+    lv.rows.idx = colind;
+    GESPMM_TRY(build_cols(sc, lv, nullptr, st));
+    {
+        int32_t* rw = nullptr;
+        GESPMM_TRY(sc.get(&rw, M));
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(M)), dim3(256), 0, st, rw, M, 1);
+        lv.rweight = rw;
+        lv.owned.push_back(rw);
+    }
+    int32_t* node_of_row = nullptr;
+    GESPMM_TRY(sc.get(&node_of_row, M));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, node_of_row, M);
+    std::vector<int32_t*> level_labels;
+    std::vector<int32_t> level_count;
+
+    int32_t* flags_dev = nullptr;  // {done, changed, counts_rows[4], counts_cols[4]}
+    GESPMM_TRY(sc.get(&flags_dev, 16));
+
+    long long cap = opt.first_cap > 0 ? opt.first_cap : 256;
+    const int max_levels = opt.max_levels > 0 ? opt.max_levels : 10;
+    const int sweeps = opt.sweeps > 0 ? opt.sweeps : 5;
+
+    for (int level = 0; level < max_levels; ++level) {
+        const int32_t R = lv.R, C = lv.C;
+        if (R <= 1 || lv.E == 0) break;
+        int32_t *rlab = nullptr, *clab = nullptr, *rnext = nullptr, *cnext = nullptr, *size = nullptr, *rlists = nullptr,
+                *clists = nullptr;
+        GESPMM_TRY(sc.get(&rlab, R));
+        GESPMM_TRY(sc.get(&rnext, R));
+        GESPMM_TRY(sc.get(&clab, C));
+        GESPMM_TRY(sc.get(&cnext, C));
+        GESPMM_TRY(sc.get(&size, R));
+        GESPMM_TRY(sc.get(&rlists, (int64_t)kBins * R));
+        GESPMM_TRY(sc.get(&clists, (int64_t)kBins * C));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(R)), dim3(256), 0, st, rlab, (int64_t)R);
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(C)), dim3(256), 0, st, clab, (int64_t)C, -1);
+        GESPMM_TRY(hipMemsetAsync(flags_dev, 0, 16 * 4, st));
+        int32_t* done = flags_dev;
+        int32_t* changed = flags_dev + 1;
+        int32_t* rcounts = flags_dev + 4;
+        int32_t* ccounts = flags_dev + 8;
+        hipLaunchKernelGGL(k_bin_nodes, dim3(grid_for(R)), dim3(256), 0, st, lv.rows.ptr, (const int32_t*)nullptr, R, rlists,
+                           rcounts);
+        hipLaunchKernelGGL(k_bin_nodes, dim3(grid_for(C)), dim3(256), 0, st, lv.cols.ptr, lv.twin, C, clists, ccounts);
+        GESPMM_TRY(hipGetLastError());
+        int32_t h_counts[8];
+        GESPMM_TRY(fetch(h_counts, (const int32_t*)(flags_dev + 4), 8, st));
+        // dense accumulators of the > 2048-entry class (label space = the row labels of this level)
+        unsigned long long* acc = nullptr;
+        int acc_wgs = 0;
+        if (h_counts[3] > 0 || h_counts[7] > 0) {
+            const int want = std::max(h_counts[3], h_counts[7]);
+            int64_t wgs = std::min<int64_t>(want, 64);
+            while (wgs > 1 && wgs * (int64_t)R * 8 > (1ll << 30)) wgs >>= 1;
+            acc_wgs = (int)wgs;
+            GESPMM_TRY(sc.get(&acc, (int64_t)acc_wgs * R));
+            GESPMM_TRY(hipMemsetAsync(acc, 0, (size_t)acc_wgs * (size_t)R * 8, st));
+        }
+        const bool twins = lv.twin != nullptr;
+        for (int sweep = 0; sweep < sweeps; ++sweep) {
+            LpArgs a;
+            a.seed = 0x9e3779b9u * (uint32_t)(level * 16 + sweep + 1);
+            a.done = done;
+            a.cap = cap;
+            // columns <- heaviest row label
+            a.adj = lv.cols;
+            a.nbr_label = rlab;
+            a.cur = clab;
+            a.next = cnext;
+            a.size = nullptr;
+            a.rweight = nullptr;
+            a.skip_half = 0;
+            a.list = nullptr;
+            a.count = nullptr;
+            hipLaunchKernelGGL(k_lp_default, dim3(grid_for(C)), dim3(256), 0, st, (const int32_t*)clab, lv.twin,
+                               (const int32_t*)rlab, C, cnext, (const int32_t*)done);
+            GESPMM_TRY(launch_half_sweep<false>(a, clists, ccounts, h_counts + 4, C, acc, acc_wgs, R, st));
+            hipLaunchKernelGGL(k_commit, dim3(grid_for(C)), dim3(256), 0, st, clab, (const int32_t*)cnext, C,
+                               (int32_t*)nullptr, (const int32_t*)done);
+            // rows <- heaviest column label, within the size cap (sizes: snapshot at the start of the half-sweep)
+            hipLaunchKernelGGL(k_zero_if_running, dim3(grid_for(R)), dim3(256), 0, st, size, R, (const int32_t*)done);
+            hipLaunchKernelGGL(k_sizes, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab, lv.rweight, R, size,
+                               (const int32_t*)done);
+            a.adj = lv.rows;
+            a.nbr_label = clab;
+            a.cur = rlab;
+            a.next = rnext;
+            a.size = size;
+            a.rweight = lv.rweight;
+            a.skip_half = (twins && sweep + 1 < sweeps) ? 1 : 0;
+            hipLaunchKernelGGL(k_lp_default, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab,
+                               (const int32_t*)nullptr, (const int32_t*)nullptr, R, rnext, (const int32_t*)done);
+            GESPMM_TRY(launch_half_sweep<true>(a, rlists, rcounts, h_counts, R, acc, acc_wgs, R, st));
+            hipLaunchKernelGGL(k_commit, dim3(grid_for(R)), dim3(256), 0, st, rlab, (const int32_t*)rnext, R, changed,
+                               (const int32_t*)done);
+            hipLaunchKernelGGL(k_check_done, dim3(1), dim3(1), 0, st, changed, R, done);
+            GESPMM_TRY(hipGetLastError());
+        }
+        sc.release(rnext);
+        sc.release(cnext);
+        sc.release(size);
+        sc.release(rlists);
+        sc.release(clists);
+        if (acc) sc.release(acc);
+
+        // ---- contract: compact row labels -> new row nodes, column labels -> new column nodes
+        int32_t *used = nullptr, *pos = nullptr, *rid = nullptr, *cid = nullptr;
+        const int64_t R1 = (int64_t)R + 1;
+        GESPMM_TRY(sc.get(&used, 2 * R1));
+        GESPMM_TRY(sc.get(&pos, 2 * R1));
+        GESPMM_TRY(sc.get(&rid, R));
+        GESPMM_TRY(sc.get(&cid, R));
+        GESPMM_TRY(hipMemsetAsync(used, 0, (size_t)(2 * R1) * 4, st));
+        hipLaunchKernelGGL(k_mark_used, dim3(grid_for(std::max(R, C))), dim3(256), 0, st, (const int32_t*)rlab, R,
+                           (const int32_t*)clab, C, used, used + R1);
+        GESPMM_TRY(exclusive_scan<int32_t>(sc, used, pos, R1, st));
+        GESPMM_TRY(exclusive_scan<int32_t>(sc, used + R1, pos + R1, R1, st));
+        hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)used, (const int32_t*)pos, R, rid);
+        hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)(used + R1),
+                           (const int32_t*)(pos + R1), R, cid);
+        int32_t* lab = nullptr;
+        GESPMM_TRY(sc.get(&lab, M));
+        hipLaunchKernelGGL(k_relabel, dim3(grid_for(M)), dim3(256), 0, st, node_of_row, (const int32_t*)rlab,
+                           (const int32_t*)rid, M, lab);
+        GESPMM_TRY(hipGetLastError());
+        int32_t R2 = 0, C2 = 0;
+        GESPMM_TRY(fetch(&R2, (const int32_t*)(pos + R), 1, st));
+        GESPMM_TRY(fetch(&C2, (const int32_t*)(pos + R1 + R), 1, st));
+        sc.release(used);
+        sc.release(pos);
+        level_labels.push_back(lab);
+        level_count.push_back(R2);
+        if (stats) {
+            stats->levels = level + 1;
+            if (level < 16) stats->clusters[level] = R2;
+        }
+        const bool last = (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * 97 || level + 1 >= max_levels);
+        if (last) {
+            sc.release(rlab);
+            sc.release(clab);
+            sc.release(rid);
+            sc.release(cid);
+            break;
+        }
+
+        // ---- the next level: members' weights, twins, merged adjacency over the new column nodes
+        DLevel nx;
+        nx.R = R2;
+        nx.C = C2;
+        int32_t *rw2 = nullptr, *twin2 = nullptr;
+        GESPMM_TRY(sc.get(&rw2, R2));
+        GESPMM_TRY(sc.get(&twin2, C2));
+        GESPMM_TRY(hipMemsetAsync(rw2, 0, (size_t)R2 * 4, st));
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(C2)), dim3(256), 0, st, twin2, (int64_t)C2, -1);
+        hipLaunchKernelGGL(k_new_weights, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab, (const int32_t*)rid,
+                           lv.rweight, R, rw2);
+        hipLaunchKernelGGL(k_new_twin, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rid, (const int32_t*)cid, R, twin2);
+        nx.rweight = rw2;
+        nx.twin = twin2;
+        nx.owned.push_back(rw2);
+        nx.owned.push_back(twin2);
+        const int64_t E = lv.E;
+        const int shift = bits_for(C2);
+        unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+        int32_t *vals = nullptr, *vals_sorted = nullptr, *hflags = nullptr, *uid = nullptr;
+        GESPMM_TRY(sc.get(&keys, E));
+        GESPMM_TRY(sc.get(&keys_sorted, E));
+        GESPMM_TRY(sc.get(&vals, E));
+        GESPMM_TRY(sc.get(&vals_sorted, E));
+        hipLaunchKernelGGL(k_emit_edges, dim3(grid_for(E)), dim3(256), 0, st, lv.rows, R, (int)E, (const int32_t*)rlab,
+                           (const int32_t*)clab, (const int32_t*)rid, (const int32_t*)cid, (const int32_t*)twin2, R2, shift,
+                           keys, vals);
+        GESPMM_TRY(hipGetLastError());
+        GESPMM_TRY(sort_pairs<unsigned long long>(sc, keys, keys_sorted, vals, vals_sorted, E,
+                                                  shift + bits_for((int64_t)R2 + 1), st));
+        sc.release(keys);
+        sc.release(vals);
+        sc.release(rlab);
+        sc.release(clab);
+        sc.release(rid);
+        sc.release(cid);
+        GESPMM_TRY(sc.get(&hflags, E + 1));
+        GESPMM_TRY(sc.get(&uid, E + 1));
+        hipLaunchKernelGGL(k_heads, dim3(grid_for(E + 1)), dim3(256), 0, st, (const unsigned long long*)keys_sorted, (int)E,
+                           hflags);
+        GESPMM_TRY(exclusive_scan<int32_t>(sc, hflags, uid, E + 1, st));
+        int32_t U = 0;
+        unsigned long long last_key = 0;
+        GESPMM_TRY(fetch(&U, (const int32_t*)(uid + E), 1, st));
+        GESPMM_TRY(fetch(&last_key, (const unsigned long long*)(keys_sorted + (E - 1)), 1, st));
+        const int64_t E2 = ((int64_t)(last_key >> shift) >= R2) ? U - 1 : U;
+        int32_t *n_of = nullptr, *idx2 = nullptr, *w2 = nullptr, *ptr2 = nullptr;
+        GESPMM_TRY(sc.get(&n_of, E2));
+        GESPMM_TRY(sc.get(&idx2, E2));
+        GESPMM_TRY(sc.get(&w2, E2));
+        GESPMM_TRY(sc.get(&ptr2, (int64_t)R2 + 1));
+        hipLaunchKernelGGL(k_run_sums, dim3(grid_for(E)), dim3(256), 0, st, (const unsigned long long*)keys_sorted,
+                           (const int32_t*)vals_sorted, (const int32_t*)hflags, (const int32_t*)uid, (int)E, R2, shift, n_of,
+                           idx2, w2);
+        hipLaunchKernelGGL(k_lower_bound_ptr, dim3(grid_for((int64_t)R2 + 1)), dim3(256), 0, st, (const int32_t*)n_of,
+                           (int)E2, R2, ptr2);
+        GESPMM_TRY(hipGetLastError());
+        sc.release(keys_sorted);
+        sc.release(vals_sorted);
+        sc.release(hflags);
+        sc.release(uid);
+        nx.E = E2;
+        nx.rows.ptr = ptr2;
+        nx.rows.idx = idx2;
+        nx.rows.w = w2;
+        nx.owned.push_back(ptr2);
+        nx.owned.push_back(idx2);
+        nx.owned.push_back(w2);
+        if (E2 > 0) GESPMM_TRY(build_cols(sc, nx, n_of, st));
+        sc.release(n_of);
+        release_level(lv);
+        lv = nx;
+        cap *= opt.cap_growth > 1 ? opt.cap_growth : 4;
+    }
+    release_level(lv);
+
+    // ---- order: stable sorts by the labels of each level, finest first = lexicographic by
+    //      (coarsest label, ..., finest label, original row id)
+    if (!level_labels.empty()) {
+        int32_t *keys = nullptr, *keys_out = nullptr, *order = nullptr, *order_out = nullptr;
+        GESPMM_TRY(sc.get(&keys, M));
+        GESPMM_TRY(sc.get(&keys_out, M));
+        GESPMM_TRY(sc.get(&order, M));
+        GESPMM_TRY(sc.get(&order_out, M));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, order, M);
+        for (size_t l = 0; l < level_labels.size(); ++l) {
+            hipLaunchKernelGGL(k_gather_keys, dim3(grid_for(M)), dim3(256), 0, st, (const int32_t*)level_labels[l],
+                               (const int32_t*)order, M, keys);
+            GESPMM_TRY(sort_pairs<int32_t>(sc, keys, keys_out, order, order_out, M, bits_for(level_count[l]), st));
+            std::swap(order, order_out);
+        }
+        GESPMM_TRY(hipMemcpyAsync(perm, order, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
+    }
+    GESPMM_TRY(hipGetLastError());
+    return hipStreamSynchronize(st);  // the scratch goes back to the pool in stream order; callers may read perm now
+}
+
+hipError_t device_permute_csr(int64_t M, int64_t nnz, const int32_t* rowptr, const int32_t* colind, const int32_t* perm,
+                              int32_t* rowptr_p, int32_t* colind_p, int32_t* src_begin, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    Scratch sc(st);
+    int32_t* deg = nullptr;
+    GESPMM_TRY(sc.get(&deg, M + 1));
+    hipLaunchKernelGGL(k_perm_degrees, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr, perm, M, deg, src_begin);
+    GESPMM_TRY(exclusive_scan<int32_t>(sc, deg, rowptr_p, M + 1, st));
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_copy_entries, dim3(grid_for(nnz)), dim3(256), 0, st, (const int32_t*)rowptr_p,
+                           (const int32_t*)src_begin, colind, (int)M, (int)nnz, colind_p);
+    return hipGetLastError();
+}
+
+hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr, const int32_t* colind, int slices,
+                           int64_t window, int64_t max_entries_per_slice, int samples_per_slice, double* hits_host,
+                           hipStream_t st) {
+    *hits_host = 0.0;
+    if (M <= 0 || K <= 0 || nnz <= 0 || slices < 1 || slices > 16 || window < 1) return hipSuccess;
+    Scratch sc(st);
+    SliceInfo* info = nullptr;
+    GESPMM_TRY(sc.get(&info, 1));
+    hipLaunchKernelGGL(k_slice_bounds, dim3(1), dim3(64), 0, st, rowptr, (int)M, (int)nnz, slices,
+                       (long long)max_entries_per_slice, info);
+    SliceInfo h;
+    GESPMM_TRY(fetch(&h, (const SliceInfo*)info, 1, st));
+    int64_t total = 0;
+    for (int s = 0; s < slices; ++s) total += h.end[s] - h.begin[s];
+    if (total <= 0) return hipSuccess;
+    const int posbits = bits_for(nnz);
+    unsigned long long *keys = nullptr, *sorted = nullptr;
+    int32_t *prev = nullptr, *cnt = nullptr;
+    GESPMM_TRY(sc.get(&keys, total));
+    GESPMM_TRY(sc.get(&sorted, total));
+    GESPMM_TRY(sc.get(&prev, nnz));
+    GESPMM_TRY(sc.get(&cnt, 32));
+    GESPMM_TRY(hipMemsetAsync(cnt, 0, 32 * 4, st));
+    hipLaunchKernelGGL(k_model_keys, dim3(grid_for(total)), dim3(256), 0, st, colind, (const SliceInfo*)info, slices,
+                       posbits, total, keys);
+    GESPMM_TRY(sort_keys64(sc, keys, sorted, total, posbits + bits_for(K), st));
+    hipLaunchKernelGGL(k_model_prev, dim3(grid_for(total)), dim3(256), 0, st, (const unsigned long long*)sorted, total,
+                       posbits, prev);
+    hipLaunchKernelGGL(k_model_sample, dim3((unsigned)samples_per_slice, (unsigned)slices), dim3(64), 0, st,
+                       (const int32_t*)prev, (const SliceInfo*)info, slices, samples_per_slice, (long long)window, cnt,
+                       cnt + 16);
+    GESPMM_TRY(hipGetLastError());
+    int32_t hc[32];
+    GESPMM_TRY(fetch(hc, (const int32_t*)cnt, 32, st));
+    double hits = 0.0;
+    for (int s = 0; s < slices; ++s)
+        if (hc[16 + s] > 0) hits += (double)hc[s] / (double)hc[16 + s] * (double)(h.end[s] - h.begin[s]);
+    *hits_host = hits / (double)total;
+    return hipSuccess;
+}
+
+hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, int64_t budget, int64_t row_floor, int32_t** tasks,
+                            int32_t* ntasks_host, hipStream_t st) {
+    *tasks = nullptr;
+    *ntasks_host = 0;
+    if (M <= 0) return hipSuccess;
+    Scratch sc(st);
+    long long *cost = nullptr, *P = nullptr;
+    int32_t *next = nullptr, *exits = nullptr, *entry = nullptr, *flags = nullptr, *tid_of = nullptr;
+    const int64_t nblk = (M + kCutBlock - 1) / kCutBlock;
+    GESPMM_TRY(sc.get(&cost, M + 1));
+    GESPMM_TRY(sc.get(&P, M + 1));
+    GESPMM_TRY(sc.get(&next, M));
+    GESPMM_TRY(sc.get(&exits, nblk * kMaxRowsPerWave));
+    GESPMM_TRY(sc.get(&entry, nblk));
+    GESPMM_TRY(sc.get(&flags, M + 1));
+    GESPMM_TRY(sc.get(&tid_of, M + 1));
+    hipLaunchKernelGGL(k_row_costs, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr_p, M, (long long)row_floor, cost);
+    GESPMM_TRY(exclusive_scan<long long>(sc, cost, P, M + 1, st));
+    hipLaunchKernelGGL(k_task_next, dim3(grid_for(M)), dim3(256), 0, st, (const long long*)P, M, (long long)budget, next);
+    hipLaunchKernelGGL(k_task_exits, dim3((unsigned)nblk), dim3(64), 0, st, (const int32_t*)next, M, exits);
+    hipLaunchKernelGGL(k_task_entries, dim3(1), dim3(64), 0, st, (const int32_t*)exits, nblk, entry);
+    GESPMM_TRY(hipMemsetAsync(flags, 0, (size_t)(M + 1) * 4, st));
+    hipLaunchKernelGGL(k_task_mark, dim3((unsigned)nblk), dim3(64), 0, st, (const int32_t*)next, (const int32_t*)entry, M,
+                       flags);
+    GESPMM_TRY(exclusive_scan<int32_t>(sc, flags, tid_of, M + 1, st));
+    int32_t nt = 0;
+    GESPMM_TRY(fetch(&nt, (const int32_t*)(tid_of + M), 1, st));
+    int32_t* out = nullptr;
+    GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)(nt > 0 ? nt : 1) * 16));
+    hipLaunchKernelGGL(k_task_write, dim3(grid_for(M)), dim3(256), 0, st, (const int32_t*)flags, (const int32_t*)tid_of,
+                       (const int32_t*)next, rowptr_p, M, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(out);
+        return e;
+    }
+    *tasks = out;
+    *ntasks_host = nt;
+    return hipSuccess;
+}
+
+}  // namespace gespmm

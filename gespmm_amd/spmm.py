@@ -82,8 +82,9 @@ def _make_cfg(cfg):
 
 class SpmmPlan:
     """The analysis stage for ONE sparse matrix at one feature width (``gespmm_plan_*`` of the C ABI — what the
-    vendor libraries call preprocess; the reference has none). Creating a plan reads the matrix on the host once
-    (one synchronisation) and keeps what every later launch reuses: the long-row decision from the longest row it
+    vendor libraries call preprocess; the reference has none). Creating a plan analyses the matrix once, on the
+    device (``analysis="host"`` keeps the round-2 host form: same order, ~20x slower), and keeps what every later
+    launch reuses: the long-row decision from the longest row it
     saw, the split points of the cache-blocked path (dense graphs), and — for sparse graphs whose B exceeds the
     L2s — a row-CLUSTERED copy of the matrix with an nnz-balanced task table, so rows that share neighbours run
     next to each other and find the shared B rows in L2. Only the processing order changes: the result has the
@@ -98,7 +99,7 @@ class SpmmPlan:
     """
 
     def __init__(self, rowptr, colind, K, N, variant=_lib.VARIANT_AUTO, values=None, reorder="auto", task_entries=0,
-                 threads=0, flags=0, row_floor=0, kernel="auto"):
+                 threads=0, flags=0, row_floor=0, kernel="auto", analysis="device"):
         _need(rowptr, "rowptr", torch.int32, 1)
         _need(colind, "colind", torch.int32, 1)
         if values is not None:
@@ -115,7 +116,8 @@ class SpmmPlan:
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
         kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "lds-rows": _lib.PLAN_KERNEL_LDS_ROWS,
                 "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM, "task-outer": _lib.PLAN_KERNEL_OUTER}[kernel]
-        opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern)
+        where = {"device": _lib.PLAN_ANALYSIS_DEVICE, "host": _lib.PLAN_ANALYSIS_HOST}[analysis]
+        opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where)
         self._handle = ctypes.c_void_p()
         M, K_, N_, nnz, var = self.shape
         with _on_device(dev):
@@ -158,11 +160,13 @@ class SpmmPlan:
             raise ValueError("rowptr/colind were modified in place after the plan was made: create a new SpmmPlan")
         if values is None:
             if self._values is not None:
-                check(lib.gespmm_plan_set_values(self._handle, None, _stream(self.device)), "gespmm_plan_set_values")
+                with _on_device(self.device):
+                    check(lib.gespmm_plan_set_values(self._handle, None, _stream(self.device)), "gespmm_plan_set_values")
                 self._values, self._values_version = None, None
         elif self._values is None or values.data_ptr() != self._values.data_ptr() or \
                 values._version != self._values_version:
-            check(lib.gespmm_plan_set_values(self._handle, _ptr(values), _stream(self.device)), "gespmm_plan_set_values")
+            with _on_device(self.device):
+                check(lib.gespmm_plan_set_values(self._handle, _ptr(values), _stream(self.device)), "gespmm_plan_set_values")
             self._values, self._values_version = values, values._version
 
     def run(self, values, dense, out=None, reduce_max=None):

@@ -250,7 +250,8 @@ int gespmm_csr2csc_f32(const int32_t* rowptr, const int32_t* colind, const float
  * Repeated products with ONE sparse matrix (200 timed launches in spmm_test.cu:754-762; every layer of every
  * epoch in gcn_custom.py:118-143) can be prepared once. The reference has no such stage — its kernels walk the
  * rows in storage order on every launch; vendor SpMMs have one (rocsparse_spmm_stage_preprocess). A plan
- *   - reads the matrix on the HOST once (gespmm_plan_create synchronises `stream`),
+ *   - reads the matrix ONCE, on the device (validation, clustering, L2 model, task cutting are device passes;
+ *     gespmm_plan_create synchronises `stream` a handful of times; GESPMM_PLAN_ANALYSIS_HOST keeps the host form),
  *   - decides the long-row pass from the longest row it actually saw,
  *   - keeps the scratch of the cache-blocked path (dense graphs) so its split scan runs once,
  *   - and, for sparse graphs whose B exceeds the L2s, keeps a ROW-CLUSTERED copy of the matrix plus a task
@@ -279,7 +280,11 @@ typedef struct gespmm_plan_options {
     int32_t threads;       /* host threads for the clustering, 0 = all (the result does not depend on it) */
     int32_t flags;         /* GESPMM_FLAG_* applied to every launch (e.g. GESPMM_FLAG_STRICT_ORDER) */
     int32_t kernel;        /* GESPMM_PLAN_KERNEL_*: which kernel a clustered plan launches */
+    int32_t analysis;      /* GESPMM_PLAN_ANALYSIS_*: where the clustering / L2 model / task cutting run */
 } gespmm_plan_options;
+
+#define GESPMM_PLAN_ANALYSIS_DEVICE 0  /* on the device (default): no copy of the matrix leaves HBM */
+#define GESPMM_PLAN_ANALYSIS_HOST   1  /* round-2 path: the matrix is copied to the host and clustered there (same order) */
 
 #define GESPMM_PLAN_KERNEL_AUTO     0  /* batch-stream kernel on the task table; segmented-stream for products-shaped rows */
 #define GESPMM_PLAN_KERNEL_STREAM   1  /* batch-stream kernel on the task table */
@@ -321,6 +326,20 @@ int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M,
  */
 double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                int32_t slices, int64_t window_rows);
+
+/*
+ * The device analysis passes by themselves (what gespmm_plan_create runs; DEVICE rowptr / colind, HOST outputs):
+ * gespmm_device_cluster_rows gives the SAME order as gespmm_cluster_rows (the rules are identical and every sum is an
+ * integer sum); gespmm_device_l2_model estimates what gespmm_simulate_l2_hits simulates (exact LRU stack distances of
+ * `samples_per_slice` stratified accesses per slice; max_entries_per_slice > 0 models only the head of every slice).
+ */
+int gespmm_device_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
+                               int32_t* perm_out_host, int32_t* levels_out, int32_t* clusters_out, void* stream);
+double gespmm_device_l2_model(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
+                              const int32_t* perm_host, int32_t slices, int64_t window_rows, int64_t max_entries_per_slice,
+                              int32_t samples_per_slice, void* stream);
+/* Test hook: task table of a clustered plan (which = 0 wavefront tasks, 1 lane-group tasks), int4 records, HOST memory. */
+int gespmm_plan_debug_tasks(const gespmm_plan* plan, int32_t which, int32_t* out_host, int64_t capacity);
 
 /*
  * Test hook (HOST pointers, no device): the task records a clustered plan cuts for its LDS-staged-rows kernel
