@@ -382,6 +382,16 @@ void build_outer_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, c
     }
 }
 
+// Experiment knobs (scripts/plan_time.py): GESPMM_CLUSTER_LEVELS / _SWEEPS / _STOP / _CAP override the clustering defaults.
+gespmm::ClusterOptions cluster_options_from_env() {
+    gespmm::ClusterOptions o;
+    if (const char* v = getenv("GESPMM_CLUSTER_LEVELS")) o.max_levels = atoi(v);
+    if (const char* v = getenv("GESPMM_CLUSTER_SWEEPS")) o.sweeps = atoi(v);
+    if (const char* v = getenv("GESPMM_CLUSTER_STOP")) o.stop_percent = atoi(v);
+    if (const char* v = getenv("GESPMM_CLUSTER_CAP")) o.first_cap = atoi(v);
+    return o;
+}
+
 template <typename T>
 hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
     const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
@@ -697,25 +707,38 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
         const int64_t model_rowb = 4 * (N < tile_cols ? N : tile_cols);
         const int64_t model_window = (3ll << 20) / (model_rowb > 0 ? model_rowb : 4);
 
+        static const bool timing = getenv("GESPMM_PLAN_TIMING") != nullptr;
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            (void)hipStreamSynchronize(st);
+            static thread_local std::chrono::steady_clock::time_point last;
+            const auto now = std::chrono::steady_clock::now();
+            if (what) fprintf(stderr, "[plan] %-22s %8.3f ms\n", what, std::chrono::duration<double>(now - last).count() * 1e3);
+            last = now;
+        };
         if (reorder && !on_host) {
             // ==================================================================== analysis on the device
+            lap(nullptr);
             const auto tc = std::chrono::steady_clock::now();
             e = hipMalloc(reinterpret_cast<void**>(&p->d_perm), (size_t)M * 4);
-            gespmm::ClusterOptions copt;
+            gespmm::ClusterOptions copt = cluster_options_from_env();
             if (e == hipSuccess) e = gespmm::device_cluster_rows(M, K, nnz, rowptr, colind, copt, p->d_perm, &p->stats, st);
             p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+            lap("cluster");
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_rowptr), ((size_t)M + 1) * 4);
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_colind), (size_t)(nnz > 0 ? nnz : 1) * 4);
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_src_begin), (size_t)M * 4);
             if (e == hipSuccess)
                 e = gespmm::device_permute_csr(M, nnz, rowptr, colind, p->d_perm, p->d_rowptr, p->d_colind, p->d_src_begin, st);
+            lap("permute");
             const auto tm = std::chrono::steady_clock::now();
             if (e == hipSuccess)
-                e = gespmm::device_l2_model(M, K, nnz, rowptr, colind, 8, model_window, model_sample, 8192, &p->hits_before, st);
+                e = gespmm::device_l2_model(M, K, nnz, rowptr, colind, 8, model_window, model_sample, 4096, &p->hits_before, st);
             if (e == hipSuccess)
-                e = gespmm::device_l2_model(M, K, nnz, p->d_rowptr, p->d_colind, 8, model_window, model_sample, 8192,
+                e = gespmm::device_l2_model(M, K, nnz, p->d_rowptr, p->d_colind, 8, model_window, model_sample, 4096,
                                             &p->hits_after, st);
             p->model_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tm).count();
+            lap("l2 model x2");
             if (e != hipSuccess) {
                 free_device(p);
                 delete p;
@@ -742,6 +765,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             else if (mean < 16) gbudget = 16;
             e = gespmm::device_cut_tasks(M, p->d_rowptr, budget, row_floor, &p->d_tasks, &p->ntasks, st);
             if (e == hipSuccess) e = gespmm::device_cut_tasks(M, p->d_rowptr, gbudget, 0, &p->d_gtasks, &p->ngtasks, st);
+            lap("tasks x2");
             if (e == hipSuccess && p->valued) e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(nnz > 0 ? nnz : 1) * 4);
             if (e == hipSuccess && p->valued && nnz > 0) {
                 hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
@@ -763,6 +787,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 if (e == hipSuccess) e = build_and_upload_records(p, opt, rp, ci, src, val, st);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
+            lap("values");
             if (e != hipSuccess) {
                 free_device(p);
                 delete p;
@@ -777,7 +802,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
         if (reorder) {
             const auto tc = std::chrono::steady_clock::now();
             p->perm_host.resize((size_t)M);
-            gespmm::ClusterOptions copt;
+            gespmm::ClusterOptions copt = cluster_options_from_env();
             copt.threads = opt ? opt->threads : 0;
             if (gespmm::cluster_rows(M, K, h_rowptr.data(), h_colind.data(), copt, p->perm_host.data(), &p->stats) != 0) {
                 delete p;

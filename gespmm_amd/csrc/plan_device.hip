@@ -30,6 +30,9 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -227,16 +230,6 @@ __device__ inline bool sits_out(const LpArgs& a, int node) {
     return a.skip_half && (mix32((uint32_t)node * 0x85ebca6bu ^ a.seed) & 1u);
 }
 
-// nodes outside every class (no neighbours / twins): columns with a twin carry their cluster's label, the rest keep theirs
-__global__ void k_lp_default(const int32_t* __restrict__ cur, const int32_t* __restrict__ twin,
-                             const int32_t* __restrict__ rlab, int n, int32_t* __restrict__ next,
-                             const int32_t* __restrict__ done) {
-    if (*done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    next[i] = (twin && twin[i] >= 0) ? rlab[twin[i]] : cur[i];
-}
-
 // (weight, hash, label) butterfly maximum inside a group of G lanes: larger weight wins, then the smaller hash
 template <int G>
 __device__ inline void best_of_group(long long& bt, uint32_t& bh, int& bL) {
@@ -430,39 +423,45 @@ __global__ void __launch_bounds__(256) k_lp_dense(LpArgs a, unsigned long long* 
     }
 }
 
-__global__ void k_sizes(const int32_t* __restrict__ rlab, const int32_t* __restrict__ rweight, int R,
-                        int32_t* __restrict__ size, const int32_t* __restrict__ done) {
-    if (*done) return;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < R) atomicAdd(&size[rlab[r]], rweight[r]);
-}
-
-__global__ void k_zero_if_running(int32_t* __restrict__ a, int n, const int32_t* __restrict__ done) {
+// Column side: labels move from `next` to `cur`; a column with a twin carries its cluster's (new) row label instead.
+__global__ void k_commit_cols(int32_t* __restrict__ cur, const int32_t* __restrict__ next, const int32_t* __restrict__ twin,
+                              const int32_t* __restrict__ rlab, int n, const int32_t* __restrict__ done) {
     if (*done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = 0;
+    if (i < n) cur[i] = (twin && twin[i] >= 0) ? rlab[twin[i]] : next[i];
 }
 
-__global__ void k_commit(int32_t* __restrict__ cur, const int32_t* __restrict__ next, int n, int32_t* __restrict__ changed,
-                         const int32_t* __restrict__ done) {
+// Row side: labels move, the per-label sizes follow the rows that moved (so `size` is always the snapshot the next
+// half-sweep needs), and the last workgroup to finish decides whether the level's remaining sweeps are skipped:
+// fewer than 0.25 % of the row nodes moved (reorder.cpp).
+__global__ void k_commit_rows(int32_t* __restrict__ cur, const int32_t* __restrict__ next, const int32_t* __restrict__ rweight,
+                              int32_t* __restrict__ size, int n, int32_t* __restrict__ changed, int32_t* __restrict__ ticket,
+                              int32_t* __restrict__ done) {
     if (*done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int ch = 0;
     if (i < n) {
-        const int v = next[i];
-        ch = v != cur[i];
-        cur[i] = v;
+        const int v = next[i], old = cur[i];
+        if (v != old) {
+            ch = 1;
+            cur[i] = v;
+            const int w = rweight[i];
+            atomicAdd(&size[v], w);
+            atomicSub(&size[old], w);
+        }
     }
-    if (changed) {
-        const unsigned long long m = __ballot(ch);
-        if (m && lane_id() == (__ffsll((long long)m) - 1)) atomicAdd(changed, __popcll(m));
+    const unsigned long long m = __ballot(ch);
+    if (m && lane_id() == (__ffsll((long long)m) - 1)) atomicAdd(changed, __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+            const int c = atomicAdd(changed, 0);
+            if ((long long)c * 400 < n) atomicExch(done, 1);
+            atomicExch(changed, 0);
+            atomicExch(ticket, 0);
+        }
     }
-}
-
-// fewer than 0.25 % of the row nodes moved: the level's remaining sweeps are skipped (reorder.cpp)
-__global__ void k_check_done(int32_t* __restrict__ changed, int R, int32_t* __restrict__ done) {
-    if (*done == 0 && (long long)(*changed) * 400 < R) *done = 1;
-    *changed = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ contraction
@@ -483,13 +482,11 @@ __global__ void k_make_ids(const int32_t* __restrict__ used, const int32_t* __re
     if (L < R) ids[L] = used[L] ? pos[L] : -1;
 }
 
-__global__ void k_relabel(int32_t* __restrict__ node_of_row, const int32_t* __restrict__ rlab,
-                          const int32_t* __restrict__ rid, int64_t M, int32_t* __restrict__ level_lab) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const int v = rid[rlab[node_of_row[i]]];
-    node_of_row[i] = v;
-    level_lab[i] = v;
+// parent[r] = node of the next level that row node r becomes part of
+__global__ void k_parents(const int32_t* __restrict__ rlab, const int32_t* __restrict__ rid, int R,
+                          int32_t* __restrict__ parent) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) parent[r] = rid[rlab[r]];
 }
 
 __global__ void k_new_weights(const int32_t* __restrict__ rlab, const int32_t* __restrict__ rid,
@@ -529,33 +526,57 @@ __global__ void k_heads(const unsigned long long* __restrict__ keys, int E, int3
     if (i == E) flags[i] = 0;
 }
 
-// every run of equal keys becomes one weighted edge (weight clamped to int32 as on the host)
-__global__ void k_run_sums(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
-                           const int32_t* __restrict__ flags, const int32_t* __restrict__ uid, int E, int R2, int shift,
-                           int32_t* __restrict__ n_of, int32_t* __restrict__ idx2, int32_t* __restrict__ w2) {
+// every run of equal keys becomes one weighted edge: a wavefront sums the pieces of runs it sees with a segmented
+// shuffle scan, the last lane of every piece adds it to the run's 64-bit total (integer adds: order-free)
+__global__ void __launch_bounds__(256) k_run_sums(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                  const int32_t* __restrict__ flags, const int32_t* __restrict__ uid, int E,
+                                                  int R2, int shift, int32_t* __restrict__ n_of, int32_t* __restrict__ idx2,
+                                                  unsigned long long* __restrict__ total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= E || !flags[i]) return;
-    const unsigned long long key = keys[i];
+    const int lane = lane_id();
+    const bool in = i < E;
+    const unsigned long long key = in ? keys[i] : ~0ull;
+    long long sum = in ? (long long)vals[i] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long ko = __shfl_up(key, o);
+        const long long so = __shfl_up(sum, o);
+        if (lane >= o && ko == key) sum += so;
+    }
+    const unsigned long long kn = __shfl_down(key, 1);
+    const bool piece_end = in && (lane == 63 || kn != key || i + 1 >= E);
+    if (!in) return;
     const int n = (int)(key >> shift);
     if (n >= R2) return;  // the sentinel run
-    long long s = 0;
-    int j = i;
-    do {
-        s += vals[j];
-        ++j;
-    } while (j < E && !flags[j]);
-    const int u = uid[i];
-    n_of[u] = n;
-    idx2[u] = (int)(key & ((1ull << shift) - 1ull));
-    w2[u] = (int32_t)(s < 0x7fffffffLL ? s : 0x7fffffffLL);
+    const int head = flags[i];
+    const int u = uid[i] + head - 1;  // uid = heads strictly before i
+    if (head) {
+        n_of[u] = n;
+        idx2[u] = (int)(key & ((1ull << shift) - 1ull));
+    }
+    if (piece_end) atomicAdd(&total[u], (unsigned long long)sum);
+}
+
+__global__ void k_clamp_weights(const unsigned long long* __restrict__ total, int n, int32_t* __restrict__ w2) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n) {
+        const unsigned long long t = total[u];
+        w2[u] = (int32_t)(t < 0x7fffffffull ? t : 0x7fffffffull);  // as on the host
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ order, copy
 
-__global__ void k_gather_keys(const int32_t* __restrict__ lab, const int32_t* __restrict__ order, int64_t M,
+// keys[c] = rank of c's parent (rank == nullptr: the parent's id), the sort key that orders level-l clusters
+__global__ void k_parent_rank(const int32_t* __restrict__ parent, const int32_t* __restrict__ rank, int64_t n,
                               int32_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) keys[i] = lab[order[i]];
+    if (i < n) keys[i] = rank ? rank[parent[i]] : parent[i];
+}
+
+__global__ void k_invert(const int32_t* __restrict__ sorted_ids, int64_t n, int32_t* __restrict__ rank) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rank[sorted_ids[i]] = (int32_t)i;
 }
 
 __global__ void k_perm_degrees(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, int64_t M,
@@ -673,9 +694,17 @@ __global__ void __launch_bounds__(64) k_model_sample(const int32_t* __restrict__
         else {
             long long distinct = 0;
             hit = 1;
-            for (int q = a + 1 + lane; q - lane < p; q += 64) {
-                const int first = (q < p) && (prev[q] < a);
-                distinct += __popcll(__ballot(first));
+            // 256 accesses per step: four independent coalesced loads per lane in flight
+            for (int q0 = a + 1; q0 < p; q0 += 256) {
+                int first = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = q0 + j * 64 + lane;
+                    first += (q < p && prev[q] < a) ? 1 : 0;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) first += __shfl_xor(first, o);
+                distinct += first;
                 if (distinct >= window) {
                     hit = 0;
                     break;
@@ -722,19 +751,18 @@ __global__ void k_task_next(const long long* __restrict__ P /* exclusive prefix 
 }
 
 // A chain enters a block within its first kMaxRowsPerWave rows (a task never has more rows): exit row of the chain
-// for each of those entry points.
-__global__ void __launch_bounds__(64) k_task_exits(const int32_t* __restrict__ next, int64_t M,
-                                                   int32_t* __restrict__ exits /* [nblk][kMaxRowsPerWave] */) {
+// for each of those entry points. The block's next[] is staged in LDS: the walks are serial chains of lookups.
+__global__ void __launch_bounds__(256) k_task_exits(const int32_t* __restrict__ next, int64_t M,
+                                                    int32_t* __restrict__ exits /* [nblk][kMaxRowsPerWave] */) {
+    __shared__ int32_t s_next[kCutBlock];
     const int64_t b0 = (int64_t)blockIdx.x * kCutBlock;
     const int64_t b1 = b0 + kCutBlock < M ? b0 + kCutBlock : M;
+    for (int i = threadIdx.x; i < b1 - b0; i += blockDim.x) s_next[i] = next[b0 + i];
+    __syncthreads();
     const int t = threadIdx.x;
     if (t >= kMaxRowsPerWave) return;
     int64_t cur = b0 + t;
-    if (cur >= b1) {
-        exits[(int64_t)blockIdx.x * kMaxRowsPerWave + t] = (int32_t)cur;
-        return;
-    }
-    while (cur < b1) cur = next[cur];
+    while (cur < b1) cur = s_next[cur - b0];
     exits[(int64_t)blockIdx.x * kMaxRowsPerWave + t] = (int32_t)cur;
 }
 
@@ -747,15 +775,18 @@ __global__ void k_task_entries(const int32_t* __restrict__ exits, int64_t nblk, 
     }
 }
 
-__global__ void __launch_bounds__(64) k_task_mark(const int32_t* __restrict__ next, const int32_t* __restrict__ entry,
-                                                  int64_t M, int32_t* __restrict__ flags /* zeroed, [M + 1] */) {
-    if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(256) k_task_mark(const int32_t* __restrict__ next, const int32_t* __restrict__ entry,
+                                                   int64_t M, int32_t* __restrict__ flags /* zeroed, [M + 1] */) {
+    __shared__ int32_t s_next[kCutBlock];
     const int64_t b0 = (int64_t)blockIdx.x * kCutBlock;
     const int64_t b1 = b0 + kCutBlock < M ? b0 + kCutBlock : M;
+    for (int i = threadIdx.x; i < b1 - b0; i += blockDim.x) s_next[i] = next[b0 + i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     int64_t cur = entry[blockIdx.x];
     while (cur < b1) {
         flags[cur] = 1;
-        cur = next[cur];
+        cur = s_next[cur - b0];
     }
 }
 
@@ -786,14 +817,18 @@ hipError_t exclusive_scan(Scratch& sc, const T* in, T* out, int64_t n, hipStream
     return hipSuccess;
 }
 
+// Keys here have 10-35 significant bits: Onesweep (a histogram + one kernel per 8 bits) instead of rocPRIM's default
+// merge sort below 2^20 items (block sort + two kernels per doubling: ~20 launches for the 3*10^5-row rank sorts).
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 template <typename KeyT>
 hipError_t sort_pairs(Scratch& sc, const KeyT* kin, KeyT* kout, const int32_t* vin, int32_t* vout, int64_t n, int bits,
                       hipStream_t st) {
     size_t bytes = 0;
-    GESPMM_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
+    GESPMM_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
     char* tmp = nullptr;
     GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
-    GESPMM_TRY(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
+    GESPMM_TRY(rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
     sc.release(tmp);
     return hipSuccess;
 }
@@ -801,10 +836,10 @@ hipError_t sort_pairs(Scratch& sc, const KeyT* kin, KeyT* kout, const int32_t* v
 hipError_t sort_keys64(Scratch& sc, const unsigned long long* kin, unsigned long long* kout, int64_t n, int bits,
                        hipStream_t st) {
     size_t bytes = 0;
-    GESPMM_TRY(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
+    GESPMM_TRY(rocprim::radix_sort_keys<SortConfig>(nullptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
     char* tmp = nullptr;
     GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
-    GESPMM_TRY(rocprim::radix_sort_keys(tmp, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
+    GESPMM_TRY(rocprim::radix_sort_keys<SortConfig>(tmp, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
     sc.release(tmp);
     return hipSuccess;
 }
@@ -900,9 +935,10 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
     if (stats) *stats = ClusterStats{};
     if (M <= 0) return hipSuccess;
     Scratch sc(st);
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
-    GESPMM_TRY(hipGetLastError());
-    if (nnz <= 0) return hipSuccess;
+    if (nnz <= 0) {
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
+        return hipGetLastError();
+    }
 
     auto release_level = [&](DLevel& l) {
         for (void* p : l.owned) sc.release(p);
@@ -924,22 +960,33 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         lv.rweight = rw;
         lv.owned.push_back(rw);
     }
-    int32_t* node_of_row = nullptr;
-    GESPMM_TRY(sc.get(&node_of_row, M));
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, node_of_row, M);
-    std::vector<int32_t*> level_labels;
-    std::vector<int32_t> level_count;
+    // parents[l][c] = node of level l + 1 that node c of level l belongs to (level 0: c = original row)
+    std::vector<int32_t*> parents;
+    std::vector<int32_t> parent_count;  // nodes of level l (length of parents[l])
+    std::vector<int32_t> cluster_count; // nodes of level l + 1
 
-    int32_t* flags_dev = nullptr;  // {done, changed, counts_rows[4], counts_cols[4]}
+    int32_t* flags_dev = nullptr;  // {done, changed, ticket, -, counts_rows[4], counts_cols[4], R2, C2}
     GESPMM_TRY(sc.get(&flags_dev, 16));
 
     long long cap = opt.first_cap > 0 ? opt.first_cap : 256;
     const int max_levels = opt.max_levels > 0 ? opt.max_levels : 10;
     const int sweeps = opt.sweeps > 0 ? opt.sweeps : 5;
+    const int stop_percent = opt.stop_percent > 0 ? opt.stop_percent : 97;
 
+    static const bool timing = getenv("GESPMM_PLAN_TIMING") != nullptr;
+    auto lap = [&](const char* what, int level) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        static thread_local std::chrono::steady_clock::time_point last;
+        const auto now = std::chrono::steady_clock::now();
+        if (what) fprintf(stderr, "[plan]   L%d %-16s %8.3f ms\n", level, what, std::chrono::duration<double>(now - last).count() * 1e3);
+        last = now;
+    };
+    lap(nullptr, 0);
     for (int level = 0; level < max_levels; ++level) {
         const int32_t R = lv.R, C = lv.C;
         if (R <= 1 || lv.E == 0) break;
+        lap("(cols/setup)", level);
         int32_t *rlab = nullptr, *clab = nullptr, *rnext = nullptr, *cnext = nullptr, *size = nullptr, *rlists = nullptr,
                 *clists = nullptr;
         GESPMM_TRY(sc.get(&rlab, R));
@@ -949,11 +996,16 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         GESPMM_TRY(sc.get(&size, R));
         GESPMM_TRY(sc.get(&rlists, (int64_t)kBins * R));
         GESPMM_TRY(sc.get(&clists, (int64_t)kBins * C));
+        // every row node starts as its own label; a node that never moves keeps next == cur for the whole level
         hipLaunchKernelGGL(k_iota, dim3(grid_for(R)), dim3(256), 0, st, rlab, (int64_t)R);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(R)), dim3(256), 0, st, rnext, (int64_t)R);
         hipLaunchKernelGGL(k_fill, dim3(grid_for(C)), dim3(256), 0, st, clab, (int64_t)C, -1);
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(C)), dim3(256), 0, st, cnext, (int64_t)C, -1);
+        GESPMM_TRY(hipMemcpyAsync(size, lv.rweight, (size_t)R * 4, hipMemcpyDeviceToDevice, st));  // label r owns node r
         GESPMM_TRY(hipMemsetAsync(flags_dev, 0, 16 * 4, st));
         int32_t* done = flags_dev;
         int32_t* changed = flags_dev + 1;
+        int32_t* ticket = flags_dev + 2;
         int32_t* rcounts = flags_dev + 4;
         int32_t* ccounts = flags_dev + 8;
         hipLaunchKernelGGL(k_bin_nodes, dim3(grid_for(R)), dim3(256), 0, st, lv.rows.ptr, (const int32_t*)nullptr, R, rlists,
@@ -979,7 +1031,9 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             a.seed = 0x9e3779b9u * (uint32_t)(level * 16 + sweep + 1);
             a.done = done;
             a.cap = cap;
-            // columns <- heaviest row label
+            a.list = nullptr;
+            a.count = nullptr;
+            // columns <- heaviest row label (columns with a twin simply carry their cluster's label: k_commit_cols)
             a.adj = lv.cols;
             a.nbr_label = rlab;
             a.cur = clab;
@@ -987,17 +1041,10 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             a.size = nullptr;
             a.rweight = nullptr;
             a.skip_half = 0;
-            a.list = nullptr;
-            a.count = nullptr;
-            hipLaunchKernelGGL(k_lp_default, dim3(grid_for(C)), dim3(256), 0, st, (const int32_t*)clab, lv.twin,
-                               (const int32_t*)rlab, C, cnext, (const int32_t*)done);
             GESPMM_TRY(launch_half_sweep<false>(a, clists, ccounts, h_counts + 4, C, acc, acc_wgs, R, st));
-            hipLaunchKernelGGL(k_commit, dim3(grid_for(C)), dim3(256), 0, st, clab, (const int32_t*)cnext, C,
-                               (int32_t*)nullptr, (const int32_t*)done);
-            // rows <- heaviest column label, within the size cap (sizes: snapshot at the start of the half-sweep)
-            hipLaunchKernelGGL(k_zero_if_running, dim3(grid_for(R)), dim3(256), 0, st, size, R, (const int32_t*)done);
-            hipLaunchKernelGGL(k_sizes, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab, lv.rweight, R, size,
-                               (const int32_t*)done);
+            hipLaunchKernelGGL(k_commit_cols, dim3(grid_for(C)), dim3(256), 0, st, clab, (const int32_t*)cnext, lv.twin,
+                               (const int32_t*)rlab, C, (const int32_t*)done);
+            // rows <- heaviest column label, within the size cap (sizes: as of the start of the half-sweep)
             a.adj = lv.rows;
             a.nbr_label = clab;
             a.cur = rlab;
@@ -1005,14 +1052,12 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             a.size = size;
             a.rweight = lv.rweight;
             a.skip_half = (twins && sweep + 1 < sweeps) ? 1 : 0;
-            hipLaunchKernelGGL(k_lp_default, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab,
-                               (const int32_t*)nullptr, (const int32_t*)nullptr, R, rnext, (const int32_t*)done);
             GESPMM_TRY(launch_half_sweep<true>(a, rlists, rcounts, h_counts, R, acc, acc_wgs, R, st));
-            hipLaunchKernelGGL(k_commit, dim3(grid_for(R)), dim3(256), 0, st, rlab, (const int32_t*)rnext, R, changed,
-                               (const int32_t*)done);
-            hipLaunchKernelGGL(k_check_done, dim3(1), dim3(1), 0, st, changed, R, done);
+            hipLaunchKernelGGL(k_commit_rows, dim3(grid_for(R)), dim3(256), 0, st, rlab, (const int32_t*)rnext, lv.rweight, size,
+                               R, changed, ticket, done);
             GESPMM_TRY(hipGetLastError());
         }
+        lap("sweeps", level);
         sc.release(rnext);
         sc.release(cnext);
         sc.release(size);
@@ -1021,12 +1066,13 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         if (acc) sc.release(acc);
 
         // ---- contract: compact row labels -> new row nodes, column labels -> new column nodes
-        int32_t *used = nullptr, *pos = nullptr, *rid = nullptr, *cid = nullptr;
+        int32_t *used = nullptr, *pos = nullptr, *rid = nullptr, *cid = nullptr, *parent = nullptr;
         const int64_t R1 = (int64_t)R + 1;
         GESPMM_TRY(sc.get(&used, 2 * R1));
         GESPMM_TRY(sc.get(&pos, 2 * R1));
         GESPMM_TRY(sc.get(&rid, R));
         GESPMM_TRY(sc.get(&cid, R));
+        GESPMM_TRY(sc.get(&parent, R));
         GESPMM_TRY(hipMemsetAsync(used, 0, (size_t)(2 * R1) * 4, st));
         hipLaunchKernelGGL(k_mark_used, dim3(grid_for(std::max(R, C))), dim3(256), 0, st, (const int32_t*)rlab, R,
                            (const int32_t*)clab, C, used, used + R1);
@@ -1035,23 +1081,22 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)used, (const int32_t*)pos, R, rid);
         hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)(used + R1),
                            (const int32_t*)(pos + R1), R, cid);
-        int32_t* lab = nullptr;
-        GESPMM_TRY(sc.get(&lab, M));
-        hipLaunchKernelGGL(k_relabel, dim3(grid_for(M)), dim3(256), 0, st, node_of_row, (const int32_t*)rlab,
-                           (const int32_t*)rid, M, lab);
+        hipLaunchKernelGGL(k_parents, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab, (const int32_t*)rid, R, parent);
         GESPMM_TRY(hipGetLastError());
         int32_t R2 = 0, C2 = 0;
-        GESPMM_TRY(fetch(&R2, (const int32_t*)(pos + R), 1, st));
-        GESPMM_TRY(fetch(&C2, (const int32_t*)(pos + R1 + R), 1, st));
+        GESPMM_TRY(hipMemcpyAsync(&R2, pos + R, 4, hipMemcpyDeviceToHost, st));
+        GESPMM_TRY(hipMemcpyAsync(&C2, pos + R1 + R, 4, hipMemcpyDeviceToHost, st));
+        GESPMM_TRY(hipStreamSynchronize(st));
         sc.release(used);
         sc.release(pos);
-        level_labels.push_back(lab);
-        level_count.push_back(R2);
+        parents.push_back(parent);
+        parent_count.push_back(R);
+        cluster_count.push_back(R2);
         if (stats) {
             stats->levels = level + 1;
             if (level < 16) stats->clusters[level] = R2;
         }
-        const bool last = (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * 97 || level + 1 >= max_levels);
+        const bool last = (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * stop_percent || level + 1 >= max_levels);
         if (last) {
             sc.release(rlab);
             sc.release(clab);
@@ -1060,6 +1105,7 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             break;
         }
 
+        lap("relabel", level);
         // ---- the next level: members' weights, twins, merged adjacency over the new column nodes
         DLevel nx;
         nx.R = R2;
@@ -1103,17 +1149,24 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         GESPMM_TRY(exclusive_scan<int32_t>(sc, hflags, uid, E + 1, st));
         int32_t U = 0;
         unsigned long long last_key = 0;
-        GESPMM_TRY(fetch(&U, (const int32_t*)(uid + E), 1, st));
-        GESPMM_TRY(fetch(&last_key, (const unsigned long long*)(keys_sorted + (E - 1)), 1, st));
+        GESPMM_TRY(hipMemcpyAsync(&U, uid + E, 4, hipMemcpyDeviceToHost, st));
+        GESPMM_TRY(hipMemcpyAsync(&last_key, keys_sorted + (E - 1), 8, hipMemcpyDeviceToHost, st));
+        GESPMM_TRY(hipStreamSynchronize(st));
         const int64_t E2 = ((int64_t)(last_key >> shift) >= R2) ? U - 1 : U;
         int32_t *n_of = nullptr, *idx2 = nullptr, *w2 = nullptr, *ptr2 = nullptr;
+        unsigned long long* totals = nullptr;
         GESPMM_TRY(sc.get(&n_of, E2));
         GESPMM_TRY(sc.get(&idx2, E2));
         GESPMM_TRY(sc.get(&w2, E2));
+        GESPMM_TRY(sc.get(&totals, E2));
         GESPMM_TRY(sc.get(&ptr2, (int64_t)R2 + 1));
+        GESPMM_TRY(hipMemsetAsync(totals, 0, (size_t)(E2 > 0 ? E2 : 1) * 8, st));
         hipLaunchKernelGGL(k_run_sums, dim3(grid_for(E)), dim3(256), 0, st, (const unsigned long long*)keys_sorted,
                            (const int32_t*)vals_sorted, (const int32_t*)hflags, (const int32_t*)uid, (int)E, R2, shift, n_of,
-                           idx2, w2);
+                           idx2, totals);
+        if (E2 > 0)
+            hipLaunchKernelGGL(k_clamp_weights, dim3(grid_for(E2)), dim3(256), 0, st, (const unsigned long long*)totals, (int)E2,
+                               w2);
         hipLaunchKernelGGL(k_lower_bound_ptr, dim3(grid_for((int64_t)R2 + 1)), dim3(256), 0, st, (const int32_t*)n_of,
                            (int)E2, R2, ptr2);
         GESPMM_TRY(hipGetLastError());
@@ -1121,6 +1174,7 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         sc.release(vals_sorted);
         sc.release(hflags);
         sc.release(uid);
+        sc.release(totals);
         nx.E = E2;
         nx.rows.ptr = ptr2;
         nx.rows.idx = idx2;
@@ -1130,30 +1184,46 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         nx.owned.push_back(w2);
         if (E2 > 0) GESPMM_TRY(build_cols(sc, nx, n_of, st));
         sc.release(n_of);
+        lap("contract", level);
         release_level(lv);
         lv = nx;
         cap *= opt.cap_growth > 1 ? opt.cap_growth : 4;
     }
     release_level(lv);
 
-    // ---- order: stable sorts by the labels of each level, finest first = lexicographic by
-    //      (coarsest label, ..., finest label, original row id)
-    if (!level_labels.empty()) {
-        int32_t *keys = nullptr, *keys_out = nullptr, *order = nullptr, *order_out = nullptr;
-        GESPMM_TRY(sc.get(&keys, M));
-        GESPMM_TRY(sc.get(&keys_out, M));
-        GESPMM_TRY(sc.get(&order, M));
-        GESPMM_TRY(sc.get(&order_out, M));
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, order, M);
-        for (size_t l = 0; l < level_labels.size(); ++l) {
-            hipLaunchKernelGGL(k_gather_keys, dim3(grid_for(M)), dim3(256), 0, st, (const int32_t*)level_labels[l],
-                               (const int32_t*)order, M, keys);
-            GESPMM_TRY(sort_pairs<int32_t>(sc, keys, keys_out, order, order_out, M, bits_for(level_count[l]), st));
-            std::swap(order, order_out);
+    // ---- order = lexicographic by (coarsest cluster, ..., finest cluster, original row id). The clusters nest, so it
+    //      is enough to rank the clusters of each level top-down — a stable sort of the level's clusters by the rank of
+    //      their parent — and finally sort the rows by the rank of their finest cluster (stable: ascending row ids).
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
+    if (!parents.empty()) {
+        const int L = (int)parents.size();
+        int32_t* rank = nullptr;  // rank of the nodes of level l + 1 (nullptr: their ids)
+        for (int l = L - 1; l >= 0; --l) {
+            const int64_t n = parent_count[l];  // nodes of level l (l == 0: the rows)
+            int32_t *keys = nullptr, *keys_out = nullptr, *ids = nullptr, *ids_out = nullptr;
+            GESPMM_TRY(sc.get(&keys, n));
+            GESPMM_TRY(sc.get(&keys_out, n));
+            GESPMM_TRY(sc.get(&ids, n));
+            hipLaunchKernelGGL(k_parent_rank, dim3(grid_for(n)), dim3(256), 0, st, (const int32_t*)parents[l],
+                               (const int32_t*)rank, n, keys);
+            hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(256), 0, st, ids, n);
+            if (l == 0) ids_out = perm;
+            else GESPMM_TRY(sc.get(&ids_out, n));
+            GESPMM_TRY(sort_pairs<int32_t>(sc, keys, keys_out, ids, ids_out, n, bits_for(cluster_count[l]), st));
+            sc.release(keys);
+            sc.release(keys_out);
+            sc.release(ids);
+            if (rank) sc.release(rank);
+            rank = nullptr;
+            if (l > 0) {
+                GESPMM_TRY(sc.get(&rank, n));
+                hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(256), 0, st, (const int32_t*)ids_out, n, rank);
+                sc.release(ids_out);
+            }
         }
-        GESPMM_TRY(hipMemcpyAsync(perm, order, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
     }
     GESPMM_TRY(hipGetLastError());
+    lap("order", 99);
     return hipStreamSynchronize(st);  // the scratch goes back to the pool in stream order; callers may read perm now
 }
 
@@ -1231,10 +1301,10 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, int64_t budget, 
     hipLaunchKernelGGL(k_row_costs, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr_p, M, (long long)row_floor, cost);
     GESPMM_TRY(exclusive_scan<long long>(sc, cost, P, M + 1, st));
     hipLaunchKernelGGL(k_task_next, dim3(grid_for(M)), dim3(256), 0, st, (const long long*)P, M, (long long)budget, next);
-    hipLaunchKernelGGL(k_task_exits, dim3((unsigned)nblk), dim3(64), 0, st, (const int32_t*)next, M, exits);
+    hipLaunchKernelGGL(k_task_exits, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)next, M, exits);
     hipLaunchKernelGGL(k_task_entries, dim3(1), dim3(64), 0, st, (const int32_t*)exits, nblk, entry);
     GESPMM_TRY(hipMemsetAsync(flags, 0, (size_t)(M + 1) * 4, st));
-    hipLaunchKernelGGL(k_task_mark, dim3((unsigned)nblk), dim3(64), 0, st, (const int32_t*)next, (const int32_t*)entry, M,
+    hipLaunchKernelGGL(k_task_mark, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)next, (const int32_t*)entry, M,
                        flags);
     GESPMM_TRY(exclusive_scan<int32_t>(sc, flags, tid_of, M + 1, st));
     int32_t nt = 0;

@@ -284,7 +284,7 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
             stats->levels = level + 1;
             if (level < 16) stats->clusters[level] = R2;
         }
-        if (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * 97) break;  // nothing left to merge
+        if (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * (opt.stop_percent > 0 ? opt.stop_percent : 97)) break;  // nothing left to merge
         // members of every new row node, then their merged adjacency over new column nodes
         Level nx;
         nx.R = R2;

@@ -10,6 +10,7 @@ struct ClusterOptions {
     int sweeps = 0;        // 0: 5 label-propagation sweeps per level
     int64_t first_cap = 0; // 0: 256 original rows per label at level 0
     int cap_growth = 0;    // 0: x4 per level
+    int stop_percent = 0;  // 0: 97 — a level that keeps more than this share of its nodes ends the hierarchy
 };
 
 struct ClusterStats {
