@@ -53,6 +53,7 @@ struct gespmm_plan {
     int32_t ntasks = 0;
     int32_t* d_gtasks = nullptr;  // lane-group tasks of the segmented-stream kernel
     int32_t ngtasks = 0;
+    bool gtasks_shared = false;   // d_gtasks points into the block of d_tasks (device analysis)
     // task-outer kernel (spmm_outer.hip): one 544-byte record per task
     int32_t* d_orecs = nullptr;
     int32_t* d_orec_src = nullptr;
@@ -118,6 +119,7 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 }
 
 void free_device(gespmm_plan* p) {
+    if (p->gtasks_shared) p->d_gtasks = nullptr;
     void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp, p->d_orecs, p->d_orec_src};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -763,8 +765,17 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             int gbudget = budget / 2 > 16 ? budget / 2 : 16;
             if (opt && opt->task_entries > 0) gbudget = opt->task_entries / 2 > 4 ? opt->task_entries / 2 : 4;
             else if (mean < 16) gbudget = 16;
-            e = gespmm::device_cut_tasks(M, p->d_rowptr, budget, row_floor, &p->d_tasks, &p->ntasks, st);
-            if (e == hipSuccess) e = gespmm::device_cut_tasks(M, p->d_rowptr, gbudget, 0, &p->d_gtasks, &p->ngtasks, st);
+            {
+                const int64_t budgets[2] = {budget, gbudget}, floors[2] = {row_floor, 0};
+                int32_t* tables[2] = {nullptr, nullptr};
+                int32_t counts[2] = {0, 0};
+                e = gespmm::device_cut_tasks(M, p->d_rowptr, budgets, floors, tables, counts, st);
+                p->d_tasks = tables[0];
+                p->d_gtasks = tables[1];
+                p->ntasks = counts[0];
+                p->ngtasks = counts[1];
+                p->gtasks_shared = true;  // one block holds both tables: free d_tasks only
+            }
             lap("tasks x2");
             if (e == hipSuccess && p->valued) e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(nnz > 0 ? nnz : 1) * 4);
             if (e == hipSuccess && p->valued && nnz > 0) {

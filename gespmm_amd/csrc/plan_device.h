@@ -32,10 +32,11 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
                            int64_t window, int64_t max_entries_per_slice, int samples_per_slice, double* hits_host,
                            hipStream_t st);
 
-// Greedy task cutting of plan.cpp (a task = consecutive rows, <= kMaxRowsPerWave of them, cost <= budget, at least
-// one row; cost of a row = max(entries, row_floor)). *tasks = int4 {first row, #rows, CSR begin, CSR end} per task,
-// allocated with hipMalloc (caller frees).
-hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, int64_t budget, int64_t row_floor, int32_t** tasks,
-                            int32_t* ntasks_host, hipStream_t st);
+// Greedy task cutting of plan.cpp for BOTH task tables of a plan at once (v = 0: wavefront tasks, 1: lane-group tasks):
+// a task = consecutive rows, <= kMaxRowsPerWave of them, cost <= budget[v], at least one row; cost of a row =
+// max(entries, row_floor[v]). tasks[v] = int4 {first row, #rows, CSR begin, CSR end} per task; tasks[0] is ONE hipMalloc
+// block that holds both tables (free tasks[0] only).
+hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t budget[2], const int64_t row_floor[2],
+                            int32_t* tasks[2], int32_t ntasks_host[2], hipStream_t st);
 
 }  // namespace gespmm

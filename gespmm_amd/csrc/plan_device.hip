@@ -53,33 +53,58 @@ namespace {
         if (e__ != hipSuccess) return e__;     \
     } while (0)
 
-// Stream-ordered temporaries from the library's pool, all released when the object goes out of scope.
+// Temporaries of one analysis call: ONE stream-ordered block from the library's pool, carved into bump regions
+// (a plan used to make ~250 pool calls; each costs microseconds of host time and, the first time a size is seen, a
+// real allocation). Regions: persistent for the call, two "level" regions that ping-pong between a level and the one
+// built from it, and a temporary region that is rewound at phase boundaries. A request that does not fit its region
+// falls back to a pool block of its own (correct, just slower), so the size estimates need not be tight.
 struct Scratch {
+    enum { kPersist = 0, kLevelA = 1, kLevelB = 2, kTemp = 3, kRegions = 4 };
     hipStream_t st;
-    std::vector<void*> blocks;
+    char* base = nullptr;
+    size_t begin[kRegions] = {0, 0, 0, 0}, end[kRegions] = {0, 0, 0, 0}, top[kRegions] = {0, 0, 0, 0};
+    int cur = kTemp;
+    std::vector<void*> extras;
     explicit Scratch(hipStream_t s) : st(s) {}
-    ~Scratch() { release_all(); }
-    void release_all() {
-        for (void* b : blocks) (void)workspace_free(b, st);
-        blocks.clear();
+    ~Scratch() {
+        for (void* b : extras) (void)workspace_free(b, st);
+        if (base) (void)workspace_free(base, st);
     }
+    static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
+    hipError_t init(size_t persist, size_t level, size_t temp) {
+        const size_t sz[kRegions] = {up(persist), up(level), up(level), up(temp)};
+        size_t total = 0;
+        for (int r = 0; r < kRegions; ++r) {
+            begin[r] = top[r] = total;
+            total += sz[r];
+            end[r] = total;
+        }
+        void* p = nullptr;
+        hipError_t e = workspace_alloc(&p, total ? total : 256, st);
+        if (e != hipSuccess) return e;
+        base = reinterpret_cast<char*>(p);
+        return hipSuccess;
+    }
+    void use(int region) { cur = region; }
+    size_t mark() const { return top[cur]; }
+    void rewind(int region, size_t m) { top[region] = m; }
+    void reset(int region) { top[region] = begin[region]; }
     template <typename T>
     hipError_t get(T** out, int64_t count) {
+        const size_t bytes = up((size_t)(count > 0 ? count : 1) * sizeof(T));
+        if (base && top[cur] + bytes <= end[cur]) {
+            *out = reinterpret_cast<T*>(base + top[cur]);
+            top[cur] += bytes;
+            return hipSuccess;
+        }
         void* p = nullptr;
-        hipError_t e = workspace_alloc(&p, (size_t)(count > 0 ? count : 1) * sizeof(T), st);
+        hipError_t e = workspace_alloc(&p, bytes, st);
         if (e != hipSuccess) return e;
-        blocks.push_back(p);
+        extras.push_back(p);
         *out = reinterpret_cast<T*>(p);
         return hipSuccess;
     }
-    void release(void* p) {
-        for (size_t i = 0; i < blocks.size(); ++i)
-            if (blocks[i] == p) {
-                (void)workspace_free(p, st);
-                blocks.erase(blocks.begin() + (long)i);
-                return;
-            }
-    }
+    void release(void*) {}  // regions are rewound as a whole
 };
 
 inline int bits_for(int64_t n) {  // bits that hold every value in [0, n)
@@ -186,6 +211,7 @@ struct DAdj {
     const int32_t* w = nullptr;    // nullptr: all ones
 };
 
+constexpr int kDefaultClusterLevels = 3;  // == reorder.cpp (the hierarchy stops paying after three levels: cluster_knobs.log)
 constexpr int kBins = 4;  // degree classes 1..8, 9..64, 65..2048, > 2048
 constexpr int kHashSlots = 4096;
 __device__ inline int bin_of(int d) { return d <= 8 ? 0 : (d <= 64 ? 1 : (d <= 2048 ? 2 : 3)); }
@@ -476,10 +502,38 @@ __global__ void k_mark_used(const int32_t* __restrict__ rlab, int R, const int32
     }
 }
 
-__global__ void k_make_ids(const int32_t* __restrict__ used, const int32_t* __restrict__ pos, int R,
-                           int32_t* __restrict__ ids) {
+// used / pos hold two halves of R + 1 entries (row labels, column labels) scanned as ONE array: positions of the
+// second half are offset by the number of row labels in use (*row_total = pos[R])
+__global__ void k_make_ids(const int32_t* __restrict__ used, const int32_t* __restrict__ pos,
+                           const int32_t* __restrict__ row_total, int R, int32_t* __restrict__ rid, int32_t* __restrict__ cid) {
     const int L = blockIdx.x * blockDim.x + threadIdx.x;
-    if (L < R) ids[L] = used[L] ? pos[L] : -1;
+    if (L >= R) return;
+    rid[L] = used[L] ? pos[L] : -1;
+    const int j = R + 1 + L;
+    cid[L] = used[j] ? pos[j] - *row_total : -1;
+}
+
+// start of a level: every row node is its own label (and owns itself), columns are unlabelled, flags cleared
+__global__ void k_level_init(int32_t* __restrict__ rlab, int32_t* __restrict__ rnext, int32_t* __restrict__ size,
+                             const int32_t* __restrict__ rweight, int R, int32_t* __restrict__ clab,
+                             int32_t* __restrict__ cnext, int C, int32_t* __restrict__ flags /* [16] */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) {
+        rlab[i] = i;
+        rnext[i] = i;
+        size[i] = rweight[i];
+    }
+    if (i < C) {
+        clab[i] = -1;
+        cnext[i] = -1;
+    }
+    if (i < 16) flags[i] = 0;
+}
+
+__global__ void k_fill2(int32_t* __restrict__ a, int64_t na, int32_t va, int32_t* __restrict__ b, int64_t nb, int32_t vb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = va;
+    if (i < nb) b[i] = vb;
 }
 
 // parent[r] = node of the next level that row node r becomes part of
@@ -569,9 +623,11 @@ __global__ void k_clamp_weights(const unsigned long long* __restrict__ total, in
 
 // keys[c] = rank of c's parent (rank == nullptr: the parent's id), the sort key that orders level-l clusters
 __global__ void k_parent_rank(const int32_t* __restrict__ parent, const int32_t* __restrict__ rank, int64_t n,
-                              int32_t* __restrict__ keys) {
+                              int32_t* __restrict__ keys, int32_t* __restrict__ ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = rank ? rank[parent[i]] : parent[i];
+    if (i >= n) return;
+    keys[i] = rank ? rank[parent[i]] : parent[i];
+    ids[i] = (int32_t)i;
 }
 
 __global__ void k_invert(const int32_t* __restrict__ sorted_ids, int64_t n, int32_t* __restrict__ rank) {
@@ -642,7 +698,7 @@ __global__ void k_slice_bounds(const int32_t* __restrict__ rowptr, int M, int nn
 }
 
 __global__ void k_model_keys(const int32_t* __restrict__ colind, const SliceInfo* __restrict__ info, int slices,
-                             int posbits, int64_t total, unsigned long long* __restrict__ keys) {
+                             int64_t total, int32_t* __restrict__ cols, int32_t* __restrict__ poss) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     // i-th modelled access overall -> slice, position
@@ -653,23 +709,17 @@ __global__ void k_model_keys(const int32_t* __restrict__ colind, const SliceInfo
         ++s;
     }
     const int p = info->begin[s] + (int)off;
-    keys[i] = ((unsigned long long)(uint32_t)colind[p] << posbits) | (unsigned long long)p;
+    cols[i] = colind[p];
+    poss[i] = p;
 }
 
-// prev[p] = position of the previous access to the same column (any slice; the consumer checks the slice), -1 if none
-__global__ void k_model_prev(const unsigned long long* __restrict__ sorted, int64_t total, int posbits,
+// after a STABLE sort by column the positions of one column are ascending: prev[p] = position of the previous access to
+// the same column (any slice; the consumer checks the slice), -1 if none
+__global__ void k_model_prev(const int32_t* __restrict__ cols_sorted, const int32_t* __restrict__ pos_sorted, int64_t total,
                              int32_t* __restrict__ prev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const unsigned long long k = sorted[i];
-    const unsigned long long mask = (1ull << posbits) - 1ull;
-    const int p = (int)(k & mask);
-    int pv = -1;
-    if (i > 0) {
-        const unsigned long long q = sorted[i - 1];
-        if ((q >> posbits) == (k >> posbits)) pv = (int)(q & mask);
-    }
-    prev[p] = pv;
+    prev[pos_sorted[i]] = (i > 0 && cols_sorted[i - 1] == cols_sorted[i]) ? pos_sorted[i - 1] : -1;
 }
 
 // One wavefront per sampled access p: hit iff the column was used before in this slice at position a and fewer than
@@ -719,42 +769,48 @@ __global__ void __launch_bounds__(64) k_model_sample(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ task cutting
+// Both task tables of a plan (wavefront tasks, lane-group tasks) are cut together: variant v in {0, 1} has its own
+// budget and row floor; arrays carry a leading variant dimension.
 
-constexpr int kCutBlock = 4096;  // rows per block of the parallel greedy cut
+constexpr int kCutBlock = 1024;  // rows per block of the parallel greedy cut
 
-__global__ void k_row_costs(const int32_t* __restrict__ rp, int64_t M, long long row_floor, long long* __restrict__ cost) {
+struct CutParams {
+    long long budget[2];
+    long long row_floor[2];
+};
+
+__global__ void k_row_costs(const int32_t* __restrict__ rp, int64_t M, CutParams cp, long long* __restrict__ cost /* [2][M + 1] */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) {
-        const long long d = rp[i + 1] - rp[i];
-        cost[i] = d > row_floor ? d : row_floor;
-    } else if (i == M) {
-        cost[i] = 0;
-    }
+    if (i > M) return;
+    const long long d = i < M ? rp[i + 1] - rp[i] : 0;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) cost[v * (M + 1) + i] = i < M ? (d > cp.row_floor[v] ? d : cp.row_floor[v]) : 0;
 }
 
 // next[i] = row after the last row of the task that starts at row i
-__global__ void k_task_next(const long long* __restrict__ P /* exclusive prefix of the costs, [M + 1] */, int64_t M,
-                            long long budget, int32_t* __restrict__ next) {
+__global__ void k_task_next(const long long* __restrict__ P_all /* exclusive prefixes of the costs, [2][M + 1] */, int64_t M,
+                            CutParams cp, int32_t* __restrict__ next_all /* [2][M] */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
     if (i >= M) return;
+    const long long* P = P_all + v * (M + 1);
     int64_t hi = i + kMaxRowsPerWave < M ? i + kMaxRowsPerWave : M;
-    int64_t j = i + 1;
-    // largest j in [i + 1, hi] with P[j] - P[i] <= budget (P is non-decreasing)
-    int64_t lo = i + 1;
+    int64_t lo = i + 1;  // largest j in [i + 1, hi] with P[j] - P[i] <= budget (P is non-decreasing)
     while (lo < hi) {
         const int64_t mid = (lo + hi + 1) >> 1;
-        if (P[mid] - P[i] <= budget) lo = mid;
+        if (P[mid] - P[i] <= cp.budget[v]) lo = mid;
         else hi = mid - 1;
     }
-    j = lo;
-    next[i] = (int32_t)j;
+    next_all[v * M + i] = (int32_t)lo;
 }
 
 // A chain enters a block within its first kMaxRowsPerWave rows (a task never has more rows): exit row of the chain
 // for each of those entry points. The block's next[] is staged in LDS: the walks are serial chains of lookups.
-__global__ void __launch_bounds__(256) k_task_exits(const int32_t* __restrict__ next, int64_t M,
-                                                    int32_t* __restrict__ exits /* [nblk][kMaxRowsPerWave] */) {
+__global__ void __launch_bounds__(256) k_task_exits(const int32_t* __restrict__ next_all, int64_t M, int64_t nblk,
+                                                    int32_t* __restrict__ exits_all /* [2][nblk][kMaxRowsPerWave] */) {
     __shared__ int32_t s_next[kCutBlock];
+    const int v = blockIdx.y;
+    const int32_t* next = next_all + v * M;
     const int64_t b0 = (int64_t)blockIdx.x * kCutBlock;
     const int64_t b1 = b0 + kCutBlock < M ? b0 + kCutBlock : M;
     for (int i = threadIdx.x; i < b1 - b0; i += blockDim.x) s_next[i] = next[b0 + i];
@@ -763,27 +819,41 @@ __global__ void __launch_bounds__(256) k_task_exits(const int32_t* __restrict__ 
     if (t >= kMaxRowsPerWave) return;
     int64_t cur = b0 + t;
     while (cur < b1) cur = s_next[cur - b0];
-    exits[(int64_t)blockIdx.x * kMaxRowsPerWave + t] = (int32_t)cur;
+    exits_all[((int64_t)v * nblk + blockIdx.x) * kMaxRowsPerWave + t] = (int32_t)cur;
 }
 
-__global__ void k_task_entries(const int32_t* __restrict__ exits, int64_t nblk, int32_t* __restrict__ entry) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// first task start inside every block: one serial walk over the blocks per variant, out of LDS when the table fits
+__global__ void __launch_bounds__(256) k_task_entries(const int32_t* __restrict__ exits_all, int64_t nblk,
+                                                      int32_t* __restrict__ entry_all /* [2][nblk] */) {
+    constexpr int kLdsInts = 12288;  // 48 KB
+    __shared__ int32_t s_exits[kLdsInts];
+    const int v = blockIdx.x;
+    const int32_t* exits = exits_all + (int64_t)v * nblk * kMaxRowsPerWave;
+    const bool in_lds = nblk * kMaxRowsPerWave <= kLdsInts;
+    if (in_lds)
+        for (int64_t i = threadIdx.x; i < nblk * kMaxRowsPerWave; i += blockDim.x) s_exits[i] = exits[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     int64_t cur = 0;
     for (int64_t b = 0; b < nblk; ++b) {
-        entry[b] = (int32_t)cur;  // first task start inside block b (always within its first kMaxRowsPerWave rows)
-        cur = exits[b * kMaxRowsPerWave + (cur - b * kCutBlock)];
+        entry_all[v * nblk + b] = (int32_t)cur;  // always within the block's first kMaxRowsPerWave rows
+        const int64_t k = b * kMaxRowsPerWave + (cur - b * kCutBlock);
+        cur = in_lds ? s_exits[k] : exits[k];
     }
 }
 
-__global__ void __launch_bounds__(256) k_task_mark(const int32_t* __restrict__ next, const int32_t* __restrict__ entry,
-                                                   int64_t M, int32_t* __restrict__ flags /* zeroed, [M + 1] */) {
+__global__ void __launch_bounds__(256) k_task_mark(const int32_t* __restrict__ next_all, const int32_t* __restrict__ entry_all,
+                                                   int64_t M, int64_t nblk, int32_t* __restrict__ flags_all /* zeroed, [2][M + 1] */) {
     __shared__ int32_t s_next[kCutBlock];
+    const int v = blockIdx.y;
+    const int32_t* next = next_all + v * M;
+    int32_t* flags = flags_all + v * (M + 1);
     const int64_t b0 = (int64_t)blockIdx.x * kCutBlock;
     const int64_t b1 = b0 + kCutBlock < M ? b0 + kCutBlock : M;
     for (int i = threadIdx.x; i < b1 - b0; i += blockDim.x) s_next[i] = next[b0 + i];
     __syncthreads();
     if (threadIdx.x != 0) return;
-    int64_t cur = entry[blockIdx.x];
+    int64_t cur = entry_all[v * nblk + blockIdx.x];
     while (cur < b1) {
         flags[cur] = 1;
         cur = s_next[cur - b0];
@@ -811,9 +881,10 @@ hipError_t exclusive_scan(Scratch& sc, const T* in, T* out, int64_t n, hipStream
     size_t bytes = 0;
     GESPMM_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), (size_t)n, rocprim::plus<T>(), st));
     char* tmp = nullptr;
+    const size_t m = sc.mark();
     GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
     GESPMM_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, T(0), (size_t)n, rocprim::plus<T>(), st));
-    sc.release(tmp);
+    sc.rewind(sc.cur, m);  // later users of these bytes are later on the stream
     return hipSuccess;
 }
 
@@ -827,9 +898,10 @@ hipError_t sort_pairs(Scratch& sc, const KeyT* kin, KeyT* kout, const int32_t* v
     size_t bytes = 0;
     GESPMM_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
     char* tmp = nullptr;
+    const size_t m = sc.mark();
     GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
     GESPMM_TRY(rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
-    sc.release(tmp);
+    sc.rewind(sc.cur, m);
     return hipSuccess;
 }
 
@@ -838,9 +910,10 @@ hipError_t sort_keys64(Scratch& sc, const unsigned long long* kin, unsigned long
     size_t bytes = 0;
     GESPMM_TRY(rocprim::radix_sort_keys<SortConfig>(nullptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
     char* tmp = nullptr;
+    const size_t m = sc.mark();
     GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
     GESPMM_TRY(rocprim::radix_sort_keys<SortConfig>(tmp, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
-    sc.release(tmp);
+    sc.rewind(sc.cur, m);
     return hipSuccess;
 }
 
@@ -856,7 +929,7 @@ struct DLevel {
     DAdj rows, cols;
     const int32_t* rweight = nullptr;
     const int32_t* twin = nullptr;  // nullptr at level 0
-    std::vector<void*> owned;       // buffers of this level (released when the next level replaces it)
+    int region = Scratch::kLevelA;  // where this level's arrays live (rewound when the next level replaces it)
 };
 
 // transposed adjacency: stable sort of the entries by column node keeps the row nodes ascending inside a column
@@ -864,31 +937,26 @@ hipError_t build_cols(Scratch& sc, DLevel& lv, const int32_t* n_of /* nullptr: r
                       hipStream_t st) {
     const int64_t E = lv.E;
     int32_t *iota = nullptr, *keys_out = nullptr, *order = nullptr, *cidx = nullptr, *cw = nullptr, *cptr = nullptr;
+    sc.use(lv.region);
+    GESPMM_TRY(sc.get(&cidx, E));
+    GESPMM_TRY(sc.get(&cptr, (int64_t)lv.C + 1));
+    if (n_of) GESPMM_TRY(sc.get(&cw, E));
+    sc.use(Scratch::kTemp);
+    const size_t m = sc.mark();
     GESPMM_TRY(sc.get(&iota, E));
     GESPMM_TRY(sc.get(&keys_out, E));
     GESPMM_TRY(sc.get(&order, E));
-    GESPMM_TRY(sc.get(&cidx, E));
-    GESPMM_TRY(sc.get(&cptr, (int64_t)lv.C + 1));
     hipLaunchKernelGGL(k_iota, dim3(grid_for(E)), dim3(256), 0, st, iota, E);
     GESPMM_TRY(sort_pairs<int32_t>(sc, lv.rows.idx, keys_out, iota, order, E, bits_for(lv.C), st));
-    if (n_of) {
-        GESPMM_TRY(sc.get(&cw, E));
-        hipLaunchKernelGGL(k_gather2, dim3(grid_for(E)), dim3(256), 0, st, n_of, lv.rows.w, order, (int)E, cidx, cw);
-    } else {
-        hipLaunchKernelGGL(k_gather_rows_of, dim3(grid_for(E)), dim3(256), 0, st, lv.rows.ptr, lv.R, order, (int)E, cidx);
-    }
+    if (n_of) hipLaunchKernelGGL(k_gather2, dim3(grid_for(E)), dim3(256), 0, st, n_of, lv.rows.w, order, (int)E, cidx, cw);
+    else hipLaunchKernelGGL(k_gather_rows_of, dim3(grid_for(E)), dim3(256), 0, st, lv.rows.ptr, lv.R, order, (int)E, cidx);
     hipLaunchKernelGGL(k_lower_bound_ptr, dim3(grid_for((int64_t)lv.C + 1)), dim3(256), 0, st, keys_out, (int)E, lv.C,
                        cptr);
     GESPMM_TRY(hipGetLastError());
-    sc.release(iota);
-    sc.release(keys_out);
-    sc.release(order);
+    sc.rewind(Scratch::kTemp, m);
     lv.cols.ptr = cptr;
     lv.cols.idx = cidx;
     lv.cols.w = cw;
-    lv.owned.push_back(cptr);
-    lv.owned.push_back(cidx);
-    if (cw) lv.owned.push_back(cw);
     return hipSuccess;
 }
 
@@ -917,6 +985,7 @@ hipError_t launch_half_sweep(const LpArgs& base, const int32_t* lists, const int
 hipError_t device_validate_csr(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
                                int32_t* max_degree_host, int32_t* bad_host, hipStream_t st) {
     Scratch sc(st);
+    GESPMM_TRY(sc.init(0, 0, 1024));
     int32_t* out = nullptr;
     GESPMM_TRY(sc.get(&out, 2));
     GESPMM_TRY(hipMemsetAsync(out, 0, 8, st));
@@ -934,16 +1003,23 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
                                const ClusterOptions& opt, int32_t* perm, ClusterStats* stats, hipStream_t st) {
     if (stats) *stats = ClusterStats{};
     if (M <= 0) return hipSuccess;
-    Scratch sc(st);
     if (nnz <= 0) {
         hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
         return hipGetLastError();
     }
-
-    auto release_level = [&](DLevel& l) {
-        for (void* p : l.owned) sc.release(p);
-        l.owned.clear();
-    };
+    Scratch sc(st);
+    {
+        // region sizes (upper bounds for level 0, every later level is smaller; see Scratch for what happens beyond them)
+        size_t sort_tmp = 0;
+        (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_tmp, (const unsigned long long*)nullptr,
+                                                    (unsigned long long*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                                    (size_t)nnz, 0u, 64u, st);
+        const size_t E = (size_t)nnz, V = (size_t)(M + K);
+        const size_t persist = 4 * (3 * (size_t)M + 4096);
+        const size_t level = 4 * (4 * E + 2 * V + 64) + 16 * 256;
+        const size_t temp = 48 * E + 40 * V + 2 * sort_tmp + (1 << 20);
+        GESPMM_TRY(sc.init(persist, level, temp));
+    }
 
     // ---- level 0: the matrix itself (rows = the caller's CSR), its transpose, unit weights
     DLevel lv;
@@ -952,24 +1028,26 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
     lv.E = nnz;
     lv.rows.ptr = rowptr;
     lv.rows.idx = colind;
+    lv.region = Scratch::kLevelA;
     GESPMM_TRY(build_cols(sc, lv, nullptr, st));
     {
         int32_t* rw = nullptr;
+        sc.use(lv.region);
         GESPMM_TRY(sc.get(&rw, M));
         hipLaunchKernelGGL(k_fill, dim3(grid_for(M)), dim3(256), 0, st, rw, M, 1);
         lv.rweight = rw;
-        lv.owned.push_back(rw);
     }
     // parents[l][c] = node of level l + 1 that node c of level l belongs to (level 0: c = original row)
     std::vector<int32_t*> parents;
     std::vector<int32_t> parent_count;  // nodes of level l (length of parents[l])
     std::vector<int32_t> cluster_count; // nodes of level l + 1
 
-    int32_t* flags_dev = nullptr;  // {done, changed, ticket, -, counts_rows[4], counts_cols[4], R2, C2}
+    int32_t* flags_dev = nullptr;  // {done, changed, ticket, -, counts_rows[4], counts_cols[4], -}
+    sc.use(Scratch::kPersist);
     GESPMM_TRY(sc.get(&flags_dev, 16));
 
     long long cap = opt.first_cap > 0 ? opt.first_cap : 256;
-    const int max_levels = opt.max_levels > 0 ? opt.max_levels : 10;
+    const int max_levels = opt.max_levels > 0 ? opt.max_levels : kDefaultClusterLevels;
     const int sweeps = opt.sweeps > 0 ? opt.sweeps : 5;
     const int stop_percent = opt.stop_percent > 0 ? opt.stop_percent : 97;
 
@@ -987,22 +1065,21 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         const int32_t R = lv.R, C = lv.C;
         if (R <= 1 || lv.E == 0) break;
         lap("(cols/setup)", level);
+        sc.reset(Scratch::kTemp);
+        sc.use(Scratch::kTemp);
         int32_t *rlab = nullptr, *clab = nullptr, *rnext = nullptr, *cnext = nullptr, *size = nullptr, *rlists = nullptr,
                 *clists = nullptr;
         GESPMM_TRY(sc.get(&rlab, R));
-        GESPMM_TRY(sc.get(&rnext, R));
         GESPMM_TRY(sc.get(&clab, C));
+        const size_t after_labels = sc.mark();
+        GESPMM_TRY(sc.get(&rnext, R));
         GESPMM_TRY(sc.get(&cnext, C));
         GESPMM_TRY(sc.get(&size, R));
         GESPMM_TRY(sc.get(&rlists, (int64_t)kBins * R));
         GESPMM_TRY(sc.get(&clists, (int64_t)kBins * C));
         // every row node starts as its own label; a node that never moves keeps next == cur for the whole level
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(R)), dim3(256), 0, st, rlab, (int64_t)R);
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(R)), dim3(256), 0, st, rnext, (int64_t)R);
-        hipLaunchKernelGGL(k_fill, dim3(grid_for(C)), dim3(256), 0, st, clab, (int64_t)C, -1);
-        hipLaunchKernelGGL(k_fill, dim3(grid_for(C)), dim3(256), 0, st, cnext, (int64_t)C, -1);
-        GESPMM_TRY(hipMemcpyAsync(size, lv.rweight, (size_t)R * 4, hipMemcpyDeviceToDevice, st));  // label r owns node r
-        GESPMM_TRY(hipMemsetAsync(flags_dev, 0, 16 * 4, st));
+        hipLaunchKernelGGL(k_level_init, dim3(grid_for(std::max(R, C))), dim3(256), 0, st, rlab, rnext, size, lv.rweight, R, clab,
+                           cnext, C, flags_dev);
         int32_t* done = flags_dev;
         int32_t* changed = flags_dev + 1;
         int32_t* ticket = flags_dev + 2;
@@ -1058,37 +1135,34 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             GESPMM_TRY(hipGetLastError());
         }
         lap("sweeps", level);
-        sc.release(rnext);
-        sc.release(cnext);
-        sc.release(size);
-        sc.release(rlists);
-        sc.release(clists);
-        if (acc) sc.release(acc);
+        sc.rewind(Scratch::kTemp, after_labels);  // rlab / clab stay
 
         // ---- contract: compact row labels -> new row nodes, column labels -> new column nodes
         int32_t *used = nullptr, *pos = nullptr, *rid = nullptr, *cid = nullptr, *parent = nullptr;
         const int64_t R1 = (int64_t)R + 1;
-        GESPMM_TRY(sc.get(&used, 2 * R1));
-        GESPMM_TRY(sc.get(&pos, 2 * R1));
+        sc.use(Scratch::kPersist);
+        GESPMM_TRY(sc.get(&parent, R));
+        sc.use(Scratch::kTemp);
         GESPMM_TRY(sc.get(&rid, R));
         GESPMM_TRY(sc.get(&cid, R));
-        GESPMM_TRY(sc.get(&parent, R));
+        const size_t after_ids = sc.mark();
+        GESPMM_TRY(sc.get(&used, 2 * R1));
+        GESPMM_TRY(sc.get(&pos, 2 * R1));
         GESPMM_TRY(hipMemsetAsync(used, 0, (size_t)(2 * R1) * 4, st));
         hipLaunchKernelGGL(k_mark_used, dim3(grid_for(std::max(R, C))), dim3(256), 0, st, (const int32_t*)rlab, R,
                            (const int32_t*)clab, C, used, used + R1);
-        GESPMM_TRY(exclusive_scan<int32_t>(sc, used, pos, R1, st));
-        GESPMM_TRY(exclusive_scan<int32_t>(sc, used + R1, pos + R1, R1, st));
-        hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)used, (const int32_t*)pos, R, rid);
-        hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)(used + R1),
-                           (const int32_t*)(pos + R1), R, cid);
+        GESPMM_TRY(exclusive_scan<int32_t>(sc, used, pos, 2 * R1, st));  // one scan over both halves: the second half's
+                                                                        // positions are offset by the first half's total
+        hipLaunchKernelGGL(k_make_ids, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)used, (const int32_t*)pos,
+                           (const int32_t*)(pos + R), R, rid, cid);
         hipLaunchKernelGGL(k_parents, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab, (const int32_t*)rid, R, parent);
         GESPMM_TRY(hipGetLastError());
-        int32_t R2 = 0, C2 = 0;
-        GESPMM_TRY(hipMemcpyAsync(&R2, pos + R, 4, hipMemcpyDeviceToHost, st));
-        GESPMM_TRY(hipMemcpyAsync(&C2, pos + R1 + R, 4, hipMemcpyDeviceToHost, st));
+        int32_t tot[2] = {0, 0};  // pos[R] = #row labels in use, pos[2 R1 - 1] = that + #column labels in use
+        GESPMM_TRY(hipMemcpyAsync(&tot[0], pos + R, 4, hipMemcpyDeviceToHost, st));
+        GESPMM_TRY(hipMemcpyAsync(&tot[1], pos + 2 * R1 - 1, 4, hipMemcpyDeviceToHost, st));
         GESPMM_TRY(hipStreamSynchronize(st));
-        sc.release(used);
-        sc.release(pos);
+        const int32_t R2 = tot[0], C2 = tot[1] - tot[0];
+        sc.rewind(Scratch::kTemp, after_ids);
         parents.push_back(parent);
         parent_count.push_back(R);
         cluster_count.push_back(R2);
@@ -1096,32 +1170,27 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             stats->levels = level + 1;
             if (level < 16) stats->clusters[level] = R2;
         }
-        const bool last = (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * stop_percent || level + 1 >= max_levels);
-        if (last) {
-            sc.release(rlab);
-            sc.release(clab);
-            sc.release(rid);
-            sc.release(cid);
-            break;
-        }
-
         lap("relabel", level);
+        const bool last = (R2 <= 8 || (int64_t)R2 * 100 > (int64_t)R * stop_percent || level + 1 >= max_levels);
+        if (last) break;
+
         // ---- the next level: members' weights, twins, merged adjacency over the new column nodes
         DLevel nx;
         nx.R = R2;
         nx.C = C2;
+        nx.region = lv.region == Scratch::kLevelA ? Scratch::kLevelB : Scratch::kLevelA;
+        sc.reset(nx.region);
         int32_t *rw2 = nullptr, *twin2 = nullptr;
+        sc.use(nx.region);
         GESPMM_TRY(sc.get(&rw2, R2));
         GESPMM_TRY(sc.get(&twin2, C2));
-        GESPMM_TRY(hipMemsetAsync(rw2, 0, (size_t)R2 * 4, st));
-        hipLaunchKernelGGL(k_fill, dim3(grid_for(C2)), dim3(256), 0, st, twin2, (int64_t)C2, -1);
+        sc.use(Scratch::kTemp);
+        hipLaunchKernelGGL(k_fill2, dim3(grid_for(std::max(R2, C2))), dim3(256), 0, st, rw2, (int64_t)R2, 0, twin2, (int64_t)C2, -1);
         hipLaunchKernelGGL(k_new_weights, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rlab, (const int32_t*)rid,
                            lv.rweight, R, rw2);
         hipLaunchKernelGGL(k_new_twin, dim3(grid_for(R)), dim3(256), 0, st, (const int32_t*)rid, (const int32_t*)cid, R, twin2);
         nx.rweight = rw2;
         nx.twin = twin2;
-        nx.owned.push_back(rw2);
-        nx.owned.push_back(twin2);
         const int64_t E = lv.E;
         const int shift = bits_for(C2);
         unsigned long long *keys = nullptr, *keys_sorted = nullptr;
@@ -1136,12 +1205,6 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         GESPMM_TRY(hipGetLastError());
         GESPMM_TRY(sort_pairs<unsigned long long>(sc, keys, keys_sorted, vals, vals_sorted, E,
                                                   shift + bits_for((int64_t)R2 + 1), st));
-        sc.release(keys);
-        sc.release(vals);
-        sc.release(rlab);
-        sc.release(clab);
-        sc.release(rid);
-        sc.release(cid);
         GESPMM_TRY(sc.get(&hflags, E + 1));
         GESPMM_TRY(sc.get(&uid, E + 1));
         hipLaunchKernelGGL(k_heads, dim3(grid_for(E + 1)), dim3(256), 0, st, (const unsigned long long*)keys_sorted, (int)E,
@@ -1155,11 +1218,13 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         const int64_t E2 = ((int64_t)(last_key >> shift) >= R2) ? U - 1 : U;
         int32_t *n_of = nullptr, *idx2 = nullptr, *w2 = nullptr, *ptr2 = nullptr;
         unsigned long long* totals = nullptr;
-        GESPMM_TRY(sc.get(&n_of, E2));
+        sc.use(nx.region);
         GESPMM_TRY(sc.get(&idx2, E2));
         GESPMM_TRY(sc.get(&w2, E2));
-        GESPMM_TRY(sc.get(&totals, E2));
         GESPMM_TRY(sc.get(&ptr2, (int64_t)R2 + 1));
+        sc.use(Scratch::kTemp);
+        GESPMM_TRY(sc.get(&n_of, E2));
+        GESPMM_TRY(sc.get(&totals, E2));
         GESPMM_TRY(hipMemsetAsync(totals, 0, (size_t)(E2 > 0 ? E2 : 1) * 8, st));
         hipLaunchKernelGGL(k_run_sums, dim3(grid_for(E)), dim3(256), 0, st, (const unsigned long long*)keys_sorted,
                            (const int32_t*)vals_sorted, (const int32_t*)hflags, (const int32_t*)uid, (int)E, R2, shift, n_of,
@@ -1170,56 +1235,47 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         hipLaunchKernelGGL(k_lower_bound_ptr, dim3(grid_for((int64_t)R2 + 1)), dim3(256), 0, st, (const int32_t*)n_of,
                            (int)E2, R2, ptr2);
         GESPMM_TRY(hipGetLastError());
-        sc.release(keys_sorted);
-        sc.release(vals_sorted);
-        sc.release(hflags);
-        sc.release(uid);
-        sc.release(totals);
         nx.E = E2;
         nx.rows.ptr = ptr2;
         nx.rows.idx = idx2;
         nx.rows.w = w2;
-        nx.owned.push_back(ptr2);
-        nx.owned.push_back(idx2);
-        nx.owned.push_back(w2);
         if (E2 > 0) GESPMM_TRY(build_cols(sc, nx, n_of, st));
-        sc.release(n_of);
         lap("contract", level);
-        release_level(lv);
-        lv = nx;
+        lv = nx;  // the old level's region is rewound when the level after this one is built
         cap *= opt.cap_growth > 1 ? opt.cap_growth : 4;
     }
-    release_level(lv);
 
     // ---- order = lexicographic by (coarsest cluster, ..., finest cluster, original row id). The clusters nest, so it
     //      is enough to rank the clusters of each level top-down — a stable sort of the level's clusters by the rank of
     //      their parent — and finally sort the rows by the rank of their finest cluster (stable: ascending row ids).
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
-    if (!parents.empty()) {
+    sc.reset(Scratch::kTemp);
+    sc.use(Scratch::kTemp);
+    if (parents.empty()) {
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
+    } else {
         const int L = (int)parents.size();
         int32_t* rank = nullptr;  // rank of the nodes of level l + 1 (nullptr: their ids)
+        int32_t* rank_buf[2] = {nullptr, nullptr};
+        GESPMM_TRY(sc.get(&rank_buf[0], parent_count[0]));
+        GESPMM_TRY(sc.get(&rank_buf[1], parent_count[0]));
         for (int l = L - 1; l >= 0; --l) {
             const int64_t n = parent_count[l];  // nodes of level l (l == 0: the rows)
+            const size_t m = sc.mark();
             int32_t *keys = nullptr, *keys_out = nullptr, *ids = nullptr, *ids_out = nullptr;
             GESPMM_TRY(sc.get(&keys, n));
             GESPMM_TRY(sc.get(&keys_out, n));
             GESPMM_TRY(sc.get(&ids, n));
             hipLaunchKernelGGL(k_parent_rank, dim3(grid_for(n)), dim3(256), 0, st, (const int32_t*)parents[l],
-                               (const int32_t*)rank, n, keys);
-            hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(256), 0, st, ids, n);
+                               (const int32_t*)rank, n, keys, ids);
             if (l == 0) ids_out = perm;
             else GESPMM_TRY(sc.get(&ids_out, n));
             GESPMM_TRY(sort_pairs<int32_t>(sc, keys, keys_out, ids, ids_out, n, bits_for(cluster_count[l]), st));
-            sc.release(keys);
-            sc.release(keys_out);
-            sc.release(ids);
-            if (rank) sc.release(rank);
-            rank = nullptr;
             if (l > 0) {
-                GESPMM_TRY(sc.get(&rank, n));
-                hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(256), 0, st, (const int32_t*)ids_out, n, rank);
-                sc.release(ids_out);
+                int32_t* nr = rank_buf[l & 1];
+                hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(256), 0, st, (const int32_t*)ids_out, n, nr);
+                rank = nr;
             }
+            sc.rewind(Scratch::kTemp, m);
         }
     }
     GESPMM_TRY(hipGetLastError());
@@ -1231,6 +1287,7 @@ hipError_t device_permute_csr(int64_t M, int64_t nnz, const int32_t* rowptr, con
                               int32_t* rowptr_p, int32_t* colind_p, int32_t* src_begin, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     Scratch sc(st);
+    GESPMM_TRY(sc.init(0, 0, 4 * (size_t)(M + 1) + (4 << 20)));
     int32_t* deg = nullptr;
     GESPMM_TRY(sc.get(&deg, M + 1));
     hipLaunchKernelGGL(k_perm_degrees, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr, perm, M, deg, src_begin);
@@ -1247,6 +1304,12 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
     *hits_host = 0.0;
     if (M <= 0 || K <= 0 || nnz <= 0 || slices < 1 || slices > 16 || window < 1) return hipSuccess;
     Scratch sc(st);
+    {
+        size_t sort_tmp = 0;
+        (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_tmp, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                                    (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)nnz, 0u, 32u, st);
+        GESPMM_TRY(sc.init(0, 0, 20 * (size_t)nnz + 2 * sort_tmp + (1 << 20)));
+    }
     SliceInfo* info = nullptr;
     GESPMM_TRY(sc.get(&info, 1));
     hipLaunchKernelGGL(k_slice_bounds, dim3(1), dim3(64), 0, st, rowptr, (int)M, (int)nnz, slices,
@@ -1256,19 +1319,19 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
     int64_t total = 0;
     for (int s = 0; s < slices; ++s) total += h.end[s] - h.begin[s];
     if (total <= 0) return hipSuccess;
-    const int posbits = bits_for(nnz);
-    unsigned long long *keys = nullptr, *sorted = nullptr;
-    int32_t *prev = nullptr, *cnt = nullptr;
-    GESPMM_TRY(sc.get(&keys, total));
-    GESPMM_TRY(sc.get(&sorted, total));
+    int32_t *cols = nullptr, *poss = nullptr, *cols_sorted = nullptr, *pos_sorted = nullptr, *prev = nullptr, *cnt = nullptr;
+    GESPMM_TRY(sc.get(&cols, total));
+    GESPMM_TRY(sc.get(&poss, total));
+    GESPMM_TRY(sc.get(&cols_sorted, total));
+    GESPMM_TRY(sc.get(&pos_sorted, total));
     GESPMM_TRY(sc.get(&prev, nnz));
     GESPMM_TRY(sc.get(&cnt, 32));
     GESPMM_TRY(hipMemsetAsync(cnt, 0, 32 * 4, st));
-    hipLaunchKernelGGL(k_model_keys, dim3(grid_for(total)), dim3(256), 0, st, colind, (const SliceInfo*)info, slices,
-                       posbits, total, keys);
-    GESPMM_TRY(sort_keys64(sc, keys, sorted, total, posbits + bits_for(K), st));
-    hipLaunchKernelGGL(k_model_prev, dim3(grid_for(total)), dim3(256), 0, st, (const unsigned long long*)sorted, total,
-                       posbits, prev);
+    hipLaunchKernelGGL(k_model_keys, dim3(grid_for(total)), dim3(256), 0, st, colind, (const SliceInfo*)info, slices, total,
+                       cols, poss);
+    GESPMM_TRY(sort_pairs<int32_t>(sc, cols, cols_sorted, poss, pos_sorted, total, bits_for(K), st));
+    hipLaunchKernelGGL(k_model_prev, dim3(grid_for(total)), dim3(256), 0, st, (const int32_t*)cols_sorted,
+                       (const int32_t*)pos_sorted, total, prev);
     hipLaunchKernelGGL(k_model_sample, dim3((unsigned)samples_per_slice, (unsigned)slices), dim3(64), 0, st,
                        (const int32_t*)prev, (const SliceInfo*)info, slices, samples_per_slice, (long long)window, cnt,
                        cnt + 16);
@@ -1282,45 +1345,63 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
     return hipSuccess;
 }
 
-hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, int64_t budget, int64_t row_floor, int32_t** tasks,
-                            int32_t* ntasks_host, hipStream_t st) {
-    *tasks = nullptr;
-    *ntasks_host = 0;
+hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t budget[2], const int64_t row_floor[2],
+                            int32_t* tasks[2], int32_t ntasks_host[2], hipStream_t st) {
+    tasks[0] = tasks[1] = nullptr;
+    ntasks_host[0] = ntasks_host[1] = 0;
     if (M <= 0) return hipSuccess;
     Scratch sc(st);
+    const int64_t nblk = (M + kCutBlock - 1) / kCutBlock;
+    GESPMM_TRY(sc.init(0, 0, 48 * (size_t)(M + 1) + 8 * (size_t)nblk * (kMaxRowsPerWave + 1) + (4 << 20)));
+    CutParams cp;
+    for (int v = 0; v < 2; ++v) {
+        cp.budget[v] = budget[v];
+        cp.row_floor[v] = row_floor[v];
+    }
     long long *cost = nullptr, *P = nullptr;
     int32_t *next = nullptr, *exits = nullptr, *entry = nullptr, *flags = nullptr, *tid_of = nullptr;
-    const int64_t nblk = (M + kCutBlock - 1) / kCutBlock;
-    GESPMM_TRY(sc.get(&cost, M + 1));
-    GESPMM_TRY(sc.get(&P, M + 1));
-    GESPMM_TRY(sc.get(&next, M));
-    GESPMM_TRY(sc.get(&exits, nblk * kMaxRowsPerWave));
-    GESPMM_TRY(sc.get(&entry, nblk));
-    GESPMM_TRY(sc.get(&flags, M + 1));
-    GESPMM_TRY(sc.get(&tid_of, M + 1));
-    hipLaunchKernelGGL(k_row_costs, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr_p, M, (long long)row_floor, cost);
-    GESPMM_TRY(exclusive_scan<long long>(sc, cost, P, M + 1, st));
-    hipLaunchKernelGGL(k_task_next, dim3(grid_for(M)), dim3(256), 0, st, (const long long*)P, M, (long long)budget, next);
-    hipLaunchKernelGGL(k_task_exits, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)next, M, exits);
-    hipLaunchKernelGGL(k_task_entries, dim3(1), dim3(64), 0, st, (const int32_t*)exits, nblk, entry);
-    GESPMM_TRY(hipMemsetAsync(flags, 0, (size_t)(M + 1) * 4, st));
-    hipLaunchKernelGGL(k_task_mark, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)next, (const int32_t*)entry, M,
-                       flags);
-    GESPMM_TRY(exclusive_scan<int32_t>(sc, flags, tid_of, M + 1, st));
-    int32_t nt = 0;
-    GESPMM_TRY(fetch(&nt, (const int32_t*)(tid_of + M), 1, st));
+    GESPMM_TRY(sc.get(&cost, 2 * (M + 1)));
+    GESPMM_TRY(sc.get(&P, 2 * (M + 1)));
+    GESPMM_TRY(sc.get(&next, 2 * M));
+    GESPMM_TRY(sc.get(&exits, 2 * nblk * kMaxRowsPerWave));
+    GESPMM_TRY(sc.get(&entry, 2 * nblk));
+    GESPMM_TRY(sc.get(&flags, 2 * (M + 1)));
+    GESPMM_TRY(sc.get(&tid_of, 2 * (M + 1)));
+    hipLaunchKernelGGL(k_row_costs, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr_p, M, cp, cost);
+    // one scan over both variants: the second prefix carries the first one's total, which cancels in P[j] - P[i]
+    GESPMM_TRY(exclusive_scan<long long>(sc, cost, P, 2 * (M + 1), st));
+    hipLaunchKernelGGL(k_task_next, dim3(grid_for(M), 2), dim3(256), 0, st, (const long long*)P, M, cp, next);
+    hipLaunchKernelGGL(k_task_exits, dim3((unsigned)nblk, 2), dim3(256), 0, st, (const int32_t*)next, M, nblk, exits);
+    hipLaunchKernelGGL(k_task_entries, dim3(2), dim3(256), 0, st, (const int32_t*)exits, nblk, entry);
+    GESPMM_TRY(hipMemsetAsync(flags, 0, (size_t)(2 * (M + 1)) * 4, st));
+    hipLaunchKernelGGL(k_task_mark, dim3((unsigned)nblk, 2), dim3(256), 0, st, (const int32_t*)next, (const int32_t*)entry, M,
+                       nblk, flags);
+    GESPMM_TRY(exclusive_scan<int32_t>(sc, flags, tid_of, 2 * (M + 1), st));  // second half offset by the first table's size
+    int32_t tot[2] = {0, 0};
+    GESPMM_TRY(hipMemcpyAsync(&tot[0], tid_of + M, 4, hipMemcpyDeviceToHost, st));
+    GESPMM_TRY(hipMemcpyAsync(&tot[1], tid_of + 2 * (M + 1) - 1, 4, hipMemcpyDeviceToHost, st));
+    GESPMM_TRY(hipStreamSynchronize(st));
+    const int32_t nt[2] = {tot[0], tot[1] - tot[0]};
+    // ONE allocation for both tables (the first owns it); int4-aligned halves
+    const size_t n0 = ((size_t)(nt[0] > 0 ? nt[0] : 1) + 15) & ~(size_t)15;
     int32_t* out = nullptr;
-    GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)(nt > 0 ? nt : 1) * 16));
+    GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&out), (n0 + (size_t)(nt[1] > 0 ? nt[1] : 1)) * 16));
     hipLaunchKernelGGL(k_task_write, dim3(grid_for(M)), dim3(256), 0, st, (const int32_t*)flags, (const int32_t*)tid_of,
                        (const int32_t*)next, rowptr_p, M, out);
+    // the second table's ids start at nt[0]: shift the base pointer so that id nt[0] lands on its first slot
+    hipLaunchKernelGGL(k_task_write, dim3(grid_for(M)), dim3(256), 0, st, (const int32_t*)(flags + (M + 1)),
+                       (const int32_t*)(tid_of + (M + 1)), (const int32_t*)(next + M), rowptr_p, M,
+                       out + 4 * ((int64_t)n0 - nt[0]));
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         (void)hipFree(out);
         return e;
     }
-    *tasks = out;
-    *ntasks_host = nt;
+    tasks[0] = out;
+    tasks[1] = out + 4 * n0;
+    ntasks_host[0] = nt[0];
+    ntasks_host[1] = nt[1];
     return hipSuccess;
 }
 
