@@ -9,6 +9,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_fingerprint  # noqa: E402  (bench.py refuses to QUOTE an entry whose fingerprint is not the tree's)
+
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
 for arg in sys.argv[1:]:
@@ -22,6 +25,7 @@ for arg in sys.argv[1:]:
         "bytes_per_launch": int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)),
         "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4),
         "kernel": kern,
+        "csrc_sha16": csrc_fingerprint(),
         "source": "%s (2*FETCH_SIZE + WRITE_SIZE, KiB->B; separate --pmc passes of `python bench.py --no-extra --no-cpu-baseline "
                   "--steps 50 --warmup 5 ...`; memory-side requests include Infinity-Cache hits)" % os.path.relpath(f, ROOT),
     }
