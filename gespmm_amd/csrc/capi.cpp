@@ -87,6 +87,7 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
         flags |= gespmm::kFlagNoSlabBlocked;
         flags &= ~(gespmm::kFlagSlabBlocked | gespmm::kFlagSegStream | gespmm::kFlagBatchStream);
         flags |= (pl->prefer_segmented && pl->gtasks) ? gespmm::kFlagSegStream : gespmm::kFlagBatchStream;
+        flags &= ~gespmm::kFlagAllowReassoc;  // a plan runs the CRC family only (the parallel-reduction variant has no task table)
     }
     const int src = gespmm::resolve_geometry(M, K, N, nnz, variant, max_vec, cfg ? cfg->vec : 0,
                                              cfg ? cfg->strips : 0, cfg ? cfg->group : 0,
@@ -135,6 +136,9 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
         bool seg = sel.geo.segmented;
         if (flags & gespmm::kFlagBatchStream) seg = false;
         if ((flags & gespmm::kFlagSegStream) && !sel.geo.split_long_rows) seg = true;
+        // operands that are only 4- or 8-byte aligned resolve to a narrower vector; two strips of < 4 floats have no
+        // segmented-stream instantiation: a plan then runs its wavefront task table (any N and alignment stay legal)
+        if (seg && pl && sel.geo.strips == 2 && sel.geo.vec < 4) seg = false;
         if (seg) e = gespmm::launch_spmm_segstream(a, sel.geo, st);
         else {
             a.rpw = sel.geo.rows_per_wave;

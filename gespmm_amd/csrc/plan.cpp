@@ -62,6 +62,7 @@ struct gespmm_plan {
     // SDDMM through the plan (built on first use): edges in clustered order as COO with the ORIGINAL row ids, the
     // position of every edge in the caller's CSR, and a buffer for the results in clustered order
     int32_t* d_coo_row = nullptr;
+    int32_t* d_coo_row_storage = nullptr;  // storage-order plans: row id of every edge (the COO form skips the row search)
     int32_t* d_edge_dst = nullptr;
     float* d_sddmm_tmp = nullptr;
     int32_t task_entries = 0;
@@ -77,6 +78,7 @@ struct gespmm_plan {
     void* ws = nullptr;
     int64_t ws_bytes = 0;
     bool split_ready = false;
+    int split_vec = 0;               // vector width (operand alignment) the kept split points were computed for
     gespmm::ClusterStats stats;
     double analysis_seconds = 0.0, cluster_seconds = 0.0;
     double hits_before = -1.0, hits_after = -1.0;
@@ -112,6 +114,18 @@ __global__ void plan_edge_maps_kernel(const int32_t* __restrict__ rowptr_p, cons
     edge_dst[p] = src_begin[lo] + (p - rowptr_p[lo]);
 }
 
+__global__ void expand_rows_kernel(const int32_t* __restrict__ rowptr, int32_t* __restrict__ coo_row, int M, int nnz) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    int lo = 0, hi = M;  // rowptr[lo] <= p < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    coo_row[p] = lo;
+}
+
 __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int32_t* __restrict__ dst_index,
                                         float* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,11 +134,12 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 
 void free_device(gespmm_plan* p) {
     if (p->gtasks_shared) p->d_gtasks = nullptr;
-    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp, p->d_orecs, p->d_orec_src};
+    void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp, p->d_orecs, p->d_orec_src, p->d_coo_row_storage};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = p->d_tasks = p->d_recs = p->d_rec_src = p->d_gtasks = p->d_coo_row = p->d_edge_dst = nullptr;
     p->d_sddmm_tmp = nullptr;
+    p->d_coo_row_storage = nullptr;
     p->d_orecs = p->d_orec_src = nullptr;
     p->d_val = nullptr;
     p->ws = nullptr;
@@ -384,6 +399,12 @@ void build_outer_records(int64_t M, int64_t K, const std::vector<int32_t>& rp, c
     }
 }
 
+bool columns_in_range(const int32_t* colind, int64_t nnz, int64_t K) {
+    for (int64_t p = 0; p < nnz; ++p)
+        if ((uint32_t)colind[p] >= (uint64_t)K) return false;
+    return true;
+}
+
 // Experiment knobs (scripts/plan_time.py): GESPMM_CLUSTER_LEVELS / _SWEEPS / _STOP / _CAP override the clustering defaults.
 gespmm::ClusterOptions cluster_options_from_env() {
     gespmm::ClusterOptions o;
@@ -491,6 +512,7 @@ double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int
 int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                int32_t target, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out) {
     if (!rowptr || !perm || !recs_out || !nrec_out || M < 0 || K <= 0) return GESPMM_EINVAL;
+    if (M > 0 && !columns_in_range(colind, rowptr[M], K)) return GESPMM_EINVAL;  // the builders index scratch by column
     try {
         std::vector<int32_t> rp((size_t)M + 1, 0), src((size_t)M, 0), pv(perm, perm + M);
         for (int64_t i = 0; i < M; ++i) rp[i + 1] = rp[i] + (rowptr[perm[i] + 1] - rowptr[perm[i]]);
@@ -520,6 +542,7 @@ int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int
 int gespmm_debug_build_outer_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                      int32_t target, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out) {
     if (!rowptr || !perm || !recs_out || !nrec_out || M < 0 || K <= 0) return GESPMM_EINVAL;
+    if (M > 0 && !columns_in_range(colind, rowptr[M], K)) return GESPMM_EINVAL;  // the builders index scratch by column
     try {
         std::vector<int32_t> rp((size_t)M + 1, 0), src((size_t)M, 0), pv(perm, perm + M);
         for (int64_t i = 0; i < M; ++i) rp[i + 1] = rp[i] + (rowptr[perm[i] + 1] - rowptr[perm[i]]);
@@ -955,7 +978,13 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags};
     void* ws = (N == p->N) ? p->ws : nullptr;  // another width: the library's pool serves the scratch
     const int64_t ws_bytes = (N == p->N) ? p->ws_bytes : 0;
-    if (ws && p->split_ready) cfg.flags |= GESPMM_FLAG_REUSE_SPLIT;
+    // the slab geometry (rows per slab) depends on the vector width the operands' alignment allows: split points kept from
+    // a call with other alignment must not be reused
+    int vec_now = 4;
+    while (vec_now > 1 && ((N % vec_now) != 0 || (reinterpret_cast<uintptr_t>(B) % (4u * vec_now)) != 0 ||
+                           (reinterpret_cast<uintptr_t>(C) % (4u * vec_now)) != 0))
+        vec_now >>= 1;
+    if (ws && p->split_ready && p->split_vec == vec_now) cfg.flags |= GESPMM_FLAG_REUSE_SPLIT;
     int rc;
     const bool variant_v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 ||
                             p->variant == GESPMM_VARIANT_CRC_CWM8;
@@ -1004,7 +1033,10 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         rc = gespmm::run_spmm(p->rowptr, p->colind, p->valued ? p->val : nullptr, B, C, p->M, p->K, N, p->nnz, p->variant,
                               &cfg, reduce, empty, stream, ws, ws_bytes, nullptr);
     }
-    if (rc == 0 && ws) p->split_ready = true;
+    if (rc == 0 && ws) {
+        p->split_ready = true;
+        p->split_vec = vec_now;
+    }
     return rc;
 }
 
@@ -1029,19 +1061,51 @@ int gespmm_plan_sddmm_f32(gespmm_plan* p, const float* D1, const float* D2, floa
     // gathers and the rows are >= 256 bytes (com-Amazon-shaped communities, N = 128: 114 vs 151 us COO / 167 us CSR; on the
     // structureless graph or at N = 41 it is equal or slower — profiles/r02/sddmm_plan.log). Otherwise: the plain CSR
     // form on the caller's arrays (which must therefore still be alive).
-    if (!p->reordered || p->hits_after < 0.40 || N < 64)
-        return gespmm_sddmm_csr_f32(p->rowptr, p->colind, D1, D2, out, p->M, p->nnz, N, stream);
     hipError_t e = hipSuccess;
+    if (!p->reordered || p->hits_after < 0.40 || N < 64) {
+        // Short rows: the COO form on row ids expanded ONCE (the CSR form spends a row search per wavefront: 4-18 % on
+        // com-Amazon-shaped patterns, profiles/r03/sddmm_audit.log); same lane butterfly per edge, same bits. Long rows
+        // keep the CSR call, whose row-walking / cache-blocked forms need no row ids at all.
+        if (p->M > 0 && p->nnz / p->M < 32) {
+            if (!p->d_coo_row_storage) {
+                int32_t* rows = nullptr;
+                e = hipMalloc(reinterpret_cast<void**>(&rows), (size_t)p->nnz * 4);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->rowptr, rows,
+                                   (int)p->M, (int)p->nnz);
+                e = hipGetLastError();
+                if (e != hipSuccess) {
+                    (void)hipFree(rows);
+                    return (int)e;
+                }
+                p->d_coo_row_storage = rows;
+            }
+            return (int)gespmm::launch_sddmm(p->d_coo_row_storage, false, p->colind, D1, D2, out, p->M, p->nnz, N, 0, st);
+        }
+        return gespmm_sddmm_csr_f32(p->rowptr, p->colind, D1, D2, out, p->M, p->nnz, N, stream);
+    }
     if (!p->d_coo_row) {
         const size_t bytes = (size_t)p->nnz * 4;
-        e = hipMalloc(reinterpret_cast<void**>(&p->d_coo_row), bytes);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_edge_dst), bytes);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_sddmm_tmp), bytes);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(plan_edge_maps_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
-                           p->d_src_begin, p->d_perm, p->d_coo_row, p->d_edge_dst, (int)p->M, (int)p->nnz);
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
+        // all three buffers or none: a half-built set must not survive into the next call
+        int32_t *coo = nullptr, *dst = nullptr;
+        float* tmp = nullptr;
+        e = hipMalloc(reinterpret_cast<void**>(&coo), bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dst), bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tmp), bytes);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(plan_edge_maps_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
+                               p->d_src_begin, p->d_perm, coo, dst, (int)p->M, (int)p->nnz);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            if (coo) (void)hipFree(coo);
+            if (dst) (void)hipFree(dst);
+            if (tmp) (void)hipFree(tmp);
+            return (int)e;
+        }
+        p->d_coo_row = coo;
+        p->d_edge_dst = dst;
+        p->d_sddmm_tmp = tmp;
     }
     e = gespmm::launch_sddmm(p->d_coo_row, false, p->d_colind, D1, D2, p->d_sddmm_tmp, p->M, p->nnz, N, 0, st);
     if (e != hipSuccess) return (int)e;

@@ -41,15 +41,31 @@ __device__ __forceinline__ int row_of_edge(const int32_t* __restrict__ rowptr, i
     return lo;
 }
 
+// The same for a wavefront-uniform e, all 64 lanes probing at once: every round cuts [lo, hi) into 64 pieces with one
+// coalesced-ish load per lane and a ballot, so a matrix of 3 * 10^5 rows takes 4 dependent round trips instead of 18
+// (the prologue of every CSR-form wavefront: com-Amazon-shaped N = 128, CSR 166 -> COO's 148 us was this search).
+__device__ __forceinline__ int row_of_edge_wave(const int32_t* __restrict__ rowptr, int M, int e, int lane) {
+    int lo = 0, hi = M;  // invariant: rowptr[lo] <= e < rowptr[hi]
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + (lane + 1) * step;
+        const bool le = idx < hi && rowptr[idx] <= e;  // monotone in the lane: a prefix of the lanes says yes
+        const int cnt = __popcll(__ballot(le));
+        lo += cnt * step;
+        hi = (lo + step < hi) ? lo + step : hi;
+    }
+    return lo;
+}
+
 template <int V, int W, bool CSR>
 __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restrict__ rows,
                                                           const int32_t* __restrict__ colind,
                                                           const float* __restrict__ D1,
                                                           const float* __restrict__ D2, float* __restrict__ out,
-                                                          int M, int nnz, int N) {
+                                                          int M, int nnz, int N, int epw) {
     constexpr int G = 64 / W;
-    constexpr int EPW = 64;  // edges per wavefront (CSR form): G edges at a time, EPW/G rounds
-    constexpr int UE = 4;    // edges per lane group per step (COO form)
+    constexpr int EPW = 256;  // most edges a CSR-form wavefront owns (epw <= EPW): one row search per epw edges
+    constexpr int UE = 4;    // edges per lane group per step
     constexpr int IT = (V == 4) ? 2 : (V == 2) ? 4 : 8;  // vectors per lane that cover a row under launch_sddmm's width rule
     using T = typename SdVec<V>::type;
     const int lane = threadIdx.x & 63;
@@ -57,13 +73,55 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
     const int g = lane / W;
     const int l = lane % W;
 
-    if constexpr (!CSR) {
-        // UE consecutive edges per lane group: all 2*UE row slices are requested before any
-        // is used (for N <= W*V, i.e. one slice per row), so UE gathers are in flight per
-        // group instead of one.
-        const int ebase = ((blockIdx.x * kWaves + wave) * G + g) * UE;
+    // ---- the wavefront's edges [e_lo, e_hi) and where their (row, column) ids come from.
+    // COO form: G * UE consecutive edges, ids straight from the caller's arrays.
+    // CSR form: epw consecutive edges. ONE wavefront-wide search finds the row of the first edge; the rows of all
+    // its edges then lie in a window of at most epw + 1 row pointers, staged in LDS, where every lane resolves the
+    // row of one edge (the reference searches rowptr in global memory once per edge, computeUtil.h:11-28). After that
+    // both forms run the SAME loop: UE edges per lane group in flight, all slices requested before the first FMA.
+    __shared__ int s_rp[CSR ? kWaves : 1][CSR ? EPW + 2 : 1];
+    __shared__ int s_row[CSR ? kWaves : 1][CSR ? EPW : 1];
+    __shared__ int s_col[CSR ? kWaves : 1][CSR ? EPW : 1];
+    const int per_wave = CSR ? epw : G * UE;
+    const int e_lo = (blockIdx.x * kWaves + wave) * per_wave;
+    if (e_lo >= nnz) return;  // whole wavefront
+    const int e_hi = (e_lo + per_wave < nnz) ? e_lo + per_wave : nnz;
+    if constexpr (CSR) {
+        const int r0 = row_of_edge_wave(rows, M, e_lo, lane);
+        for (int i = lane; i < epw + 2; i += 64) s_rp[wave][i] = (r0 + i <= M) ? rows[r0 + i] : 0x7fffffff;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = e_lo + lane; e < e_hi; e += 64) {
+            int lo = 0;
+            if (s_rp[wave][1] <= e) {  // (long rows: the wavefront's edges usually lie inside ONE row — no search then)
+                // largest i in [0, epw + 1] with s_rp[i] <= e   (s_rp[0] = rowptr[r0] <= e_lo <= e)
+                int hi = epw + 1;
+                if (s_rp[wave][hi] <= e) {  // more than epw empty rows in the window: search the whole array
+                    lo = row_of_edge(rows, M, e) - r0;
+                    hi = lo + 1;
+                }
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_rp[wave][mid] <= e) lo = mid;
+                    else hi = mid;
+                }
+            }
+            s_row[wave][e - e_lo] = r0 + lo;
+            s_col[wave][e - e_lo] = colind[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    auto row_id = [&](int e) { return CSR ? s_row[wave][e - e_lo] : rows[e]; };
+    auto col_id = [&](int e) { return CSR ? s_col[wave][e - e_lo] : colind[e]; };
+
+    for (int rb = 0; rb < e_hi - e_lo; rb += G * UE) {  // (COO form: one round)
+        const int ebase = e_lo + rb + g * UE;
         float part[UE];
         if (N <= W * V) {
+            // one slice per row: all 2 * UE slices of the group's UE edges are requested before any is used
             T x[UE], y[UE];
             const int j = l * V;
 #pragma unroll
@@ -71,9 +129,9 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
                 const int e = ebase + u;
                 x[u] = T{};
                 y[u] = T{};
-                if (e < nnz && j < N) {
-                    x[u] = *reinterpret_cast<const T*>(D1 + (size_t)rows[e] * (size_t)N + j);
-                    y[u] = *reinterpret_cast<const T*>(D2 + (size_t)colind[e] * (size_t)N + j);
+                if (e < e_hi && j < N) {
+                    x[u] = *reinterpret_cast<const T*>(D1 + (size_t)row_id(e) * (size_t)N + j);
+                    y[u] = *reinterpret_cast<const T*>(D2 + (size_t)col_id(e) * (size_t)N + j);
                 }
             }
 #pragma unroll
@@ -94,9 +152,9 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
                 T x[2][IT], y[2][IT];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int e = (ebase + u0 + u < nnz) ? ebase + u0 + u : nnz - 1;
-                    const float* p1 = D1 + (size_t)rows[e] * (size_t)N;
-                    const float* p2 = D2 + (size_t)colind[e] * (size_t)N;
+                    const int e = (ebase + u0 + u < e_hi) ? ebase + u0 + u : e_hi - 1;
+                    const float* p1 = D1 + (size_t)row_id(e) * (size_t)N;
+                    const float* p2 = D2 + (size_t)col_id(e) * (size_t)N;
 #pragma unroll
                     for (int it = 0; it < IT; ++it) {
                         const int j = l * V + it * W * V;
@@ -126,9 +184,9 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
             for (int u = 0; u < UE; ++u) {
                 const int e = ebase + u;
                 part[u] = 0.0f;
-                if (e < nnz) {
-                    const float* p1 = D1 + (size_t)rows[e] * (size_t)N;
-                    const float* p2 = D2 + (size_t)colind[e] * (size_t)N;
+                if (e < e_hi) {
+                    const float* p1 = D1 + (size_t)row_id(e) * (size_t)N;
+                    const float* p2 = D2 + (size_t)col_id(e) * (size_t)N;
                     for (int j = l * V; j < N; j += W * V) {
                         const T x = *reinterpret_cast<const T*>(p1 + j);
                         const T y = *reinterpret_cast<const T*>(p2 + j);
@@ -146,107 +204,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_kernel(const int32_t* __restri
         for (int u = 0; u < UE; ++u) {
 #pragma unroll
             for (int m = W >> 1; m > 0; m >>= 1) part[u] += __shfl_xor(part[u], m, 64);
-            if (l == 0 && ebase + u < nnz) out[ebase + u] = part[u];
-        }
-    } else {
-        // CSR form: the wavefront owns EPW consecutive edges. ONE global binary search
-        // (wave-uniform) finds the row of its first edge; the rows of all its edges then
-        // lie in a window of at most EPW+1 row pointers, staged in LDS, and every group
-        // finds its edge's row there (the reference searches rowptr in global memory once
-        // per edge, computeUtil.h:11-28).
-        __shared__ int s_rp[kWaves][EPW + 2];
-        __shared__ int s_col[kWaves][EPW];
-        const int e0 = (blockIdx.x * kWaves + wave) * EPW;
-        if (e0 >= nnz) return;
-        const int e1 = (e0 + EPW < nnz) ? e0 + EPW : nnz;
-        const int r0 = row_of_edge(rows, M, e0);  // same address in every lane: broadcast loads
-        // rows r0 .. r0+EPW cover [e0, e1) unless empty rows intervene; rows past the window
-        // are found by continuing the search from the window's end
-        for (int i = lane; i < EPW + 2; i += 64) s_rp[wave][i] = (r0 + i <= M) ? rows[r0 + i] : 0x7fffffff;
-        if (e0 + lane < e1) s_col[wave][lane] = colind[e0 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // long rows: the wavefront's 64 edges usually lie inside ONE row — no per-edge search then
-        const bool single_row = s_rp[wave][1] >= e1;
-        auto row_of = [&](int e) {
-            if (single_row) return r0;
-            // largest i in [0, EPW+1] with s_rp[i] <= e   (s_rp[0] = rowptr[r0] <= e0 <= e)
-            int lo = 0, hi = EPW + 1;
-            if (s_rp[wave][hi] <= e) {  // more than EPW empty rows in the window: fall back
-                lo = row_of_edge(rows, M, e) - r0;
-                hi = lo + 1;
-            }
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_rp[wave][mid] <= e) lo = mid;
-                else hi = mid;
-            }
-            return r0 + lo;
-        };
-        if (N <= W * V * IT) {
-            // two edges per lane group and step, every slice requested before the first FMA
-            for (int e = e0 + g; e < e1; e += 2 * G) {
-                T x[2][IT], y[2][IT];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int ee = (e + u * G < e1) ? e + u * G : e;
-                    const float* p1 = D1 + (size_t)row_of(ee) * (size_t)N;
-                    const float* p2 = D2 + (size_t)s_col[wave][ee - e0] * (size_t)N;
-#pragma unroll
-                    for (int it = 0; it < IT; ++it) {
-                        const int j = l * V + it * W * V;
-                        x[u][it] = *reinterpret_cast<const T*>(p1 + (j < N ? j : 0));
-                        y[u][it] = *reinterpret_cast<const T*>(p2 + (j < N ? j : 0));
-                    }
-                }
-                float part[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    part[u] = 0.0f;
-#pragma unroll
-                    for (int it = 0; it < IT; ++it) {
-                        if (l * V + it * W * V < N) {
-                            if constexpr (V == 1) {
-                                part[u] = __builtin_fmaf(x[u][it], y[u][it], part[u]);
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < V; ++i) part[u] = __builtin_fmaf(x[u][it][i], y[u][it][i], part[u]);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int m = W >> 1; m > 0; m >>= 1) {
-                    part[0] += __shfl_xor(part[0], m, 64);
-                    part[1] += __shfl_xor(part[1], m, 64);
-                }
-                if (l == 0) {
-                    out[e] = part[0];
-                    if (e + G < e1) out[e + G] = part[1];
-                }
-            }
-        } else {
-            for (int e = e0 + g; e < e1; e += G) {
-                const int r = row_of(e);
-                const int c = s_col[wave][e - e0];
-                const float* p1 = D1 + (size_t)r * (size_t)N;
-                const float* p2 = D2 + (size_t)c * (size_t)N;
-                float part = 0.0f;
-                for (int j = l * V; j < N; j += W * V) {
-                    const T x = *reinterpret_cast<const T*>(p1 + j);
-                    const T y = *reinterpret_cast<const T*>(p2 + j);
-                    if constexpr (V == 1) {
-                        part = __builtin_fmaf(x, y, part);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < V; ++i) part = __builtin_fmaf(x[i], y[i], part);
-                    }
-                }
-#pragma unroll
-                for (int m = W >> 1; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
-                if (l == 0) out[e] = part;
-            }
+            if (l == 0 && ebase + u < e_hi) out[ebase + u] = part[u];
         }
     }
 }
@@ -386,10 +344,13 @@ static hipError_t sddmm_w(int W, const int32_t* rows, const int32_t* colind, con
 #define GESPMM_SD(WW)                                                                                         \
     case WW: {                                                                                                 \
         constexpr int G = 64 / WW;                                                                             \
-        constexpr int per_wave = CSR ? 64 : G * 4; /* edges per wavefront (COO: UE = 4 per group) */                                       \
+        /* edges per wavefront: COO G * UE (UE = 4); CSR 256 — one row search per 256 edges — unless that leaves \
+           the chip short of wavefronts (small patterns: pubmed-sized N = 128 ran 18.4 us against COO's 9.8) */   \
+        int per_wave = G * 4;                                                                                  \
+        if (CSR) per_wave = (nnz >= 256 * 16384) ? 256 : (nnz >= 64 * 16384) ? 64 : (G * 4 > 16 ? G * 4 : 16); \
         const int nblk = (int)(((int64_t)nnz + kWaves * per_wave - 1) / (kWaves * per_wave));                  \
         hipLaunchKernelGGL((sddmm_kernel<V, WW, CSR>), dim3(nblk), dim3(kThreads), 0, st, rows, colind, D1, D2, \
-                           out, M, nnz, N);                                                                    \
+                           out, M, nnz, N, per_wave);                                                          \
         return hipGetLastError();                                                                              \
     }
     switch (W) {

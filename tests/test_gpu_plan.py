@@ -212,3 +212,51 @@ def test_sddmm_through_a_plan_keeps_the_bits(pkg, bundled):
         grads.append((y.detach(), x.grad, ww.grad))
     for a, b in zip(*grads):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def _misaligned(t):
+    """Same values, storage shifted by one float: 4-byte aligned only."""
+    buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+    v = buf[1:].view(t.shape)
+    v.copy_(t)
+    assert v.data_ptr() % 16 != 0
+    return v
+
+
+@pytest.mark.parametrize("kernel", ("auto", "seg-stream", "stream"))
+def test_plans_accept_operands_that_are_only_4_byte_aligned(pkg, oracle, bundled, kernel):
+    """include/gespmm.h: any N and any 4-byte-aligned B / C are legal. A plan that prefers the segmented-stream kernel
+    used to fail (no instantiation for two strips of < 4 floats): it now runs its wavefront task table instead."""
+    from gespmm_amd import spmm
+
+    g = bundled["cora"]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=2)
+    val = _dev(val_h)
+    for N in (128, 200, 66, 12):
+        B_h = oracle.hash_B(g["K"], N, seed=N)
+        ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
+        plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True, kernel=kernel)
+        for B in (_dev(B_h), _misaligned(_dev(B_h))):
+            for out in (None, _misaligned(torch.empty(g["M"], N, device="cuda"))):
+                got = spmm.csr_spmm(rp, ci, val, B, plan=plan, out=out)
+                assert np.array_equal(bits(got.cpu().numpy()), bits(ref)), (kernel, N, B.data_ptr() % 16)
+
+
+def test_kept_split_points_are_not_reused_across_operand_alignments(pkg, oracle):
+    """Dense graph through a plan (cache-blocked path, split points kept in the plan's workspace): the slab geometry
+    depends on the vector width the operands' alignment allows, so a call with other alignment must rescan."""
+    from gespmm_amd import graphs, spmm
+
+    M, deg, N = 20_000, 200, 384
+    rp, ci = graphs.synthetic_csr(M, M * deg, symmetric=True, gamma=1.2, seed=9, device="cuda")
+    val = torch.rand(ci.numel(), device="cuda") - 0.5
+    B = (torch.randint(0, 100, (M, N), device="cuda", dtype=torch.int32) - 50).float() / 100
+    plan = spmm.SpmmPlan(rp, ci, M, N, values=val)
+    assert "slab" in plan.describe() or "blocked" in plan.describe(), plan.describe()
+    ref = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x800 | 0x100})  # streaming, strict order: the CSR-order chain
+    a = spmm.csr_spmm(rp, ci, val, B, plan=plan)            # aligned: scans and keeps the split points
+    b = spmm.csr_spmm(rp, ci, val, _misaligned(B), plan=plan)  # 4-byte aligned: another slab geometry
+    c = spmm.csr_spmm(rp, ci, val, B, plan=plan)            # aligned again
+    for got in (a, b, c):
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32))

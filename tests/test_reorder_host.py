@@ -323,3 +323,24 @@ def test_records_of_the_task_outer_kernel_reproduce_the_oracle(pkg, oracle):
     recs, _ = _outer_records(_lib.lib, rp, ci, M, K, np.arange(M, dtype=np.int32), 0)
     assert (recs[:, 0] > 1).sum() > 20, "rows are actually packed"
     assert (recs[:, 2] < recs[:, 1]).sum() > 10, "packed rows actually share columns"
+
+
+def test_record_builders_reject_out_of_range_columns(pkg):
+    """The host record builders index scratch arrays by column: an index outside [0, K) must be refused, not written."""
+    from gespmm_amd import _lib
+
+    lib = _lib.lib
+    rp = np.array([0, 2, 3], dtype=np.int32)
+    perm = np.array([1, 0], dtype=np.int32)
+    for bad in (np.array([0, 5, 1], dtype=np.int32), np.array([0, -1, 1], dtype=np.int32)):
+        for name in ("gespmm_debug_build_records", "gespmm_debug_build_outer_records"):
+            fn = getattr(lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                           ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)),
+                           ctypes.POINTER(ctypes.c_int32)]
+            recs = ctypes.POINTER(ctypes.c_int32)()
+            src = ctypes.POINTER(ctypes.c_int32)()
+            n = ctypes.c_int32(0)
+            rc = fn(rp.ctypes.data, bad.ctypes.data, 2, 4, perm.ctypes.data, 0, ctypes.byref(recs), ctypes.byref(src), ctypes.byref(n))
+            assert rc == -1, (name, rc)  # GESPMM_EINVAL
