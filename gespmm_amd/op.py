@@ -146,6 +146,10 @@ class GCNConv(torch.nn.Module):
             h = h * out_scale
         plans = None
         if self.cached:  # `cached` is the caller's promise of a static graph: keep the SpMM scratch as well
+            # Keyed on the addresses only. That is safe: the plans hold strong references to the index tensors they were
+            # made from, so those addresses cannot be recycled for another graph while the plans are alive, and SpmmPlan
+            # itself notices in-place edits of the pattern through the tensors' version counters (and raises). The analysis
+            # runs on the device: ~6 ms per direction for a com-Amazon-sized graph, ~0.1 ms for pubmed.
             key = (rowptr.data_ptr(), colind.data_ptr(), colptr.data_ptr(), rowind.data_ptr(), h.shape[1])
             if self.cached_plans is None or self.cached_plans[0] != key:
                 n = rowptr.numel() - 1

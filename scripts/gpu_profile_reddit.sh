@@ -4,7 +4,7 @@ set -x
 mkdir -p gpurun_out/prof_reddit
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-CMD="python scripts/exp10.py reddit-like 128 3"
+CMD="python profiles/r01/scripts/reddit_auto_path_for_rocprof.py reddit-like 128 3"
 P=/tmp/prof
 O=gpurun_out/prof_reddit
 rm -rf $P; mkdir -p $P
