@@ -8,7 +8,10 @@ A "step" is ONE launch of the hot path (C = A @ B, valued CSR x dense fp32) over
 synthetic input — what the reference's driver times 200x per width (spmm_test.cu:754-762).
 
 One GPU (the BENCH line): BASELINE.json configs[1], the com-Amazon-shaped graph (M = K = 334 863,
-nnz = 1 851 744) at feature width 128 as a seeded synthetic stand-in (no network: SURVEY.md §8 d4). Launches go
+nnz = 1 851 744) at feature width 128 as a seeded synthetic stand-in (no network: SURVEY.md §8 d4) — since round 3
+the planted-community stand-in `com-amazon-sbm` (clustering coefficient 0.408 against SNAP com-Amazon's 0.397, vertex ids
+shuffled); rounds 1-2's structureless `com-amazon-like` (clustering 4e-5) is measured beside it in `extra` with the
+same fields, so both series continue. Launches go
 through a gespmm plan (the analysis stage: row clustering + task table, built ONCE outside the timed region, its
 time reported as `plan_ms`; the plain entry point is timed beside it in `extra`). Inputs are resident in HBM
 before the timed region. `roofline.kernel_us` is the MEDIAN of >= 200 launches, each bracketed by its own pair
@@ -61,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ncols", type=int, default=0, help="feature width (default: 128 on one GPU, 256 for the RMAT run)")
     ap.add_argument("--graph", default=None,
-                    help="named stand-in (default on one GPU: com-amazon-like) or 'rmat' (default on several GPUs)")
+                    help="named stand-in (default on one GPU: com-amazon-sbm) or 'rmat' (default on several GPUs)")
     ap.add_argument("--rmat-scale", type=int, default=0, help="log2(vertices) of the RMAT graph (default 26, the north_star's)")
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--variant", type=int, default=-1)
@@ -92,7 +95,7 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
-    graph = args.graph or ("rmat" if world > 1 else "com-amazon-like")
+    graph = args.graph or ("rmat" if world > 1 else "com-amazon-sbm")
     strong = graph == "rmat"
     N = args.ncols or (256 if strong else 128)
 
@@ -288,16 +291,22 @@ def main():
                 extra["N%d_%s" % (n2, "valued" if valued else "unweighted")] = measure_graph(g, val, n2, valued, samples=50)
         extra["N%d_unweighted" % N] = measure_graph(g, val, N, False, samples=50)
 
-        if graph == "com-amazon-like" and args.locality == 0.0:
-            # ---- the structured stand-in: same M, nnz and degree law, planted communities (SNAP: 75 149 communities,
-            #      clustering 0.397), vertex ids SHUFFLED — any locality is found by the plan's clustering, not inherited
+        if graph in ("com-amazon-sbm", "com-amazon-like") and args.locality == 0.0:
+            # ---- the OTHER com-Amazon stand-in, same M and nnz, same fields as the headline, so that every round has both:
+            #      `com-amazon-sbm`  planted communities (SNAP: 75 149 communities, clustering 0.397; generated: 0.408), vertex
+            #                        ids SHUFFLED — any locality is found by the plan's clustering, not inherited (headline
+            #                        since round 3: it is the stand-in whose measured graph statistics match com-Amazon's);
+            #      `com-amazon-like` structureless (clustering 4e-5: an expander; rounds 1-2's headline, the adversarial case)
+            other = "com-amazon-like" if graph == "com-amazon-sbm" else "com-amazon-sbm"
             torch.cuda.empty_cache()
-            gs = graphs.synthetic_graph("com-amazon-sbm", seed=42, device=dev)
+            gs = graphs.synthetic_graph(other, seed=42, device=dev)
             r = measure_graph(gs, val, N, True)
-            r["traffic"], r["traffic_source"], r["l2_hit_rate"] = traffic_for("com-amazon-sbm/N%d/valued/plan" % N)
-            rp_ = measure_graph(gs, val, N, True, use_plan=False, samples=50)
+            r["traffic"], r["traffic_source"], r["l2_hit_rate"] = traffic_for("%s/N%d/valued/plan" % (other, N))
+            rp_ = measure_graph(gs, val, N, True, use_plan=False, samples=MIN_KERNEL_SAMPLES)
             r["plain_call_kernel_us"] = rp_["kernel_us"]
-            extra["com-amazon-sbm_N%d_valued" % N] = r
+            r["plain_call_gflops"] = rp_["gflops"]
+            r["plain_call_frac"] = rp_["frac"]
+            extra["%s_N%d_valued" % (other, N)] = r
             del gs
 
             # ---- the second graph of BASELINE configs[1]: reddit-shaped x N=128 (cache-blocked path), sampled rows verified
