@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import gespmm_amd
 from gespmm_amd import graphs, spmm
 
-names = sys.argv[1:] or ["com-amazon-like", "com-amazon-sbm", "products-sbm", "products-like"]
+names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["com-amazon-like", "com-amazon-sbm", "products-sbm", "products-like"]
 for name in names:
     g = graphs.synthetic_graph(name, seed=42, device="cuda")
     val = torch.rand(g["nnz"], device="cuda") - 0.5
