@@ -381,6 +381,35 @@ def main():
                 "note": "run_rmat() with world = 1: what the N > 1 SCALE lines call `one_gpu_reference`"}
             torch.cuda.empty_cache()
 
+        # ---- boundary #1 in the record: the `spmm_test` driver (reference CLI and protocol: 200 timed launches per width,
+        #      N in {128, 256, 512}, vendor column = rocSPARSE where the reference has cuSPARSE, spmm_test.cu:714-762) on the
+        #      headline graph written as a MatrixMarket file; default method (2, what the reference times) and AUTO through a plan
+        try:
+            import re
+            import subprocess
+            import tempfile
+
+            drv = os.path.join(ROOT, "gespmm_amd", "lib", "spmm_test")
+            if os.path.exists(drv):
+                with tempfile.TemporaryDirectory() as td:
+                    mtx = os.path.join(td, graph + ".mtx")
+                    graphs.write_mtx(mtx, g["rowptr"], g["colind"])
+                    rows_ = {}
+                    for label, more in (("method2_reference_default", []), ("auto_plan", ["--method", "-1", "--plan"])):
+                        r = subprocess.run([drv, mtx, str(local_rank), "--out", os.path.join(td, "csv.out"), "--seed", "1"] + more,
+                                           capture_output=True, text=True, timeout=600)
+                        rows_[label] = {
+                            "N%s" % m.group(1): {"ms_per_iter": float(m.group(2)), "gflops": float(m.group(3)),
+                                                 "rocsparse_gflops": float(m.group(4))}
+                            for m in re.finditer(r"N=(\d+) method=-?\d+[^:]*: ([0-9.]+) ms/iter, ([0-9.]+) GFLOP/s \(rocsparse ([0-9.]+) GFLOP/s\)",
+                                                 r.stdout)}
+                        rows_[label]["exit_status"] = r.returncode
+                    rows_["note"] = ("A == 1 as the reference's driver sets it (spmm_test.cu:574), B = rand()%100-50 with seed 1, host-side "
+                                     "load + upload outside the timed loops, 200 launches per figure")
+                    extra["driver_spmm_test"] = rows_
+        except Exception as ex:  # noqa: BLE001
+            extra["driver_spmm_test"] = {"skipped": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+
         # ---- the reference's own kernels on this MI355X (oracle/_ref/libref_kernels.so: spmm_test.cu compiled by hipcc
         #      as it is — a baseline leg, never the product): spmmWrapper(method 2, tile_row 8), what the reference times
         #      (spmm_test.cu:756), on the headline operands — A == 1 as its driver sets it, and with the bench's values
