@@ -665,7 +665,8 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
     }
     int user_flags = opt ? opt->flags : 0;
 
-    const int analysis = opt ? opt->analysis : GESPMM_PLAN_ANALYSIS_DEVICE;
+    int analysis = opt ? opt->analysis : GESPMM_PLAN_ANALYSIS_DEVICE;
+    if (const char* v = getenv("GESPMM_PLAN_ANALYSIS")) analysis = (v[0] == 'h') ? GESPMM_PLAN_ANALYSIS_HOST : GESPMM_PLAN_ANALYSIS_DEVICE;  // debugging aid
     if (analysis != GESPMM_PLAN_ANALYSIS_DEVICE && analysis != GESPMM_PLAN_ANALYSIS_HOST) {
         delete p;
         return GESPMM_EINVAL;

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -53,22 +54,83 @@ namespace {
         if (e__ != hipSuccess) return e__;     \
     } while (0)
 
-// Temporaries of one analysis call: ONE stream-ordered block from the library's pool, carved into bump regions
-// (a plan used to make ~250 pool calls; each costs microseconds of host time and, the first time a size is seen, a
-// real allocation). Regions: persistent for the call, two "level" regions that ping-pong between a level and the one
-// built from it, and a temporary region that is rewound at phase boundaries. A request that does not fit its region
-// falls back to a pool block of its own (correct, just slower), so the size estimates need not be tight.
+// Temporaries of one analysis call: ONE device block carved into bump regions (a plan used to make ~250 allocator calls;
+// each costs microseconds of host time and, the first time a size is seen, a real allocation). Regions: persistent for
+// the call, two "level" regions that ping-pong between a level and the one built from it, and a temporary region that
+// is rewound at phase boundaries. A request that does not fit its region gets a block of its own (correct, just
+// slower), so the size estimates need not be tight.
+//
+// The block comes from plain hipMalloc through a one-entry cache (blocks up to 512 MiB are kept for the next plan), NOT
+// from the library's stream-ordered pool: with hipMallocFromPoolAsync / hipFreeAsync cycles of changing sizes interleaved
+// with the plan's own hipMalloc calls, analysis results came out corrupted in processes without PyTorch's allocator in
+// them (the spmm_test driver: wrong task tables, then a memory fault in the first launch; profiles/r03/pool_hazard.log).
+// The analysis synchronises the stream anyway, so a synchronous free costs nothing here.
+constexpr size_t kArenaCacheCap = 512ull << 20;
+struct ArenaCache {
+    std::mutex lock;
+    void* block = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    bool busy = false;
+};
+ArenaCache g_arena;
+
+hipError_t arena_acquire(size_t bytes, void** out, bool* cached) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> guard(g_arena.lock);
+        if (!g_arena.busy) {
+            if (g_arena.block && (g_arena.device != dev || g_arena.bytes < bytes)) {
+                (void)hipFree(g_arena.block);
+                g_arena.block = nullptr;
+                g_arena.bytes = 0;
+            }
+            if (!g_arena.block && bytes <= kArenaCacheCap) {
+                e = hipMalloc(&g_arena.block, bytes);
+                if (e != hipSuccess) {
+                    g_arena.block = nullptr;
+                    return e;
+                }
+                g_arena.bytes = bytes;
+                g_arena.device = dev;
+            }
+            if (g_arena.block) {
+                g_arena.busy = true;
+                *out = g_arena.block;
+                *cached = true;
+                return hipSuccess;
+            }
+        }
+    }
+    *cached = false;  // larger than the cache keeps, or another thread is analysing: a private block
+    return hipMalloc(out, bytes);
+}
+
+void arena_release(void* p, bool cached) {
+    if (cached) {
+        std::lock_guard<std::mutex> guard(g_arena.lock);
+        g_arena.busy = false;
+    } else {
+        (void)hipFree(p);
+    }
+}
+
 struct Scratch {
     enum { kPersist = 0, kLevelA = 1, kLevelB = 2, kTemp = 3, kRegions = 4 };
     hipStream_t st;
     char* base = nullptr;
+    bool base_cached = false;
     size_t begin[kRegions] = {0, 0, 0, 0}, end[kRegions] = {0, 0, 0, 0}, top[kRegions] = {0, 0, 0, 0};
     int cur = kTemp;
     std::vector<void*> extras;
     explicit Scratch(hipStream_t s) : st(s) {}
     ~Scratch() {
-        for (void* b : extras) (void)workspace_free(b, st);
-        if (base) (void)workspace_free(base, st);
+        if (!base && extras.empty()) return;
+        (void)hipStreamSynchronize(st);  // everything that used these bytes has finished
+        for (void* b : extras) (void)hipFree(b);
+        if (base) arena_release(base, base_cached);
     }
     static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
     hipError_t init(size_t persist, size_t level, size_t temp) {
@@ -80,7 +142,7 @@ struct Scratch {
             end[r] = total;
         }
         void* p = nullptr;
-        hipError_t e = workspace_alloc(&p, total ? total : 256, st);
+        hipError_t e = arena_acquire(total ? total : 256, &p, &base_cached);
         if (e != hipSuccess) return e;
         base = reinterpret_cast<char*>(p);
         return hipSuccess;
@@ -98,7 +160,7 @@ struct Scratch {
             return hipSuccess;
         }
         void* p = nullptr;
-        hipError_t e = workspace_alloc(&p, bytes, st);
+        hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return e;
         extras.push_back(p);
         *out = reinterpret_cast<T*>(p);
@@ -1280,7 +1342,7 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
     }
     GESPMM_TRY(hipGetLastError());
     lap("order", 99);
-    return hipStreamSynchronize(st);  // the scratch goes back to the pool in stream order; callers may read perm now
+    return hipStreamSynchronize(st);  // callers may read perm now
 }
 
 hipError_t device_permute_csr(int64_t M, int64_t nnz, const int32_t* rowptr, const int32_t* colind, const int32_t* perm,

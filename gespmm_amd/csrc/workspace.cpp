@@ -4,6 +4,7 @@
 
 #include <stdint.h>
 
+#include <cstdlib>
 #include <mutex>
 
 namespace gespmm {
@@ -42,7 +43,10 @@ hipError_t pool_for_current_device(hipMemPool_t* out) {
 }
 }  // namespace
 
+static const bool g_no_pool = getenv("GESPMM_NO_POOL") != nullptr;  // debugging aid: plain hipMalloc / synchronised hipFree
+
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t st) {
+    if (g_no_pool) return hipMalloc(ptr, bytes ? bytes : 1);
     hipMemPool_t pool = nullptr;
     if (pool_for_current_device(&pool) != hipSuccess) {
         (void)hipGetLastError();  // no explicit pools on this runtime: the device's default pool will do
@@ -51,6 +55,12 @@ hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t st) {
     return hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, st);
 }
 
-hipError_t workspace_free(void* ptr, hipStream_t st) { return hipFreeAsync(ptr, st); }
+hipError_t workspace_free(void* ptr, hipStream_t st) {
+    if (g_no_pool) {
+        (void)hipStreamSynchronize(st);
+        return hipFree(ptr);
+    }
+    return hipFreeAsync(ptr, st);
+}
 
 }  // namespace gespmm

@@ -91,3 +91,27 @@ def test_gcn_example_runs(tmp_path):
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert re.search(r"gpu [0-9.]+ ms/epoch", r.stdout), r.stdout
+
+
+def test_driver_plan_on_the_headline_graph(tmp_path):
+    """`spmm_test --plan --validate` on the full-size community stand-in written as a MatrixMarket file: the analysis stage from
+    a process WITHOUT PyTorch's allocator in it, exact-size hipMalloc operands, NULL stream and NULL options. Round 3's device
+    analysis passed every Python-side test and still produced corrupt task tables here (temporaries from the stream-ordered pool:
+    profiles/r03/pool_hazard.log)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import gespmm_amd  # noqa: F401
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    mtx = str(tmp_path / "com-amazon-sbm.mtx")
+    graphs.write_mtx(mtx, g["rowptr"], g["colind"])
+    out = str(tmp_path / "out.csv")
+    r = subprocess.run([DRIVER, mtx, "0", "--out", out, "--seed", "1", "--method", "-1", "--plan", "--validate", "--ncols", "128",
+                        "--no-vendor"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stdout[-600:], r.stderr[-600:])
+    assert "order=clustered" in r.stdout and "tasks=72427" in r.stdout and "group_tasks=138912" in r.stdout, r.stdout[-800:]
+    assert " WA: " not in r.stdout and "validate done" in r.stdout, r.stdout[-800:]  # the driver prints "<who> WA: ..." on a mismatch
+    m = re.search(r"N=128 method=-1 plan: [0-9.]+ ms/iter, ([0-9.]+) GFLOP/s", r.stdout)
+    assert m and float(m.group(1)) > 2000.0, r.stdout[-400:]
