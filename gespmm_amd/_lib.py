@@ -73,6 +73,7 @@ EXPORTS = [
     "gespmm_device_cluster_rows",
     "gespmm_device_l2_model",
     "gespmm_plan_debug_tasks",
+    "gespmm_release_cached_memory",
 ]
 
 PLAN_REORDER_AUTO = 0
@@ -181,6 +182,8 @@ def _load():
     lib.gespmm_device_cluster_rows.argtypes = [p, p, c_int64, c_int64, c_int64, p, p, p, p]
     lib.gespmm_device_l2_model.restype = ctypes.c_double
     lib.gespmm_device_l2_model.argtypes = [p, p, c_int64, c_int64, c_int64, p, c_int32, c_int64, c_int64, c_int32, p]
+    lib.gespmm_release_cached_memory.restype = None
+    lib.gespmm_release_cached_memory.argtypes = []
     lib.gespmm_plan_debug_tasks.restype = c_int
     lib.gespmm_plan_debug_tasks.argtypes = [p, c_int32, p, c_int64]
     lib.gespmm_simulate_l2_hits.restype = ctypes.c_double

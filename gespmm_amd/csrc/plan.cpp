@@ -1194,6 +1194,8 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
     return n < capacity ? n : (int)capacity - 1;
 }
 
+void gespmm_release_cached_memory(void) { gespmm::release_cached_arena(); }
+
 void gespmm_plan_destroy(gespmm_plan* p) {
     if (!p) return;
     free_device(p);

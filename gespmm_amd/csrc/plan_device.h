@@ -39,4 +39,7 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
 hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t budget[2], const int64_t row_floor[2],
                             int32_t* tasks[2], int32_t ntasks_host[2], hipStream_t st);
 
+// Frees the analysis arena kept for the next plan (up to 512 MiB of device memory).
+void release_cached_arena();
+
 }  // namespace gespmm

@@ -108,6 +108,20 @@ hipError_t arena_acquire(size_t bytes, void** out, bool* cached) {
     return hipMalloc(out, bytes);
 }
 
+}  // namespace
+
+// Drops the cached analysis arena (gespmm_release_cached_memory): the next plan allocates a new one.
+void release_cached_arena() {
+    std::lock_guard<std::mutex> guard(g_arena.lock);
+    if (!g_arena.busy && g_arena.block) {
+        (void)hipFree(g_arena.block);
+        g_arena.block = nullptr;
+        g_arena.bytes = 0;
+    }
+}
+
+namespace {
+
 void arena_release(void* p, bool cached) {
     if (cached) {
         std::lock_guard<std::mutex> guard(g_arena.lock);
@@ -963,18 +977,6 @@ hipError_t sort_pairs(Scratch& sc, const KeyT* kin, KeyT* kout, const int32_t* v
     const size_t m = sc.mark();
     GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
     GESPMM_TRY(rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, st));
-    sc.rewind(sc.cur, m);
-    return hipSuccess;
-}
-
-hipError_t sort_keys64(Scratch& sc, const unsigned long long* kin, unsigned long long* kout, int64_t n, int bits,
-                       hipStream_t st) {
-    size_t bytes = 0;
-    GESPMM_TRY(rocprim::radix_sort_keys<SortConfig>(nullptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
-    char* tmp = nullptr;
-    const size_t m = sc.mark();
-    GESPMM_TRY(sc.get(&tmp, (int64_t)bytes));
-    GESPMM_TRY(rocprim::radix_sort_keys<SortConfig>(tmp, bytes, kin, kout, (size_t)n, 0u, (unsigned)bits, st));
     sc.rewind(sc.cur, m);
     return hipSuccess;
 }

@@ -173,3 +173,20 @@ def test_full_size_device_plan(pkg):
     a = spmm.csr_spmm(g["rowptr"], g["colind"], val, B, plan=plan)
     b = spmm.csr_spmm(g["rowptr"], g["colind"], val, B)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_release_cached_memory_between_plans(pkg, bundled):
+    """The analysis arena is kept for the next plan; gespmm_release_cached_memory gives it back and the next plan still works."""
+    from gespmm_amd import _lib, graphs, spmm
+
+    gs = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda", scale=0.1)
+    orders = []
+    for i in range(3):
+        plan = spmm.SpmmPlan(gs["rowptr"], gs["colind"], gs["K"], 64, reorder=True)
+        orders.append(plan.order().numpy())
+        del plan
+        if i == 0:
+            free0 = torch.cuda.mem_get_info()[0]
+            _lib.lib.gespmm_release_cached_memory()
+            assert torch.cuda.mem_get_info()[0] >= free0  # nothing is held any more
+    assert np.array_equal(orders[0], orders[1]) and np.array_equal(orders[1], orders[2])
