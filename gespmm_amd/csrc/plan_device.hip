@@ -352,8 +352,8 @@ __device__ inline void best_of_group(long long& bt, uint32_t& bh, int& bL) {
 template <int G, bool ROWS>
 __global__ void __launch_bounds__(256) k_lp_small(LpArgs a) {
     if (*a.done) return;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = tid / G, l = tid % G;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (count * G may exceed 2^31 on forced huge plans)
+    const int g = (int)(tid / G), l = (int)(tid % G);
     const bool active = g < *a.count;
     const int node = active ? a.list[g] : 0;
     const int beg = active ? a.adj.ptr[node] : 0, end = active ? a.adj.ptr[node + 1] : 0;
