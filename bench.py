@@ -525,11 +525,25 @@ def cpu_baselines(graphs, torch, g, val, N, graph, quick=False):
 
     import oracle_py
 
+    try:  # the reference's OWN golden loop (spmm_test.cu:596-604 compiled from the checkout: oracle/_ref/libref_host.so)
+        import ref_py
+
+        have_ref = ref_py.available()
+    except Exception:  # noqa: BLE001
+        ref_py, have_ref = None, False
+    kind = "reference" if have_ref else "port"
+
     def time_pass(rph, cih, vh, Bh, mode, reps):
+        """mode 'golden' = the single-threaded loop: the reference's lines when oracle/_ref is there, else the oracle's restatement
+        (pinned to them bit for bit, tests/test_ref_pin.py); 'omp' = the oracle's OpenMP form of the same loop body."""
         best = None
+        ones = np.ones(cih.shape[0], dtype=np.float32) if (vh is None and have_ref and mode == "golden") else None
         for _ in range(reps):
             t0 = time.perf_counter()
-            oracle_py.spmm(rph, cih, vh, Bh, mode)
+            if have_ref and mode == "golden":
+                ref_py.golden(rph, cih, vh if vh is not None else ones, Bh)
+            else:
+                oracle_py.spmm(rph, cih, vh, Bh, mode)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         return best
@@ -572,7 +586,9 @@ def cpu_baselines(graphs, torch, g, val, N, graph, quick=False):
         "value": head["value"],
         "unit": "GFLOP/s",
         "cores": 1,
-        "kind": "port",
+        "kind": kind,
+        "what": ("the reference's own CPU loop, spmm_test.cu:596-604 compiled from the checkout by oracle/make_ref.sh (g++ -O3)" if have_ref
+                 else "oracle restatement of spmm_test.cu:596-604 (gcc -O3), pinned to the reference's lines bit for bit"),
         "sample": "full %s x N=%d pass (%.2f GFLOP), best of 3, reference loop order i->k->ptr" % (graph, N, head["gflop_per_pass"]),
         "all_cores": dict(head["all_cores"], note="same loop body, OpenMP over rows, best of 3 after one warm pass"),
     }
@@ -618,11 +634,22 @@ def rmat_cpu_baseline(torch, g, N):
     Bh = np.ascontiguousarray(((np.random.RandomState(2).randint(0, 100, (len(cols_u), N)) - 50) / 100).astype(np.float32))
     inv = inv.astype(np.int32)
 
+    try:
+        import ref_py
+
+        have_ref = ref_py.available()
+    except Exception:  # noqa: BLE001
+        ref_py, have_ref = None, False
+    ones = np.ones(int(sub_ptr[-1]), dtype=np.float32)
+
     def best(mode, reps):
         t = None
         for _ in range(reps):
             t0 = time.perf_counter()
-            oracle_py.spmm(sub_ptr, inv, None, Bh, mode)
+            if have_ref and mode == "golden":
+                ref_py.golden(sub_ptr, inv, ones, Bh)  # the reference's own loop (oracle/_ref)
+            else:
+                oracle_py.spmm(sub_ptr, inv, None, Bh, mode)
             dt = time.perf_counter() - t0
             t = dt if t is None else min(t, dt)
         return t
@@ -631,7 +658,7 @@ def rmat_cpu_baseline(torch, g, N):
     oracle_py.spmm(sub_ptr, inv, None, Bh, "omp")
     allc = best("omp", 3)
     fl = 2.0 * int(sub_ptr[-1]) * N
-    return {"value": fl / one / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+    return {"value": fl / one / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "reference" if have_ref else "port",
             "all_cores": {"value": fl / allc / 1e9, "cores": oracle_py.num_threads()},
             "sample": "%d rows (%.3f %% of M, blocks of 64), %.2f GFLOP; B restricted to the %d rows they touch" %
                       (len(rows), 100.0 * len(rows) / M, fl / 1e9, len(cols_u))}
