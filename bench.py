@@ -468,6 +468,10 @@ def main():
                           if not args.no_plan else "gespmm_csr_spmm_f32 (no plan)",
                 "partition": "independent replicas, one graph per rank (the row-partitioned experiment is --graph rmat)"
                              if world > 1 else "single GPU",
+                "stand_in": ("com-Amazon-shaped seeded stand-ins (no network): `com-amazon-sbm` = planted communities, clustering "
+                             "coefficient 0.408 (SNAP com-Amazon: 0.397), vertex ids shuffled — the headline since round 3; "
+                             "`com-amazon-like` = structureless (clustering 4e-5), rounds 1-2's headline — measured with the same fields "
+                             "in extra['com-amazon-like_N%d_valued']" % N) if graph.startswith("com-amazon") else graph,
             },
             "roofline": {
                 "bound": "hbm",
