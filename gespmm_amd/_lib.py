@@ -86,6 +86,7 @@ PLAN_KERNEL_STREAM = 1
 PLAN_KERNEL_LDS_ROWS = 2
 PLAN_KERNEL_SEG_STREAM = 3
 PLAN_KERNEL_OUTER = 4
+PLAN_KERNEL_STAGED = 5
 
 
 class LaunchCfg(Structure):

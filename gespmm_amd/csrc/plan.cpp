@@ -82,6 +82,9 @@ struct gespmm_plan {
     gespmm::ClusterStats stats;
     double analysis_seconds = 0.0, cluster_seconds = 0.0;
     double hits_before = -1.0, hits_after = -1.0;
+    // staged-rows kernel (spmm_staged.hip): tables for width N (plan_device.hip: device_build_staging)
+    gespmm::StagingTables stg;
+    double staging_seconds = 0.0;
 };
 
 namespace {
@@ -133,6 +136,7 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 }
 
 void free_device(gespmm_plan* p) {
+    gespmm::free_staging(&p->stg);
     if (p->gtasks_shared) p->d_gtasks = nullptr;
     void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_recs, p->d_rec_src, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp, p->d_orecs, p->d_orec_src, p->d_coo_row_storage};
     for (void* q : ptrs)
@@ -823,6 +827,30 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             lap("values");
+            // ---- staged-rows kernel: worth its tables where a block of 128 clustered rows uses the same B rows again and
+            // again (profiles/r03/staged_rows.log; products-shaped communities: 2.95 vs 3.82 ms at N = 128, 7.14 vs 7.56 ms at
+            // N = 256). At N = 128 one row is half of what a load instruction could carry, so short rows lose what staging wins
+            // (com-Amazon-shaped communities: 121 vs 109 us) and the rule asks for mean degree >= 12; at N = 256 a row fills the
+            // instruction and short rows win too (185 vs 199 us). One wavefront walks a row's entries one after the other, so hub
+            // rows stay with the streaming kernels.
+            {
+                const int H = gespmm::staged_rows_per_block_lds(N);
+                const bool fits = H > 0 && nnz > 0 && (uint64_t)K * (uint64_t)N * 4ull < 0xFFFF0000ull && p->max_degree <= 2048 &&
+                                  !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS);
+                const bool want = p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
+                                  (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && (mean >= 12 || N >= 256) && p->hits_after >= 0.40 &&
+                                   nnz >= (1 << 20) &&
+                                   (variant == GESPMM_VARIANT_AUTO || variant == GESPMM_VARIANT_CRC_CWM4 ||
+                                    variant == GESPMM_VARIANT_CRC_CWM8));
+                if (e == hipSuccess && fits && want) {
+                    const auto ts = std::chrono::steady_clock::now();
+                    e = gespmm::device_build_staging(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, H, &p->stg, st);
+                    p->staging_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+                    if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && p->stg.staged_fraction < (N >= 256 ? 0.30 : 0.40))
+                        gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay
+                    lap("staging tables");
+                }
+            }
             if (e != hipSuccess) {
                 free_device(p);
                 delete p;
@@ -994,6 +1022,15 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     // opt-in (GESPMM_PLAN_KERNEL_LDS_ROWS): 118-128 us vs 108-113 us for the batch-stream kernel on the clustered bench
     // graph — its sums are instruction-issue bound at the 8 wavefronts per CU its LDS footprint allows
     if (lds_rows && p->kernel_choice != GESPMM_PLAN_KERNEL_LDS_ROWS) lds_rows = false;
+    // staged-rows kernel: its tables exist (the plan decided at creation), same width, sum reducer, 16-byte operands
+    const bool staged = p->reordered && p->stg.ev && N == p->N && reduce == gespmm::kReduceSum && variant_v4 && !lds_rows &&
+                        p->kernel_choice != GESPMM_PLAN_KERNEL_OUTER && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    if (staged) {
+        if (!B || !C) return GESPMM_EINVAL;
+        gespmm::StagedArgs sa = {p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols, p->stg.nhot, B, C, p->stg.nblocks};
+        return (int)gespmm::launch_spmm_staged(sa, N, reinterpret_cast<hipStream_t>(stream));
+    }
     const int oV = gespmm::outer_vec_width(N);
     bool outer = p->reordered && p->d_orecs && p->norec > 0 && oV > 0 && variant_v4 && !lds_rows &&
                  (reinterpret_cast<uintptr_t>(B) % (4u * oV)) == 0 && (reinterpret_cast<uintptr_t>(C) % (4u * oV)) == 0;
@@ -1125,6 +1162,7 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     }
     if (!val) {
         p->valued = false;
+        if (p->stg.ev) return (int)gespmm::device_staging_set_values(p->stg.ev, nullptr, p->nnz, st);  // the stream carries 1.0f
         return 0;
     }
     if (!p->d_val) {
@@ -1135,6 +1173,10 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     if (p->nnz == 0) return 0;
     hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
                        p->d_src_begin, val, p->d_val, (int)p->M, (int)p->nnz);
+    if (p->stg.ev) {
+        const hipError_t es = gespmm::device_staging_set_values(p->stg.ev, p->d_val, p->nnz, st);
+        if (es != hipSuccess) return (int)es;
+    }
     if (p->d_orecs && p->norec > 0) {
         const int64_t nslots = (int64_t)p->norec * gespmm::kOutEntries;
         hipLaunchKernelGGL(scatter_outer_values_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st,
@@ -1170,7 +1212,7 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         int off = 0;
         for (int i = 0; i < p->stats.levels && i < 16 && off < 100; ++i)
             off += snprintf(lv + off, sizeof lv - (size_t)off, "%s%d", i ? ">" : "", p->stats.clusters[i]);
-        char kern[160];
+        char kern[420];
         const int W = gespmm::ldsrow_group_width(p->N);
         const bool lds = p->d_recs && p->nrec > 0 && W > 0 && p->kernel_choice == GESPMM_PLAN_KERNEL_LDS_ROWS &&
                          (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
@@ -1180,6 +1222,9 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
                            (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
         if (outer) snprintf(kern, sizeof kern, "kernel=task-outer V=%d records=%d nnz_per_distinct_row=%.2f", oV, p->norec, p->orec_dup);
         else if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
+        else if (p->stg.ev && !outer && !lds && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
+            snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f tables=%.4fs (max / other widths: %s)",
+                     p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "

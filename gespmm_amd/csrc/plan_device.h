@@ -39,6 +39,23 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
 hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t budget[2], const int64_t row_floor[2],
                             int32_t* tasks[2], int32_t ntasks_host[2], hipStream_t st);
 
+// Tables of spmm_staged.hip for the clustered matrix (rowptr_p / colind_p / val_p = the plan's row-permuted copy; val_p NULL:
+// unweighted, the stream carries 1.0f): blocks of kStagedBlockRows rows, per block the <= H columns its entries use most often
+// (>= 2 uses), kStagedWaves tasks, and the interleaved {code, value} stream. staged_fraction = share of the entries whose B row
+// comes from LDS. Deterministic (ties in column order). The four arrays are hipMalloc blocks owned by the caller (free_staging).
+struct StagingTables {
+    int32_t* ev = nullptr;        // 2 * (nnz + kStagedPad) words
+    int32_t* hot_cols = nullptr;  // nblocks * H
+    int32_t* nhot = nullptr;      // nblocks
+    int32_t* tasks = nullptr;     // nblocks * kStagedWaves int4
+    int32_t nblocks = 0;
+    double staged_fraction = 0.0;
+};
+hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
+                                const float* val_p, int H, StagingTables* out, hipStream_t st);
+hipError_t device_staging_set_values(int32_t* ev, const float* val_p, int64_t nnz, hipStream_t st);
+void free_staging(StagingTables* t);
+
 // Frees the analysis arena kept for the next plan (up to 512 MiB of device memory).
 void release_cached_arena();
 

@@ -37,7 +37,9 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/block/block_scan.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/functional.hpp>
 
 #include "plan_device.h"
@@ -1467,6 +1469,225 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
     ntasks_host[0] = nt[0];
     ntasks_host[1] = nt[1];
     return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------ staging tables (spmm_staged.hip)
+//
+// Blocks of kStagedBlockRows consecutive rows of the clustered matrix. Per block: the block's column indices sorted (one segment of
+// a segmented radix sort, payload = position of the entry), runs of equal columns = how often the block uses a B row; the H
+// most used ones (>= 2 uses; ties taken in column order, so the tables are the same on every build) get LDS slots.
+
+namespace {
+
+constexpr int kStageHistBins = 256;
+
+__global__ void k_stage_offsets(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int32_t* __restrict__ blkoff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nblk) return;
+    const int64_t r = i * kStagedBlockRows < M ? i * kStagedBlockRows : M;
+    blkoff[i] = rowptr_p[r];
+}
+
+__global__ void k_stage_iota(int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict__ blkoff, const int32_t* __restrict__ keys,
+                                                       const int32_t* __restrict__ idx, int H, int32_t* __restrict__ code,
+                                                       int32_t* __restrict__ hot_cols, int32_t* __restrict__ nhot,
+                                                       unsigned long long* __restrict__ staged_entries) {
+    using BlockScan = rocprim::block_scan<int, 256>;
+    __shared__ typename BlockScan::storage_type scan_storage;
+    __shared__ int hist[kStageHistBins];
+    __shared__ int s_t, s_ngt, s_quota;
+    const int tid = threadIdx.x;
+    const int64_t blk = blockIdx.x;
+    const int b = blkoff[blk], e = blkoff[blk + 1];
+    hist[tid] = 0;
+    __syncthreads();
+    // length of the run starting at p (0 if p is not the head of a run), clamped to the histogram
+    auto run_at = [&](int p, int& key) -> int {
+        if (p >= e) return 0;
+        key = keys[p];
+        if (p > b && keys[p - 1] == key) return 0;
+        int len = 1;
+        while (p + len < e && keys[p + len] == key) ++len;
+        return len;
+    };
+    for (int p0 = b; p0 < e; p0 += 256) {
+        int key = 0;
+        const int len = run_at(p0 + tid, key);
+        if (len >= 2) atomicAdd(&hist[len < kStageHistBins ? len : kStageHistBins - 1], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // every run longer than t is staged (ngt of them), `quota` runs of length exactly t fill the rest
+        int cum = 0, t = 1, ngt = 0, quota = 0;
+        for (int L = kStageHistBins - 1; L >= 2; --L) {
+            if (cum + hist[L] > H) {
+                t = L;
+                quota = H - cum;
+                break;
+            }
+            cum += hist[L];
+        }
+        ngt = cum;
+        s_t = t;
+        s_ngt = ngt;
+        s_quota = quota;
+    }
+    __syncthreads();
+    const int t = s_t, ngt = s_ngt, quota = s_quota;
+    int base_gt = 0, base_eq = 0;
+    unsigned long long mine = 0;
+    for (int p0 = b; p0 < e; p0 += 256) {
+        const int p = p0 + tid;
+        int key = 0;
+        const int len = run_at(p, key);
+        const int lenc = len < kStageHistBins ? len : kStageHistBins - 1;
+        const int f_gt = (len >= 2 && lenc > t) ? 1 : 0;
+        const int f_eq = (len >= 2 && t >= 2 && lenc == t) ? 1 : 0;
+        int ex = 0, total = 0;
+        BlockScan().exclusive_scan(f_gt | (f_eq << 16), ex, 0, total, scan_storage, rocprim::plus<int>());
+        int slot = -1;
+        if (f_gt) slot = base_gt + (ex & 0xffff);
+        else if (f_eq && base_eq + (ex >> 16) < quota) slot = ngt + base_eq + (ex >> 16);
+        if (len > 0) {
+            const int c = slot >= 0 ? (int)(0x80000000u | (unsigned)slot) : key;
+            for (int i = 0; i < len; ++i) code[idx[p + i]] = c;
+            if (slot >= 0) {
+                hot_cols[blk * H + slot] = key;
+                mine += (unsigned long long)len;
+            }
+        }
+        base_gt += total & 0xffff;
+        base_eq += total >> 16;
+        __syncthreads();  // scan_storage is reused by the next tile
+    }
+    if (tid == 0) nhot[blk] = ngt + (base_eq < quota ? base_eq : quota);
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((tid & 63) == 0 && mine) atomicAdd(staged_entries, mine);
+}
+
+__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int32_t* __restrict__ tasks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk * kStagedWaves) return;
+    const int64_t blk = i / kStagedWaves;
+    const int w = (int)(i % kStagedWaves);
+    const int b0 = (int)(blk * kStagedBlockRows);
+    const int b1 = (int)(b0 + kStagedBlockRows < M ? b0 + kStagedBlockRows : M);
+    const int e0 = rowptr_p[b0], e1 = rowptr_p[b1];
+    auto bound = [&](int ww) -> int {  // first row of part ww: the block's entries cut into kStagedWaves equal shares
+        if (ww <= 0) return b0;
+        if (ww >= kStagedWaves) return b1;
+        const int target = e0 + (int)(((long long)(e1 - e0) * ww) / kStagedWaves);
+        int lo = b0, hi = b1;  // first r in [b0, b1] with rowptr_p[r] >= target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rowptr_p[mid] >= target) hi = mid;
+            else lo = mid + 1;
+        }
+        return lo;
+    };
+    const int r0 = bound(w), r1 = bound(w + 1);
+    reinterpret_cast<int4*>(tasks)[i] = make_int4(r0, r1 - r0, rowptr_p[r0], rowptr_p[r1]);
+}
+
+__global__ void k_stage_interleave(const int32_t* __restrict__ code, const float* __restrict__ val_p, int64_t nnz, int64_t total,
+                                   int32_t* __restrict__ ev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int2 w = make_int2(0, 0);  // padding: column 0, value +0
+    if (i < nnz) {
+        w.x = code[i];
+        w.y = val_p ? __float_as_int(val_p[i]) : 0x3f800000;
+    }
+    reinterpret_cast<int2*>(ev)[i] = w;
+}
+
+__global__ void k_stage_values(const float* __restrict__ val_p, int64_t nnz, int32_t* __restrict__ ev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz) ev[2 * i + 1] = val_p ? __float_as_int(val_p[i]) : 0x3f800000;
+}
+
+}  // namespace
+
+void free_staging(StagingTables* t) {
+    if (!t) return;
+    void* ptrs[] = {t->ev, t->hot_cols, t->nhot, t->tasks};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    *t = StagingTables();
+}
+
+hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
+                                const float* val_p, int H, StagingTables* out, hipStream_t st) {
+    *out = StagingTables();
+    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0) return hipErrorInvalidValue;
+    const int64_t nblk = (M + kStagedBlockRows - 1) / kStagedBlockRows;
+    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr;
+    unsigned long long* staged = nullptr;
+    void* tmp = nullptr;
+    StagingTables t;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        void* ptrs[] = {blkoff, keys, idx_in, idx_out, code, staged, tmp};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+    };
+    auto body = [&]() -> hipError_t {
+        // (plain hipMalloc: these are gigabyte-sized for products-sized graphs and live for this call only)
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&blkoff), (size_t)(nblk + 1) * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&keys), (size_t)nnz * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&idx_in), (size_t)nnz * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&idx_out), (size_t)nnz * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&code), (size_t)nnz * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&staged), 8));
+        GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
+        hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, blkoff);
+        hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
+        int bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < K) ++bits;
+        size_t bytes = 0;
+        GESPMM_TRY(rocprim::segmented_radix_sort_pairs(nullptr, bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
+                                                       (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
+                                                       (unsigned)bits, st));
+        GESPMM_TRY(hipMalloc(&tmp, bytes ? bytes : 256));
+        GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
+                                                       (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
+                                                       (unsigned)bits, st));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.hot_cols), (size_t)nblk * H * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.nhot), (size_t)nblk * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.tasks), (size_t)nblk * kStagedWaves * 16));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + kStagedPad) * 8));
+        GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0, (size_t)nblk * H * 4, st));
+        hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
+                           (const int32_t*)idx_out, H, code, t.hot_cols, t.nhot, staged);
+        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, t.tasks);
+        hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz + kStagedPad)), dim3(256), 0, st, (const int32_t*)code, val_p, nnz,
+                           nnz + kStagedPad, t.ev);
+        GESPMM_TRY(hipGetLastError());
+        unsigned long long h = 0;
+        GESPMM_TRY(fetch(&h, (const unsigned long long*)staged, 1, st));
+        t.nblocks = (int32_t)nblk;
+        t.staged_fraction = (double)h / (double)nnz;
+        return hipSuccess;
+    };
+    const hipError_t e = body();
+    cleanup();
+    if (e != hipSuccess) {
+        free_staging(&t);
+        return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+hipError_t device_staging_set_values(int32_t* ev, const float* val_p, int64_t nnz, hipStream_t st) {
+    if (nnz <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stage_values, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, nnz, ev);
+    return hipGetLastError();
 }
 
 }  // namespace gespmm

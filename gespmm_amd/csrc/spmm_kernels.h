@@ -167,6 +167,28 @@ struct OuterArgs {
 int outer_vec_width(int64_t N);  // floats per lane (1, 2, 4), 0 if this width is not served
 hipError_t launch_spmm_outer(const OuterArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
 
+// spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256, sum).
+// plan_device.hip (device_build_staging) writes the tables: blocks of kStagedBlockRows consecutive rows of the clustered matrix,
+// kStagedWaves tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream
+// `ev` = {code, value bits} per entry (code >= 0: column; code < 0: staged slot in its low bits), padded by kStagedPad entries.
+constexpr int kStagedBlockRows = 128;
+constexpr int kStagedWaves = 16;
+constexpr int kStagedLdsBytes = 64 * 1024;
+constexpr int kStagedPad = 64;
+struct StagedArgs {
+    const int32_t* rowptr;    // clustered matrix
+    const int32_t* ev;        // 2 * (nnz + kStagedPad) words
+    const int32_t* perm;      // C row of clustered row i
+    const int32_t* tasks;     // nblocks * kStagedWaves int4
+    const int32_t* hot_cols;  // nblocks * H (H = staged_rows_per_block_lds(N))
+    const int32_t* nhot;      // nblocks
+    const float* B;
+    float* C;
+    int32_t nblocks;
+};
+int staged_rows_per_block_lds(int64_t N);  // H for this width; 0 = width not served
+hipError_t launch_spmm_staged(const StagedArgs& a, int64_t N, hipStream_t st);
+
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form
 hipError_t launch_sddmm(const int32_t* rowind_or_rowptr, bool csr, const int32_t* colind,

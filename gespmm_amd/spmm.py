@@ -115,7 +115,8 @@ class SpmmPlan:
         self.device = dev
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
         kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "lds-rows": _lib.PLAN_KERNEL_LDS_ROWS,
-                "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM, "task-outer": _lib.PLAN_KERNEL_OUTER}[kernel]
+                "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM, "task-outer": _lib.PLAN_KERNEL_OUTER,
+                "staged": _lib.PLAN_KERNEL_STAGED}[kernel]
         where = {"device": _lib.PLAN_ANALYSIS_DEVICE, "host": _lib.PLAN_ANALYSIS_HOST}[analysis]
         opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where)
         self._handle = ctypes.c_void_p()

@@ -1,0 +1,130 @@
+"""The plan's staged-rows kernel (csrc/spmm_staged.hip + plan_device.hip: device_build_staging): one row per wavefront walked
+from SGPRs, the most used B rows of every 128-row block read from LDS. Only WHERE a B row comes from changes — every output
+element is still one fp32 chain in CSR order — so the bits must equal the oracle's `fma` arithmetic (= the reference's
+kernels, tests/test_gpu_ref_kernels.py) and the plain call's."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import bits, edge_case_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("N", (128, 256))
+@pytest.mark.parametrize("graph", ("cora", "pubmed"))
+def test_bits_equal_oracle_valued_unweighted_and_new_values(pkg, oracle, bundled, graph, N):
+    from gespmm_amd import spmm
+
+    g = bundled[graph]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=7)
+    val = _dev(val_h)
+    plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True, kernel="staged")
+    assert plan.clustered and "kernel=staged-rows" in plan.describe(), plan.describe()
+    B_h = oracle.hash_B(g["K"], N, seed=N)
+    B = _dev(B_h)
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma"))), (graph, N)
+    # the same plan without values: the stream carries 1.0f (fma(1, b, acc) == acc + b), against the golden loop
+    got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got_u), bits(oracle.spmm(g["rowptr"], g["colind"], None, B_h, "golden"))), (graph, N)
+    # with other values (re-permuted and re-interleaved on the device)
+    val2_h = oracle.hash_val(g["nnz"], seed=8)
+    val2 = _dev(val2_h)
+    got2 = spmm.csr_spmm(rp, ci, val2, B, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got2), bits(oracle.spmm(g["rowptr"], g["colind"], val2_h, B_h, "fma")))
+    # what the staged kernel does not serve goes to the streaming kernels of the same plan: another width, the max reducer
+    B2_h = oracle.hash_B(g["K"], 64, seed=5)
+    got64 = spmm.csr_spmm(rp, ci, val2, _dev(B2_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got64), bits(oracle.spmm(g["rowptr"], g["colind"], val2_h, B2_h, "fma")))
+
+
+@pytest.mark.parametrize("N", (128, 256))
+def test_edge_shapes(pkg, oracle, N):
+    """Empty rows (also leading / trailing ones inside a block), rows of 1..200 entries, repeated and unsorted columns,
+    K != M, M < 128 and M not a multiple of the block size."""
+    from gespmm_amd import spmm
+
+    g = edge_case_csr(seed=4)
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=3)
+    B_h = oracle.hash_B(g["K"], N, seed=N + 1)
+    plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=_dev(val_h), reorder=True, kernel="staged")
+    assert "kernel=staged-rows" in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp, ci, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")))
+    # several blocks, ragged last block: the same rows tiled 37 times with shifted columns
+    reps = 37
+    degs = np.tile(np.diff(g["rowptr"]), reps)
+    rowptr = np.zeros(degs.size + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    colind = np.concatenate([(g["colind"] + 7 * r) % g["K"] for r in range(reps)]).astype(np.int32)
+    val_h = oracle.hash_val(colind.size, seed=5)
+    rp2, ci2 = _dev(rowptr), _dev(colind)
+    plan = spmm.SpmmPlan(rp2, ci2, g["K"], N, values=_dev(val_h), reorder=True, kernel="staged")
+    assert "kernel=staged-rows" in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp2, ci2, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
+
+
+def test_auto_rule_and_full_width_bits_on_a_community_graph(pkg, oracle):
+    """products-shaped planted communities at 1/8 size (306 k rows, 15 M entries, mean degree 50): AUTO takes the staged
+    kernel, its results equal the plain call's bit for bit (sampled rows also against the oracle); the com-Amazon-shaped
+    stand-in (mean degree 5.5) keeps the streaming kernels."""
+    from gespmm_amd import graphs, spmm
+
+    g = graphs.synthetic_graph("products-sbm", seed=42, device="cuda", scale=0.125)
+    rp, ci, M, K, nnz = g["rowptr"], g["colind"], g["M"], g["K"], g["nnz"]
+    val = torch.from_numpy(oracle.hash_val(nnz, seed=11)).cuda()
+    B = torch.from_numpy(oracle.hash_B(K, 128, seed=12)).cuda()
+    plan = spmm.SpmmPlan(rp, ci, K, 128, values=val)
+    d = plan.describe()
+    assert "kernel=staged-rows" in d, d
+    frac = float(d.split("staged_entries=")[1].split()[0])
+    assert 0.40 <= frac <= 1.0, d
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    plain = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x100})  # GESPMM_FLAG_STRICT_ORDER: no long-row pass
+    assert torch.equal(got.view(torch.int32), plain.view(torch.int32))
+    rows = np.random.RandomState(0).choice(M, 400, replace=False)
+    rp_h, ci_h, v_h, B_h = rp.cpu().numpy(), ci.cpu().numpy(), val.cpu().numpy(), B.cpu().numpy()
+    for r in rows:
+        sub_rp = np.array([0, rp_h[r + 1] - rp_h[r]], dtype=np.int32)
+        ref = oracle.spmm(sub_rp, ci_h[rp_h[r]:rp_h[r + 1]], v_h[rp_h[r]:rp_h[r + 1]], B_h, "fma")
+        assert np.array_equal(bits(got[r:r + 1].cpu().numpy()), bits(ref)), r
+    # the same tables twice: the analysis is deterministic
+    plan2 = spmm.SpmmPlan(rp, ci, K, 128, values=val)
+    assert plan2.describe().split("staged_entries=")[1].split()[0] == d.split("staged_entries=")[1].split()[0]
+    # operands that are not 16-byte aligned fall back to the streaming kernels of the same plan
+    Boff = torch.empty(K * 128 + 1, device="cuda")[1:].view(K, 128)
+    Boff.copy_(B)
+    assert torch.equal(spmm.csr_spmm(rp, ci, val, Boff, plan=plan).view(torch.int32), plain.view(torch.int32))
+    del plan, plan2
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    plan = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 128)
+    assert plan.clustered and "kernel=staged-rows" not in plan.describe(), plan.describe()
+
+
+def test_hub_rows_keep_the_streaming_kernels(pkg, oracle):
+    """A row beyond 2048 entries would be one wavefront's serial walk: such matrices are not staged, even on request."""
+    from gespmm_amd import spmm
+
+    rng = np.random.RandomState(3)
+    M = K = 4000
+    degs = rng.randint(1, 30, size=M)
+    degs[17] = 3000
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)
+    val_h = oracle.hash_val(colind.size, seed=2)
+    B_h = oracle.hash_B(K, 128, seed=3)
+    rp, ci = _dev(rowptr), _dev(colind)
+    plan = spmm.SpmmPlan(rp, ci, K, 128, values=_dev(val_h), reorder=True, kernel="staged", flags=0x100)
+    assert "kernel=staged-rows" not in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp, ci, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
