@@ -333,13 +333,25 @@ def main():
                 plan3 = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], 128, values=val3)
                 torch.cuda.synchronize()
                 sweep = {"plan_ms": (time.perf_counter() - t0) * 1e3, "plan": plan3.describe()}
+                # (the staged-rows kernel's tables are made for ONE width: N = 256 gets a plan of its own)
+                tw = []
+                for _ in range(2):
+                    plan3w = None
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    plan3w = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], 256, values=val3)
+                    torch.cuda.synchronize()
+                    tw.append((time.perf_counter() - t0) * 1e3)
+                sweep["plan_N256_ms"] = min(tw)
+                sweep["plan_N256_ms_each"] = tw
+                sweep["plan_N256"] = plan3w.describe()
                 for n3 in (16, 32, 64, 128, 256, 512):
                     torch.cuda.empty_cache()
                     B3 = make_B(g3["K"], n3)
                     C3 = torch.empty((g3["M"], n3), dtype=torch.float32, device=dev)
                     ab3 = algorithmic_bytes(g3["M"], g3["K"], n3, g3["nnz"], True)
                     row = {"roof_gflops": roof_gflops(g3["M"], g3["K"], n3, g3["nnz"], True)}
-                    for label, pl in (("plain", None), ("plan", plan3)):
+                    for label, pl in (("plain", None), ("plan", plan3w if n3 == 256 else plan3)):
                         def st3():
                             spmm.csr_spmm(g3["rowptr"], g3["colind"], val3, B3, variant=args.variant, out=C3, plan=pl)
                         for _ in range(2):
@@ -350,7 +362,7 @@ def main():
                     sweep["N%d" % n3] = row
                     del B3, C3
                 extra["%s_sweep_valued" % pname] = sweep
-                del g3, val3, plan3
+                del g3, val3, plan3, plan3w
 
             # ---- BASELINE configs[0] and [3]: the small graphs (launch-latency territory), unweighted as the reference's driver and
             #      its GCN run them; plain call and plan

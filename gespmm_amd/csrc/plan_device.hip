@@ -62,12 +62,18 @@ namespace {
 // is rewound at phase boundaries. A request that does not fit its region gets a block of its own (correct, just
 // slower), so the size estimates need not be tight.
 //
-// The block comes from plain hipMalloc through a one-entry cache (blocks up to 512 MiB are kept for the next plan), NOT
+// The block comes from plain hipMalloc through a one-entry cache (blocks up to 4 GiB — GESPMM_ARENA_CACHE_MB — are kept for the next plan), NOT
 // from the library's stream-ordered pool: with hipMallocFromPoolAsync / hipFreeAsync cycles of changing sizes interleaved
 // with the plan's own hipMalloc calls, analysis results came out corrupted in processes without PyTorch's allocator in
 // them (the spmm_test driver: wrong task tables, then a memory fault in the first launch; profiles/r03/pool_hazard.log).
 // The analysis synchronises the stream anyway, so a synchronous free costs nothing here.
-constexpr size_t kArenaCacheCap = 512ull << 20;
+// 4 GiB covers a products-sized matrix (2.4 M rows, 124 M entries: ~2.5 GB). Larger analyses allocate and free a private block —
+// and a multi-GB hipMalloc right after another library returned a lot of memory to the driver was seen to take seconds
+// (profiles/r03/plan_repeat.log: 65 ms -> 3.1 s for the same analysis after torch.cuda.empty_cache()).
+static size_t arena_cache_cap() {
+    static const size_t cap = getenv("GESPMM_ARENA_CACHE_MB") ? (size_t)atoll(getenv("GESPMM_ARENA_CACHE_MB")) << 20 : 4096ull << 20;
+    return cap;
+}
 struct ArenaCache {
     std::mutex lock;
     void* block = nullptr;
@@ -89,7 +95,7 @@ hipError_t arena_acquire(size_t bytes, void** out, bool* cached) {
                 g_arena.block = nullptr;
                 g_arena.bytes = 0;
             }
-            if (!g_arena.block && bytes <= kArenaCacheCap) {
+            if (!g_arena.block && bytes <= arena_cache_cap()) {
                 e = hipMalloc(&g_arena.block, bytes);
                 if (e != hipSuccess) {
                     g_arena.block = nullptr;

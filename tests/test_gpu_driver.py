@@ -115,3 +115,24 @@ def test_driver_plan_on_the_headline_graph(tmp_path):
     assert " WA: " not in r.stdout and "validate done" in r.stdout, r.stdout[-800:]  # the driver prints "<who> WA: ..." on a mismatch
     m = re.search(r"N=128 method=-1 plan: [0-9.]+ ms/iter, ([0-9.]+) GFLOP/s", r.stdout)
     assert m and float(m.group(1)) > 2000.0, r.stdout[-400:]
+
+
+def test_driver_plan_takes_the_staged_kernel_on_long_row_communities(tmp_path):
+    """`spmm_test --plan --validate` on a products-shaped community graph at 1/20 size (122 k rows, 6 M entries, mean degree
+    50): AUTO builds the staging tables (segmented sort + selection on the device, plain hipMalloc temporaries) in a process
+    without PyTorch and launches csrc/spmm_staged.hip at N = 128 and 256; the driver's --validate compares with its CPU loop."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import gespmm_amd  # noqa: F401
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("products-sbm", seed=42, device="cuda", scale=0.05)
+    mtx = str(tmp_path / "products-sbm-20th.mtx")
+    graphs.write_mtx(mtx, g["rowptr"], g["colind"])
+    out = str(tmp_path / "out.csv")
+    r = subprocess.run([DRIVER, mtx, "0", "--out", out, "--seed", "1", "--method", "-1", "--plan", "--validate", "--ncols", "128,256",
+                        "--no-vendor", "--use-values"], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, (r.returncode, r.stdout[-600:], r.stderr[-600:])
+    assert r.stdout.count("kernel=staged-rows") >= 2, r.stdout[-1500:]
+    assert " WA: " not in r.stdout and "validate done" in r.stdout, r.stdout[-800:]
