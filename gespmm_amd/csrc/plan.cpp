@@ -844,7 +844,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                                     variant == GESPMM_VARIANT_CRC_CWM8));
                 if (e == hipSuccess && fits && want) {
                     const auto ts = std::chrono::steady_clock::now();
-                    e = gespmm::device_build_staging(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, H, &p->stg, st);
+                    e = gespmm::device_build_staging(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, p->d_perm, H, &p->stg, st);
                     p->staging_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
                     if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && p->stg.staged_fraction < (N >= 256 ? 0.30 : 0.40))
                         gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay

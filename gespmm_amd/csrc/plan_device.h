@@ -51,8 +51,10 @@ struct StagingTables {
     int32_t nblocks = 0;
     double staged_fraction = 0.0;
 };
+// perm (clustered position -> original row; may be NULL): on square matrices a column whose own row is processed more than
+// GESPMM_STAGED_FAR_BLOCKS (default 64) blocks away is marked "far" (bit 30 of its code): gathered with `nt`.
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, int H, StagingTables* out, hipStream_t st);
+                                const float* val_p, const int32_t* perm, int H, StagingTables* out, hipStream_t st);
 hipError_t device_staging_set_values(int32_t* ev, const float* val_p, int64_t nnz, hipStream_t st);
 void free_staging(StagingTables* t);
 

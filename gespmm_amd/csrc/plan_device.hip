@@ -1499,8 +1499,14 @@ __global__ void k_stage_iota(int32_t* __restrict__ out, int64_t n) {
     if (i < n) out[i] = (int32_t)i;
 }
 
+__global__ void k_stage_positions(const int32_t* __restrict__ perm, int64_t M, int32_t* __restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) pos[perm[i]] = (int32_t)i;
+}
+
 __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict__ blkoff, const int32_t* __restrict__ keys,
-                                                       const int32_t* __restrict__ idx, int H, int32_t* __restrict__ code,
+                                                       const int32_t* __restrict__ idx, int H, const int32_t* __restrict__ pos,
+                                                       int far_blocks, int32_t* __restrict__ code,
                                                        int32_t* __restrict__ hot_cols, int32_t* __restrict__ nhot,
                                                        unsigned long long* __restrict__ staged_entries) {
     using BlockScan = rocprim::block_scan<int, 256>;
@@ -1560,7 +1566,11 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
         if (f_gt) slot = base_gt + (ex & 0xffff);
         else if (f_eq && base_eq + (ex >> 16) < quota) slot = ngt + base_eq + (ex >> 16);
         if (len > 0) {
-            const int c = slot >= 0 ? (int)(0x80000000u | (unsigned)slot) : key;
+            int c = slot >= 0 ? (int)(0x80000000u | (unsigned)slot) : key;
+            if (slot < 0 && pos) {  // square matrix: B row `key` is also row `key` of the matrix — how far away is it processed?
+                const long long d = (long long)(pos[key] / kStagedBlockRows) - (long long)blk;
+                if (d > far_blocks || d < -far_blocks) c |= 1 << 30;
+            }
             for (int i = 0; i < len; ++i) code[idx[p + i]] = c;
             if (slot >= 0) {
                 hot_cols[blk * H + slot] = key;
@@ -1628,17 +1638,20 @@ void free_staging(StagingTables* t) {
 }
 
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, int H, StagingTables* out, hipStream_t st) {
+                                const float* val_p, const int32_t* perm, int H, StagingTables* out, hipStream_t st) {
     *out = StagingTables();
     if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0) return hipErrorInvalidValue;
     const int64_t nblk = (M + kStagedBlockRows - 1) / kStagedBlockRows;
-    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr;
+    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr, *pos = nullptr;
     unsigned long long* staged = nullptr;
+    // "far" columns (square matrices only): more than this many blocks away in the clustered order. 0 = off.
+    static const int far_env = getenv("GESPMM_STAGED_FAR_BLOCKS") ? atoi(getenv("GESPMM_STAGED_FAR_BLOCKS")) : 64;
+    const bool mark_far = perm && M == K && far_env > 0 && K < (1 << 22);
     void* tmp = nullptr;
     StagingTables t;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(st);
-        void* ptrs[] = {blkoff, keys, idx_in, idx_out, code, staged, tmp};
+        void* ptrs[] = {blkoff, keys, idx_in, idx_out, code, staged, tmp, pos};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
     };
@@ -1651,6 +1664,10 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&code), (size_t)nnz * 4));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&staged), 8));
         GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
+        if (mark_far) {
+            GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&pos), (size_t)M * 4));
+            hipLaunchKernelGGL(k_stage_positions, dim3(grid_for(M)), dim3(256), 0, st, perm, M, pos);
+        }
         hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, blkoff);
         hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
         int bits = 1;
@@ -1669,7 +1686,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + kStagedPad) * 8));
         GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0, (size_t)nblk * H * 4, st));
         hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
-                           (const int32_t*)idx_out, H, code, t.hot_cols, t.nhot, staged);
+                           (const int32_t*)idx_out, H, (const int32_t*)pos, far_env, code, t.hot_cols, t.nhot, staged);
         hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, t.tasks);
         hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz + kStagedPad)), dim3(256), 0, st, (const int32_t*)code, val_p, nnz,
                            nnz + kStagedPad, t.ev);

@@ -111,6 +111,8 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
         rend_next = rowptr[nx + 1];
         crow_next = perm[nx];
     };
+    // code: bit 31 = staged (low bits: LDS slot); else column, bit 30 = "far": the row lives in a distant part of the clustered order,
+    // nobody near this block will ask for it again — gathered with `nt` so that it does not push the neighbourhood's rows out of L2
     auto gather = [&](int code, vec_t& d) {
         // (the reference to s_hot keeps the staging stores alive: the LDS reads below are invisible to the compiler)
         const uint32_t voff =
@@ -119,7 +121,12 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
             asm volatile(
                 "s_cmp_lt_i32 %2, 0\n\t"
                 "s_cbranch_scc1 1f\n\t"
+                "s_bitcmp1_b32 %2, 30\n\t"
+                "s_cbranch_scc1 3f\n\t"
                 "global_load_dwordx2 %0, %1, %3\n\t"
+                "s_branch 2f\n"
+                "3:\n\t"
+                "global_load_dwordx2 %0, %1, %3 nt\n\t"
                 "s_branch 2f\n"
                 "1:\n\t"
                 "ds_read_b64 %0, %1\n"
@@ -131,7 +138,12 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
             asm volatile(
                 "s_cmp_lt_i32 %2, 0\n\t"
                 "s_cbranch_scc1 1f\n\t"
+                "s_bitcmp1_b32 %2, 30\n\t"
+                "s_cbranch_scc1 3f\n\t"
                 "global_load_dwordx4 %0, %1, %3\n\t"
+                "s_branch 2f\n"
+                "3:\n\t"
+                "global_load_dwordx4 %0, %1, %3 nt\n\t"
                 "s_branch 2f\n"
                 "1:\n\t"
                 "ds_read_b128 %0, %1\n"
