@@ -128,3 +128,55 @@ def test_hub_rows_keep_the_streaming_kernels(pkg, oracle):
     assert "kernel=staged-rows" not in plan.describe(), plan.describe()
     got = spmm.csr_spmm(rp, ci, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
     assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
+
+
+def _random_local_csr(rng, M, K, max_deg, local, p_empty):
+    """Rows whose columns come mostly from a window around the row (shared inside a block), the rest from anywhere;
+    repeated and unsorted columns, empty rows."""
+    degs = rng.randint(1, max_deg + 1, size=M)
+    degs[rng.rand(M) < p_empty] = 0
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    rows = np.repeat(np.arange(M), degs)
+    near = (rows * K // max(M, 1) + rng.randint(-local, local + 1, size=rows.size)) % K
+    far = rng.randint(0, K, size=rows.size)
+    colind = np.where(rng.rand(rows.size) < 0.75, near, far).astype(np.int32)
+    return rowptr, colind
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_matrices_equal_the_plain_call(pkg, oracle, seed):
+    """Seeded random matrices, square (far columns marked) and rectangular, 1 .. 6000 rows, rows up to the 2048-entry limit:
+    the staged kernel's bits = the plain call's strict-order bits (which the other tests pin to the oracle)."""
+    from gespmm_amd import spmm
+
+    rng = np.random.RandomState(1000 + seed)
+    M = int(rng.choice([1, 2, 127, 128, 129, 700, 3000, 6000]))
+    K = M if seed % 3 else int(rng.randint(1, 5000))
+    max_deg = int(rng.choice([3, 40, 300]))
+    rowptr, colind = _random_local_csr(rng, M, K, max_deg, local=int(rng.choice([2, 30, 400])), p_empty=float(rng.choice([0.0, 0.3])))
+    if seed % 4 == 1 and M >= 128:  # one row at the limit
+        extra = rng.randint(0, K, size=2048).astype(np.int32)
+        r = int(rng.randint(0, M))
+        colind = np.concatenate([colind[:rowptr[r]], extra, colind[rowptr[r + 1]:]])
+        d = 2048 - (rowptr[r + 1] - rowptr[r])
+        rowptr = rowptr.copy()
+        rowptr[r + 1:] += d
+    if colind.size == 0:
+        colind = np.zeros(1, dtype=np.int32)
+        rowptr[-1] = 1 if M == 1 else rowptr[-1]
+        rowptr[1:] = np.maximum(rowptr[1:], 0)
+        rowptr[M] = 1
+    rp, ci = _dev(rowptr), _dev(colind)
+    val = _dev(oracle.hash_val(colind.size, seed=seed))
+    for N in (128, 256):
+        B = _dev(oracle.hash_B(K, N, seed=seed + N))
+        plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x100)
+        if plan.clustered:  # (matrices of a few rows keep their storage order: nothing to stage)
+            assert "kernel=staged-rows" in plan.describe(), plan.describe()
+        want = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x100})
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (seed, M, K, N, max_deg)
+        want_u = spmm.csr_spmm_no_edge_value(rp, ci, B, cfg={"flags": 0x100})
+        got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan)
+        assert torch.equal(got_u.view(torch.int32), want_u.view(torch.int32)), (seed, M, K, N, "unweighted")
