@@ -37,6 +37,13 @@ want = C.clone()
 print("library, plan path: %.1f us" % t_plan)
 
 perm = plan.order().cuda().to(torch.int64) if plan.clustered else torch.arange(M, device="cuda")
+if os.environ.get("TRANSPOSE"):
+    # rows of every 128-row block dealt round-robin to the 16 wavefronts: at any moment the block works on CONSECUTIVE rows
+    Tw = int(os.environ["TRANSPOSE"])   # wavefronts
+    Rb = 128
+    full = (M // Rb) * Rb
+    idx = torch.arange(full, device="cuda").view(-1, Rb // Tw, Tw).transpose(1, 2).reshape(-1)
+    perm = torch.cat([perm[idx], perm[full:]])
 deg = (rp[1:] - rp[:-1]).to(torch.int64)
 lens = deg[perm]
 rp_p = torch.zeros(M + 1, dtype=torch.int64, device="cuda")
@@ -87,7 +94,9 @@ for R, H, WAVES in cfgs:
     rp32 = rp_p.to(torch.int32)
     perm32 = perm.to(torch.int32)
     del key, u, inv, cnt, ublk, o, rank, code
-    for mode in ((7, 10, 11, 20, 21) if os.environ.get('FLOOR') else ((10, 12, 13, 14) if os.environ.get('DEBUG') else (7, 10, 11))):
+    modes = (7, 10, 11, 20, 21) if os.environ.get('FLOOR') else ((10, 12, 13, 14) if os.environ.get('DEBUG') else (7, 10, 11))
+    if os.environ.get('MODES'): modes = tuple(int(x) for x in os.environ['MODES'].split(','))
+    for mode in modes:
         C.zero_()
         codes = code32
         allstaged = mode >= 16
