@@ -828,17 +828,17 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             lap("values");
             // ---- staged-rows kernel: worth its tables where a block of 128 clustered rows uses the same B rows again and
-            // again (profiles/r03/staged_rows.log; products-shaped communities: 2.95 vs 3.82 ms at N = 128, 7.14 vs 7.56 ms at
-            // N = 256). At N = 128 one row is half of what a load instruction could carry, so short rows lose what staging wins
-            // (com-Amazon-shaped communities: 121 vs 109 us) and the rule asks for mean degree >= 12; at N = 256 a row fills the
-            // instruction and short rows win too (185 vs 199 us). One wavefront walks a row's entries one after the other, so hub
-            // rows stay with the streaming kernels.
+            // again (profiles/r03/staged_rows.log; products-shaped communities: 2.95 vs 3.82 ms at N = 128, 6.4 vs 7.7 ms at
+            // N = 256). On short rows it is level at best (com-Amazon-shaped communities, N = 128: 109-121 vs 106 us — a row is
+            // half of what a load instruction could carry; N = 256: 192 vs 213 us on one box, 210 vs 198 us on another,
+            // plan_audit.log), so AUTO asks for mean degree >= 12. One wavefront walks a row's entries one after the other, so
+            // hub rows stay with the streaming kernels.
             {
                 const int H = gespmm::staged_rows_per_block_lds(N);
                 const bool fits = H > 0 && nnz > 0 && (uint64_t)K * (uint64_t)N * 4ull < 0xFFFF0000ull && p->max_degree <= 2048 &&
                                   !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS);
                 const bool want = p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
-                                  (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && (mean >= 12 || N >= 256) && p->hits_after >= 0.40 &&
+                                  (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= 12 && p->hits_after >= 0.40 &&
                                    nnz >= (1 << 20) &&
                                    (variant == GESPMM_VARIANT_AUTO || variant == GESPMM_VARIANT_CRC_CWM4 ||
                                     variant == GESPMM_VARIANT_CRC_CWM8));

@@ -293,7 +293,7 @@ typedef struct gespmm_plan_options {
                                           to every row of the task that uses it (N >= 64, no long-row pass) */
 #define GESPMM_PLAN_KERNEL_STAGED 5     /* scalar-stream walk + the most used B rows of every 128-row block staged in LDS (N = 128 / 256, sum
                                           reducer, device analysis, longest row <= 2048); AUTO takes it for clustered matrices when
-                                          >= 40 % (N = 128, mean degree >= 12) or >= 30 % (N = 256) of the entries find their B row staged */
+                                          the mean degree is >= 12 and >= 40 % (N = 128) / >= 30 % (N = 256) of the entries find their B row staged */
 #define GESPMM_PLAN_KERNEL_LDS_ROWS 2  /* distinct B rows of a task fetched once into LDS (N % 4 == 0, no long-row pass) */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,

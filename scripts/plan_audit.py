@@ -53,7 +53,7 @@ for name, g in cases():
     M, K, nnz = g["M"], g["K"], g["nnz"]
     rp, ci = g["rowptr"], g["colind"]
     val = torch.rand(nnz, device=dev) - 0.5
-    for N in (32, 128, 512):
+    for N in (32, 128, 256, 512):
         if 4.0 * (M + K) * N > 40e9:
             continue
         B = torch.rand(K, N, device=dev) - 0.5
@@ -67,9 +67,20 @@ for name, g in cases():
         t_plan = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan), iters)
         same = torch.equal(C.view(torch.int32), ref.view(torch.int32))
         flag = "  <-- plan loses" if t_plan > 1.05 * t_plain else ""
-        print("%-46s N=%-3d plain %9.1f us  plan %9.1f us  x%.2f  bits=%s  analysis %.2fs  %s%s" %
+        kern = "staged-rows" if "kernel=staged-rows" in plan.describe() else ""
+        if kern:  # AUTO took the staged-rows kernel: what would the streaming kernels of the same plan have done?
+            best = None
+            for k2 in ("stream", "seg-stream"):
+                p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, kernel=k2)
+                t2 = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p2), iters)
+                best = t2 if best is None else min(best, t2)
+                del p2
+            kern += " (streaming kernels of the same plan: %.1f us, x%.2f)" % (best, best / t_plan)
+            if t_plan > 1.03 * best:
+                flag += "  <-- staged loses"
+        print("%-46s N=%-3d plain %9.1f us  plan %9.1f us  x%.2f  bits=%s  analysis %.2fs  %s %s%s" %
               (name, N, t_plain, t_plan, t_plain / t_plan, "same" if same else "LONG-ROW-REASSOC", dt,
-               plan.describe().split(" ")[0], flag), flush=True)
+               plan.describe().split(" ")[0], kern, flag), flush=True)
         del plan, B, C, ref
     del g
     torch.cuda.empty_cache()
