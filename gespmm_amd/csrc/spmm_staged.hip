@@ -89,6 +89,9 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
         __builtin_amdgcn_s_waitcnt(0);  // the compiler's scoreboard is clean when the assembly gathers start
     }
     if (nrows == 0) return;
+    // one offset serves both paths (LDS address of a staged row / byte offset into B): the staging array must sit at LDS address 0
+    // (it is the kernel's only LDS object; a compile-time constant — the check folds away)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) f4v*)s_hot != 0u) __builtin_trap();
     int cur = 0;
     int rend = rowptr[1], rend_next = rowptr[nrows > 1 ? 2 : 1];
     int crow = perm[0], crow_next = perm[nrows > 1 ? 1 : 0];
