@@ -1,9 +1,11 @@
 #!/bin/bash
 # Fabric reads / L2 hits of the experiment kernels on products-sbm: scalar walk with nothing staged (mode 4) vs staged (mode 11), same tasks.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-for set in "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum"; do
+CFG=${CFG:-128,128,16}; MODES=${MODES:-4,11}; export MODES
+echo "== block rows, staged rows, wavefronts per block = $CFG; modes $MODES"
+for set in "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   P=/tmp/hr_pmc; rm -rf $P; mkdir -p $P
-  MODES=4,11 timeout 900 rocprofv3 --pmc $set --output-format csv -d $P -o c -- python profiles/r03/experiments/hotrows_time.py products-sbm 128,128,16 > /dev/null 2>&1
+  timeout 900 rocprofv3 --pmc $set --output-format csv -d $P -o c -- python profiles/r03/experiments/hotrows_time.py products-sbm $CFG > /dev/null 2>&1
   f=$(find $P -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

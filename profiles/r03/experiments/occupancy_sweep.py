@@ -58,7 +58,8 @@ for budget in budgets:
     for mode, colarr, what in ((4, ci_p, "64 lanes x dwordx2"), (8, ci_p, "32 lanes x dwordx4"), (9, ci_p, "32 lanes x dwordx4 U=16"),
                                (4, ci_res, "64 lanes x dwordx2, B rows from a 2 MB table"), (8, ci_res, "32 lanes x dwordx4, B rows from a 2 MB table"),
                                (9, ci_res, "32 lanes x dwordx4 U=16, B rows from a 2 MB table")):
-        for wgs in (0,):
+        if os.environ.get("PMC_ONLY") and (mode != 4 or colarr is not ci_p): continue
+        for wgs in ((0, 8, 6, 4, 2) if os.environ.get("PMC_ONLY") else (0,)):
             fn = lambda: lib.hotrows_spmm(wgs, 1, mode, rp32.data_ptr(), colarr.data_ptr(), val_p.data_ptr(), perm32.data_ptr(),
                                           tasks.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), B.data_ptr(), C.data_ptr(), nt,
                                           K * N * 4, stream)
