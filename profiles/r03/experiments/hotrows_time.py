@@ -129,5 +129,5 @@ for R, H, WAVES in cfgs:
                 print("   row %d at position %d (degree %d, entries %d..%d) task %d = %s | got %s want %s" % (r, pp, int(lens[pp]), int(rp_p[pp]), int(rp_p[pp + 1]), tix, tk, C[r, :3].tolist(), want[r, :3].tolist()))
         t = timed(fn)
         print("R=%3d H=%3d waves=%2d mode=%d (%s): %8.1f us  x%.2f vs plan  bits=%s | staged entries %.1f%%, L2 requests saved %.1f%%, mean staged rows %.0f"
-              % (R, H, WAVES, mode, ("flat", "lds|global", "nothing staged", "buffer|lds", "scalar-stream U=8", "scalar-stream U=16", "scalar-stream + staged rows U=8", "scalar-stream + staged rows U=16", "", "", "lean scalar + staged U=8", "lean scalar + staged U=16", "lean, C++ fma", "lean, lds base added", "lean, both")[mode] + (" ALL entries staged (floor)" if allstaged else ""), t, t_plan / t, same, 100 * frac_hot, 100 * saved,
+              % (R, H, WAVES, mode, ("flat", "lds|global", "nothing staged", "buffer|lds", "scalar-stream U=8", "scalar-stream U=16", "scalar-stream + staged rows U=8", "scalar-stream + staged rows U=16", "", "", "lean scalar + staged U=8", "lean scalar + staged U=16", "lean, C++ fma", "lean, lds base added", "lean, EXEC-masked paths instead of branches")[mode] + (" ALL entries staged (floor)" if allstaged else ""), t, t_plan / t, same, 100 * frac_hot, 100 * saved,
                  float(nhot.float().mean())), flush=True)

@@ -621,6 +621,19 @@ __global__ __launch_bounds__(WAVES * 64) void scalar_hot2_kernel(HotArgs a) {
         uint32_t voff = ((uint32_t)code << 9) + loff;
         // (the reference to s_hot is what keeps the staging stores alive: the reads below are invisible to the compiler)
         voff += (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f2*)s_hot;
+        if constexpr (DBG & 4) {
+            // no branches: the path not taken runs with EXEC = 0 (is a vector memory instruction without active lanes free?)
+            asm volatile(
+                "s_cmp_lt_i32 %2, 0\n\t"
+                "s_cselect_b64 exec, 0, -1\n\t"
+                "global_load_dwordx2 %0, %1, %3\n\t"
+                "s_not_b64 exec, exec\n\t"
+                "ds_read_b64 %0, %1\n\t"
+                "s_mov_b64 exec, -1"
+                : "=&v"(d)
+                : "v"(voff), "s"(code), "s"(Bp)
+                : "memory", "scc");
+        } else
         asm volatile(
             "s_cmp_lt_i32 %2, 0\n\t"
             "s_cbranch_scc1 1f\n\t"
@@ -736,7 +749,7 @@ extern "C" int hotrows_spmm(int H, int waves, int mode, const int32_t* rowptr, c
     if (mode >= 12 && mode <= 14 && H == h && waves == w) {                                                          \
         if (mode == 12) hipLaunchKernelGGL((scalar_hot2_kernel<h, w, 8, 1>), dim3((unsigned)nblocks), dim3(w * 64), 0, st, a); \
         if (mode == 13) hipLaunchKernelGGL((scalar_hot2_kernel<h, w, 8, 2>), dim3((unsigned)nblocks), dim3(w * 64), 0, st, a); \
-        if (mode == 14) hipLaunchKernelGGL((scalar_hot2_kernel<h, w, 8, 3>), dim3((unsigned)nblocks), dim3(w * 64), 0, st, a); \
+        if (mode == 14) hipLaunchKernelGGL((scalar_hot2_kernel<h, w, 8, 4>), dim3((unsigned)nblocks), dim3(w * 64), 0, st, a); \
         return (int)hipGetLastError();                                                                               \
     }                                                                                                                \
     if (mode == 7 && H == h && waves == w) {                                                                         \
