@@ -359,6 +359,11 @@ def main():
                         med3 = statistics.median(kernel_times_us(st3, 10))
                         row[label] = {"kernel_us": med3, "gflops": 2.0 * g3["nnz"] * n3 / med3 / 1e3,
                                       "achieved_GBs": ab3 / med3 / 1e3, "frac": ab3 / med3 / 1e3 / HBM_PEAK_GBS}
+                    if pname == "products-sbm" and n3 == 128:  # counters of this launch: scripts/gpu_profile_r03b.sh
+                        tb, tsrc, thit = traffic_for("products-sbm/N128/valued/plan")
+                        row["plan"].update({"traffic": tb, "traffic_source": tsrc, "l2_hit_rate": thit,
+                                            "traffic_GBs": (tb / row["plan"]["kernel_us"] / 1e3) if tb else None,
+                                            "algorithmic_bytes_per_launch": ab3})
                     sweep["N%d" % n3] = row
                     del B3, C3
                 extra["%s_sweep_valued" % pname] = sweep
