@@ -58,7 +58,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
 hipError_t device_staging_set_values(int32_t* ev, const float* val_p, int64_t nnz, hipStream_t st);
 void free_staging(StagingTables* t);
 
-// Frees the analysis arena kept for the next plan (up to 4 GiB of device memory; GESPMM_ARENA_CACHE_MB).
+// Frees the analysis arena kept for the next plan (up to 1/16 of the device memory, at most 16 GiB; GESPMM_ARENA_CACHE_MB).
 void release_cached_arena();
 
 }  // namespace gespmm

@@ -62,16 +62,23 @@ namespace {
 // is rewound at phase boundaries. A request that does not fit its region gets a block of its own (correct, just
 // slower), so the size estimates need not be tight.
 //
-// The block comes from plain hipMalloc through a one-entry cache (blocks up to 4 GiB — GESPMM_ARENA_CACHE_MB — are kept for the next plan), NOT
+// The block comes from plain hipMalloc through a one-entry cache (blocks up to 1/16 of the device memory, at most 16 GiB — GESPMM_ARENA_CACHE_MB — are kept for the next plan), NOT
 // from the library's stream-ordered pool: with hipMallocFromPoolAsync / hipFreeAsync cycles of changing sizes interleaved
 // with the plan's own hipMalloc calls, analysis results came out corrupted in processes without PyTorch's allocator in
 // them (the spmm_test driver: wrong task tables, then a memory fault in the first launch; profiles/r03/pool_hazard.log).
 // The analysis synchronises the stream anyway, so a synchronous free costs nothing here.
-// 4 GiB covers a products-sized matrix (2.4 M rows, 124 M entries: ~2.5 GB). Larger analyses allocate and free a private block —
-// and a multi-GB hipMalloc right after another library returned a lot of memory to the driver was seen to take seconds
-// (profiles/r03/plan_repeat.log: 65 ms -> 3.1 s for the same analysis after torch.cuda.empty_cache()).
+// A products-sized analysis (2.4 M rows, 124 M entries) takes ~10 GB for its clustering arena and ~2.5 GB for the model / staging
+// passes. Blocks up to 1/16 of the device's memory (at most 16 GiB; GESPMM_ARENA_CACHE_MB) are kept for the next plan: a multi-GB
+// hipMalloc was seen to take SECONDS now and then — after another library returned memory to the driver, or for no visible reason
+// (profiles/r03/plan_repeat.log: the same 87 ms analysis took 1.9-3.6 s once in every few plans while its arena was a private block).
 static size_t arena_cache_cap() {
-    static const size_t cap = getenv("GESPMM_ARENA_CACHE_MB") ? (size_t)atoll(getenv("GESPMM_ARENA_CACHE_MB")) << 20 : 4096ull << 20;
+    static const size_t cap = []() -> size_t {
+        if (getenv("GESPMM_ARENA_CACHE_MB")) return (size_t)atoll(getenv("GESPMM_ARENA_CACHE_MB")) << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4096 << 20;
+        const size_t sixteenth = total_b / 16, top = (size_t)16384 << 20;
+        return sixteenth < top ? sixteenth : top;
+    }();
     return cap;
 }
 struct ArenaCache {
@@ -1642,44 +1649,41 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     *out = StagingTables();
     if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0) return hipErrorInvalidValue;
     const int64_t nblk = (M + kStagedBlockRows - 1) / kStagedBlockRows;
-    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr, *pos = nullptr;
-    unsigned long long* staged = nullptr;
     // "far" columns (square matrices only): more than this many blocks away in the clustered order. 0 = off.
     static const int far_env = getenv("GESPMM_STAGED_FAR_BLOCKS") ? atoi(getenv("GESPMM_STAGED_FAR_BLOCKS")) : 64;
     const bool mark_far = perm && M == K && far_env > 0 && K < (1 << 22);
-    void* tmp = nullptr;
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < K) ++bits;
+    size_t sort_bytes = 0;
+    GESPMM_TRY(rocprim::segmented_radix_sort_pairs(nullptr, sort_bytes, colind_p, (int32_t*)nullptr, (const int32_t*)nullptr,
+                                                   (int32_t*)nullptr, (size_t)nnz, (unsigned)nblk, (const int32_t*)nullptr,
+                                                   (const int32_t*)nullptr, 0u, (unsigned)bits, st));
+    // temporaries (16 bytes per entry + the sort's own) from the analysis arena: a products-sized matrix needs ~2.5 GB here, about
+    // what its clustering needed a moment ago — the cached block is reused instead of a multi-GB hipMalloc / hipFree per plan
+    Scratch sc(st);
+    GESPMM_TRY(sc.init(0, 0, 16 * (size_t)nnz + 4 * (size_t)(M + nblk) + sort_bytes + (8 << 20)));
+    sc.use(Scratch::kTemp);
+    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr, *pos = nullptr;
+    unsigned long long* staged = nullptr;
+    char* tmp = nullptr;
+    GESPMM_TRY(sc.get(&blkoff, nblk + 1));
+    GESPMM_TRY(sc.get(&keys, nnz));
+    GESPMM_TRY(sc.get(&idx_in, nnz));
+    GESPMM_TRY(sc.get(&idx_out, nnz));
+    GESPMM_TRY(sc.get(&code, nnz));
+    GESPMM_TRY(sc.get(&staged, 1));
+    GESPMM_TRY(sc.get(&tmp, (int64_t)(sort_bytes ? sort_bytes : 256)));
+    if (mark_far) GESPMM_TRY(sc.get(&pos, M));
     StagingTables t;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(st);
-        void* ptrs[] = {blkoff, keys, idx_in, idx_out, code, staged, tmp, pos};
-        for (void* q : ptrs)
-            if (q) (void)hipFree(q);
-    };
     auto body = [&]() -> hipError_t {
-        // (plain hipMalloc: these are gigabyte-sized for products-sized graphs and live for this call only)
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&blkoff), (size_t)(nblk + 1) * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&keys), (size_t)nnz * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&idx_in), (size_t)nnz * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&idx_out), (size_t)nnz * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&code), (size_t)nnz * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&staged), 8));
         GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
-        if (mark_far) {
-            GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&pos), (size_t)M * 4));
-            hipLaunchKernelGGL(k_stage_positions, dim3(grid_for(M)), dim3(256), 0, st, perm, M, pos);
-        }
+        if (mark_far) hipLaunchKernelGGL(k_stage_positions, dim3(grid_for(M)), dim3(256), 0, st, perm, M, pos);
         hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, blkoff);
         hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
-        int bits = 1;
-        while (bits < 32 && ((int64_t)1 << bits) < K) ++bits;
-        size_t bytes = 0;
-        GESPMM_TRY(rocprim::segmented_radix_sort_pairs(nullptr, bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
+        GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, sort_bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
                                                        (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
                                                        (unsigned)bits, st));
-        GESPMM_TRY(hipMalloc(&tmp, bytes ? bytes : 256));
-        GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
-                                                       (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
-                                                       (unsigned)bits, st));
+        // the tables themselves belong to the plan: blocks of their own
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.hot_cols), (size_t)nblk * H * 4));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.nhot), (size_t)nblk * 4));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.tasks), (size_t)nblk * kStagedWaves * 16));
@@ -1692,14 +1696,14 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
                            nnz + kStagedPad, t.ev);
         GESPMM_TRY(hipGetLastError());
         unsigned long long h = 0;
-        GESPMM_TRY(fetch(&h, (const unsigned long long*)staged, 1, st));
+        GESPMM_TRY(fetch(&h, (const unsigned long long*)staged, 1, st));  // (synchronises: the temporaries may go)
         t.nblocks = (int32_t)nblk;
         t.staged_fraction = (double)h / (double)nnz;
         return hipSuccess;
     };
     const hipError_t e = body();
-    cleanup();
     if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
         free_staging(&t);
         return e;
     }

@@ -314,7 +314,7 @@ int gespmm_plan_get_order(const gespmm_plan* plan, int32_t* perm_host);
 /* One line of text: order, cluster hierarchy, tasks, modelled L2 hit rate before -> after, analysis time, launch. */
 int gespmm_plan_describe(const gespmm_plan* plan, char* out, int64_t capacity);
 void gespmm_plan_destroy(gespmm_plan* plan);
-/* The analysis stage keeps its scratch arena (<= 4 GiB of device memory, GESPMM_ARENA_CACHE_MB to change the cap) for the next plan; this gives it back. */
+/* The analysis stage keeps its scratch arena (<= 1/16 of the device memory and <= 16 GiB; GESPMM_ARENA_CACHE_MB changes the cap) for the next plan; this gives it back. */
 void gespmm_release_cached_memory(void);
 
 /*
