@@ -26,8 +26,10 @@ for arg in sys.argv[1:]:
         "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4),
         "kernel": kern,
         "csrc_sha16": csrc_fingerprint(),
-        "source": "%s (2*FETCH_SIZE + WRITE_SIZE, KiB->B; separate --pmc passes of `python bench.py --no-extra --no-cpu-baseline "
-                  "--steps 50 --warmup 5 ...`; memory-side requests include Infinity-Cache hits)" % os.path.relpath(f, ROOT),
+        "source": "%s (2*FETCH_SIZE + WRITE_SIZE, KiB->B; separate --pmc passes of `%s`; memory-side requests include Infinity-Cache hits)"
+                  % (os.path.relpath(f, ROOT),
+                     "python profiles/r03/experiments/narrow_rows_sbm.py 128" if key.startswith("products-sbm")
+                     else "python bench.py --no-extra --no-cpu-baseline --steps 50 --warmup 5 ..."),
     }
     data[key] = entry
     print(key, entry["bytes_per_launch"], entry["l2_hit_rate"])
