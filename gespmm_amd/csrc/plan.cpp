@@ -827,26 +827,27 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             lap("values");
-            // ---- staged-rows kernel: worth its tables where a block of 128 clustered rows uses the same B rows again and
-            // again (profiles/r03/staged_rows.log; products-shaped communities: 2.95 vs 3.82 ms at N = 128, 6.4 vs 7.7 ms at
-            // N = 256). On short rows it is level at best (com-Amazon-shaped communities, N = 128: 109-121 vs 106 us — a row is
-            // half of what a load instruction could carry; N = 256: 192 vs 213 us on one box, 210 vs 198 us on another,
-            // plan_audit.log), so AUTO asks for mean degree >= 12. One wavefront walks a row's entries one after the other, so
-            // hub rows stay with the streaming kernels.
+            // ---- staged-rows kernel: worth its tables where a block of clustered rows uses the same B rows again and again
+            // (profiles/r03/staged_rows.log, staged_degree_sweep.log; products-shaped communities: 3.0 vs 3.9 ms at N = 128, 5.8 vs
+            // 7.8 ms at N = 256). At N = 128 a row is half of what a load instruction could carry and short rows are level at best
+            // (com-Amazon-shaped communities: 108 vs 106 us; mean degree 8: 239 vs 236 us; from 12 on: 9-15 % ahead) — AUTO asks for
+            // mean degree >= 12; at N = 256 short rows win as well (com-Amazon-shaped: 196 vs 208 us; mean degree 8: 416 vs 450 us).
+            // One wavefront walks a row's entries one after the other, so hub rows stay with the streaming kernels.
             {
                 const int H = gespmm::staged_rows_per_block_lds(N);
                 const bool fits = H > 0 && nnz > 0 && (uint64_t)K * (uint64_t)N * 4ull < 0xFFFF0000ull && p->max_degree <= 2048 &&
                                   !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS);
                 const bool want = p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
-                                  (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= 12 && p->hits_after >= 0.40 &&
+                                  (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= (N >= 256 ? 5 : 12) && p->hits_after >= 0.40 &&
                                    nnz >= (1 << 20) &&
                                    (variant == GESPMM_VARIANT_AUTO || variant == GESPMM_VARIANT_CRC_CWM4 ||
                                     variant == GESPMM_VARIANT_CRC_CWM8));
                 if (e == hipSuccess && fits && want) {
                     const auto ts = std::chrono::steady_clock::now();
-                    e = gespmm::device_build_staging(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, p->d_perm, H, &p->stg, st);
+                    e = gespmm::device_build_staging(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, p->d_perm,
+                                                     gespmm::staged_block_rows(N), H, &p->stg, st);
                     p->staging_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
-                    if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && p->stg.staged_fraction < (N >= 256 ? 0.30 : 0.40))
+                    if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && p->stg.staged_fraction < 0.40)
                         gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay
                     lap("staging tables");
                 }

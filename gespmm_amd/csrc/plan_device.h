@@ -40,7 +40,7 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
                             int32_t* tasks[2], int32_t ntasks_host[2], hipStream_t st);
 
 // Tables of spmm_staged.hip for the clustered matrix (rowptr_p / colind_p / val_p = the plan's row-permuted copy; val_p NULL:
-// unweighted, the stream carries 1.0f): blocks of kStagedBlockRows rows, per block the <= H columns its entries use most often
+// unweighted, the stream carries 1.0f): blocks of R rows, per block the <= H columns its entries use most often
 // (>= 2 uses), kStagedWaves tasks, and the interleaved {code, value} stream. staged_fraction = share of the entries whose B row
 // comes from LDS. Deterministic (ties in column order). The four arrays are hipMalloc blocks owned by the caller (free_staging).
 struct StagingTables {
@@ -52,9 +52,9 @@ struct StagingTables {
     double staged_fraction = 0.0;
 };
 // perm (clustered position -> original row; may be NULL): on square matrices a column whose own row is processed more than
-// GESPMM_STAGED_FAR_BLOCKS (default 64) blocks away is marked "far" (bit 30 of its code): gathered with `nt`.
+// GESPMM_STAGED_FAR_BLOCKS (default 64) x 128 rows away is marked "far" (bit 30 of its code): gathered with `nt`.
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, const int32_t* perm, int H, StagingTables* out, hipStream_t st);
+                                const float* val_p, const int32_t* perm, int R, int H, StagingTables* out, hipStream_t st);
 hipError_t device_staging_set_values(int32_t* ev, const float* val_p, int64_t nnz, hipStream_t st);
 void free_staging(StagingTables* t);
 

@@ -1486,7 +1486,7 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
 
 // ------------------------------------------------------------------------------------------------ staging tables (spmm_staged.hip)
 //
-// Blocks of kStagedBlockRows consecutive rows of the clustered matrix. Per block: the block's column indices sorted (one segment of
+// Blocks of R consecutive rows of the clustered matrix (R = staged_block_rows(N)). Per block: the block's column indices sorted (one segment of
 // a segmented radix sort, payload = position of the entry), runs of equal columns = how often the block uses a B row; the H
 // most used ones (>= 2 uses; ties taken in column order, so the tables are the same on every build) get LDS slots.
 
@@ -1494,10 +1494,10 @@ namespace {
 
 constexpr int kStageHistBins = 256;
 
-__global__ void k_stage_offsets(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int32_t* __restrict__ blkoff) {
+__global__ void k_stage_offsets(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int32_t* __restrict__ blkoff) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nblk) return;
-    const int64_t r = i * kStagedBlockRows < M ? i * kStagedBlockRows : M;
+    const int64_t r = i * R < M ? i * R : M;
     blkoff[i] = rowptr_p[r];
 }
 
@@ -1512,7 +1512,7 @@ __global__ void k_stage_positions(const int32_t* __restrict__ perm, int64_t M, i
 }
 
 __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict__ blkoff, const int32_t* __restrict__ keys,
-                                                       const int32_t* __restrict__ idx, int H, const int32_t* __restrict__ pos,
+                                                       const int32_t* __restrict__ idx, int H, int R, const int32_t* __restrict__ pos,
                                                        int far_blocks, int32_t* __restrict__ code,
                                                        int32_t* __restrict__ hot_cols, int32_t* __restrict__ nhot,
                                                        unsigned long long* __restrict__ staged_entries) {
@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
         if (len > 0) {
             int c = slot >= 0 ? (int)(0x80000000u | (unsigned)slot) : key;
             if (slot < 0 && pos) {  // square matrix: B row `key` is also row `key` of the matrix — how far away is it processed?
-                const long long d = (long long)(pos[key] / kStagedBlockRows) - (long long)blk;
+                const long long d = (long long)(pos[key] / kStagedFarUnitRows) - (long long)(blk * R / kStagedFarUnitRows);
                 if (d > far_blocks || d < -far_blocks) c |= 1 << 30;
             }
             for (int i = 0; i < len; ++i) code[idx[p + i]] = c;
@@ -1593,13 +1593,13 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
     if ((tid & 63) == 0 && mine) atomicAdd(staged_entries, mine);
 }
 
-__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int32_t* __restrict__ tasks) {
+__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int32_t* __restrict__ tasks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk * kStagedWaves) return;
     const int64_t blk = i / kStagedWaves;
     const int w = (int)(i % kStagedWaves);
-    const int b0 = (int)(blk * kStagedBlockRows);
-    const int b1 = (int)(b0 + kStagedBlockRows < M ? b0 + kStagedBlockRows : M);
+    const int b0 = (int)(blk * R);
+    const int b1 = (int)(b0 + R < M ? b0 + R : M);
     const int e0 = rowptr_p[b0], e1 = rowptr_p[b1];
     auto bound = [&](int ww) -> int {  // first row of part ww: the block's entries cut into kStagedWaves equal shares
         if (ww <= 0) return b0;
@@ -1645,10 +1645,10 @@ void free_staging(StagingTables* t) {
 }
 
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, const int32_t* perm, int H, StagingTables* out, hipStream_t st) {
+                                const float* val_p, const int32_t* perm, int R, int H, StagingTables* out, hipStream_t st) {
     *out = StagingTables();
-    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0) return hipErrorInvalidValue;
-    const int64_t nblk = (M + kStagedBlockRows - 1) / kStagedBlockRows;
+    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0) return hipErrorInvalidValue;
+    const int64_t nblk = (M + R - 1) / R;
     // "far" columns (square matrices only): more than this many blocks away in the clustered order. 0 = off.
     static const int far_env = getenv("GESPMM_STAGED_FAR_BLOCKS") ? atoi(getenv("GESPMM_STAGED_FAR_BLOCKS")) : 64;
     const bool mark_far = perm && M == K && far_env > 0 && K < (1 << 22);
@@ -1678,7 +1678,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     auto body = [&]() -> hipError_t {
         GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
         if (mark_far) hipLaunchKernelGGL(k_stage_positions, dim3(grid_for(M)), dim3(256), 0, st, perm, M, pos);
-        hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, blkoff);
+        hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, R, blkoff);
         hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
         GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, sort_bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
                                                        (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
@@ -1690,8 +1690,8 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + kStagedPad) * 8));
         GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0, (size_t)nblk * H * 4, st));
         hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
-                           (const int32_t*)idx_out, H, (const int32_t*)pos, far_env, code, t.hot_cols, t.nhot, staged);
-        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, t.tasks);
+                           (const int32_t*)idx_out, H, R, (const int32_t*)pos, far_env, code, t.hot_cols, t.nhot, staged);
+        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, R, t.tasks);
         hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz + kStagedPad)), dim3(256), 0, st, (const int32_t*)code, val_p, nnz,
                            nnz + kStagedPad, t.ev);
         GESPMM_TRY(hipGetLastError());

@@ -168,10 +168,10 @@ int outer_vec_width(int64_t N);  // floats per lane (1, 2, 4), 0 if this width i
 hipError_t launch_spmm_outer(const OuterArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
 
 // spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256, sum).
-// plan_device.hip (device_build_staging) writes the tables: blocks of kStagedBlockRows consecutive rows of the clustered matrix,
+// plan_device.hip (device_build_staging) writes the tables: blocks of staged_block_rows(N) consecutive rows of the clustered matrix,
 // kStagedWaves tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream
 // `ev` = {code, value bits} per entry (code >= 0: column; code < 0: staged slot in its low bits), padded by kStagedPad entries.
-constexpr int kStagedBlockRows = 128;
+constexpr int kStagedFarUnitRows = 128;  // GESPMM_STAGED_FAR_BLOCKS counts distances in units of this many rows
 constexpr int kStagedWaves = 16;
 constexpr int kStagedLdsBytes = 64 * 1024;
 constexpr int kStagedPad = 64;
@@ -187,6 +187,7 @@ struct StagedArgs {
     int32_t nblocks;
 };
 int staged_rows_per_block_lds(int64_t N);  // H for this width; 0 = width not served
+int staged_block_rows(int64_t N);          // rows per block: 96 at N = 128, 64 at N = 256 (profiles/r03/staged_rows.log)
 hipError_t launch_spmm_staged(const StagedArgs& a, int64_t N, hipStream_t st);
 
 // sddmm_kernels.hip

@@ -11,7 +11,7 @@
 //     same for the 64 lanes — the CSR stream (code, value), row ends, C row ids — lives in SGPRs and arrives through the scalar
 //     cache; "is this entry's B row staged?" is a SCALAR branch around one of {ds_read, global_load}: a staged entry issues no
 //     vector memory instruction at all;
-//   * a workgroup of 16 wavefronts owns a BLOCK of 128 consecutive rows of the plan's clustered matrix; the analysis
+//   * a workgroup of 16 wavefronts owns a BLOCK of 96 (N = 128) / 64 (N = 256) consecutive rows of the plan's clustered matrix; the analysis
 //     (plan_device.hip: device_build_staging) lists per block the <= H columns used most often inside it (>= 2 uses; H rows =
 //     64 KB) and rewrites the block's entries: code >= 0 = column, code < 0 = slot of the staged row. The workgroup copies the
 //     listed rows into LDS once, coalesced, then each wavefront walks its share of the block's rows as one stream;
@@ -203,6 +203,14 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
 }
 
 }  // namespace
+
+int staged_block_rows(int64_t N) {
+    // measured on the products-shaped community graph (us at N = 128 / 256): 64 rows 3286 / 5584, 80: 3122 / 5596, 96: 3012 / 5834,
+    // 112: 3120 / 6264, 128: 3065 / 6440 — about as many rows as LDS holds staged rows for the width's row size
+    if (N == 128) return 96;
+    if (N == 256) return 64;
+    return 0;
+}
 
 int staged_rows_per_block_lds(int64_t N) {
     if (N == 128) return kStagedLdsBytes / 512;

@@ -87,7 +87,7 @@ class SpmmPlan:
     launch reuses: the long-row decision from the longest row it
     saw, the split points of the cache-blocked path (dense graphs), and — for sparse graphs whose B exceeds the
     L2s — a row-CLUSTERED copy of the matrix with an nnz-balanced task table, so rows that share neighbours run
-    next to each other and find the shared B rows in L2 (and, at N = 128 / 256 where blocks of 128 clustered rows
+    next to each other and find the shared B rows in L2 (and, at N = 128 / 256 where blocks of 96 / 64 clustered rows
     reuse their B rows, the tables of the staged-rows kernel: those rows are read from LDS; made for THIS width
     only). Only the processing order changes: the result has the same bits as the plain call.
     ``kernel``: "auto" | "stream" | "seg-stream" | "staged" | "lds-rows" | "task-outer" (the last two: measured
