@@ -835,8 +835,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             // One wavefront walks a row's entries one after the other, so hub rows stay with the streaming kernels.
             {
                 const int H = gespmm::staged_rows_per_block_lds(N);
-                const bool fits = H > 0 && nnz > 0 && (uint64_t)K * (uint64_t)N * 4ull < 0xFFFF0000ull && p->max_degree <= 2048 &&
-                                  !(p->launch_flags & GESPMM_FLAG_SPLIT_LONG_ROWS);
+                const bool fits = H > 0 && nnz > 0 && (uint64_t)K * (uint64_t)N * 4ull < 0xFFFF0000ull;
                 const bool want = p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
                                   (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= (N >= 256 ? 5 : 12) && p->hits_after >= 0.40 &&
                                    nnz >= (1 << 20) &&
@@ -844,8 +843,28 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                                     variant == GESPMM_VARIANT_CRC_CWM8));
                 if (e == hipSuccess && fits && want) {
                     const auto ts = std::chrono::steady_clock::now();
-                    e = gespmm::device_build_staging(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, p->d_perm,
-                                                     gespmm::staged_block_rows(N), H, &p->stg, st);
+                    // hub rows (one wavefront would walk such a row alone) are taken out: the staged kernel sees them empty, the
+                    // streaming kernel's long-row pass gets them as one-row tasks (plan_run)
+                    const int32_t* rp_s = p->d_rowptr;
+                    const int32_t* ci_s = p->d_colind;
+                    const float* val_s = p->valued ? p->d_val : nullptr;
+                    int32_t* ci_tmp = nullptr;
+                    float* val_tmp = nullptr;
+                    int64_t nnz_s = nnz;
+                    if (p->max_degree > gespmm::kStagedMaxRow) {
+                        e = gespmm::device_split_long_rows(M, nnz, p->d_rowptr, p->d_colind, val_s, gespmm::kStagedMaxRow, &p->stg,
+                                                           &ci_tmp, &val_tmp, st);
+                        rp_s = p->stg.rowptr_s;
+                        ci_s = ci_tmp;
+                        val_s = val_tmp;
+                        nnz_s = p->stg.nnz_s;
+                    }
+                    if (e == hipSuccess && nnz_s > 0)
+                        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, gespmm::staged_block_rows(N), H,
+                                                         &p->stg, st);
+                    if (ci_tmp) (void)hipFree(ci_tmp);
+                    if (val_tmp) (void)hipFree(val_tmp);
+                    if (e == hipSuccess && !p->stg.ev) gespmm::free_staging(&p->stg);  // (nothing but hub rows)
                     p->staging_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
                     if (e == hipSuccess && p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && p->stg.staged_fraction < 0.40)
                         gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay
@@ -1029,8 +1048,20 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
                         (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
-        gespmm::StagedArgs sa = {p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols, p->stg.nhot, B, C, p->stg.nblocks};
-        return (int)gespmm::launch_spmm_staged(sa, N, reinterpret_cast<hipStream_t>(stream));
+        gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
+                                 p->stg.nhot, B, C, p->stg.nblocks};
+        rc = (int)gespmm::launch_spmm_staged(sa, N, reinterpret_cast<hipStream_t>(stream));
+        if (rc == 0 && p->stg.nlong > 0) {
+            // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits
+            // them — under GESPMM_FLAG_STRICT_ORDER each is one lane group's chain instead, as everywhere else
+            gespmm::PlanLaunch pl = {p->stg.ltasks, p->stg.nlong, p->d_perm, nullptr, 0, false};
+            gespmm_launch_cfg lcfg = cfg;
+            lcfg.flags = (lcfg.flags | GESPMM_FLAG_BATCH_STREAM | GESPMM_FLAG_NO_SLAB_BLOCKED) & ~GESPMM_FLAG_REUSE_SPLIT;
+            if (!(lcfg.flags & GESPMM_FLAG_STRICT_ORDER)) lcfg.flags |= GESPMM_FLAG_SPLIT_LONG_ROWS;
+            rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz, p->variant,
+                                  &lcfg, reduce, empty, stream, ws, ws_bytes, &pl);
+        }
+        return rc;
     }
     const int oV = gespmm::outer_vec_width(N);
     bool outer = p->reordered && p->d_orecs && p->norec > 0 && oV > 0 && variant_v4 && !lds_rows &&
@@ -1163,7 +1194,7 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     }
     if (!val) {
         p->valued = false;
-        if (p->stg.ev) return (int)gespmm::device_staging_set_values(p->stg.ev, nullptr, p->nnz, st);  // the stream carries 1.0f
+        if (p->stg.ev) return (int)gespmm::device_staging_set_values(p->stg, nullptr, p->d_rowptr, p->M, p->nnz, st);  // the stream carries 1.0f
         return 0;
     }
     if (!p->d_val) {
@@ -1175,7 +1206,7 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
                        p->d_src_begin, val, p->d_val, (int)p->M, (int)p->nnz);
     if (p->stg.ev) {
-        const hipError_t es = gespmm::device_staging_set_values(p->stg.ev, p->d_val, p->nnz, st);
+        const hipError_t es = gespmm::device_staging_set_values(p->stg, p->d_val, p->d_rowptr, p->M, p->nnz, st);
         if (es != hipSuccess) return (int)es;
     }
     if (p->d_orecs && p->norec > 0) {
@@ -1224,8 +1255,8 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         if (outer) snprintf(kern, sizeof kern, "kernel=task-outer V=%d records=%d nnz_per_distinct_row=%.2f", oV, p->norec, p->orec_dup);
         else if (lds) snprintf(kern, sizeof kern, "kernel=lds-rows V=4 W=%d records=%d nnz_per_distinct_row=%.2f", W, p->nrec, p->rec_dup);
         else if (p->stg.ev && !outer && !lds && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
-            snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f tables=%.4fs (max / other widths: %s)",
-                     p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->staging_seconds, what);
+            snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
+                     p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "

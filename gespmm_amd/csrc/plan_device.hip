@@ -1636,9 +1636,103 @@ __global__ void k_stage_values(const float* __restrict__ val_p, int64_t nnz, int
 
 }  // namespace
 
+namespace {
+
+__global__ void k_split_degrees(const int32_t* __restrict__ rowptr_p, int64_t M, int limit, int32_t* __restrict__ deg_s,
+                                int32_t* __restrict__ is_long) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    int d = 0, l = 0;
+    if (i < M) {
+        d = rowptr_p[i + 1] - rowptr_p[i];
+        if (d > limit) {
+            d = 0;
+            l = 1;
+        }
+    }
+    deg_s[i] = d;
+    is_long[i] = l;
+}
+
+__device__ __forceinline__ int row_of_entry(const int32_t* __restrict__ rowptr, int M, int q) {
+    int lo = 0, hi = M;  // rowptr[lo] <= q < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= q) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_split_compact(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ rowptr_s,
+                                const int32_t* __restrict__ colind_p, const float* __restrict__ val_p, int M, int64_t nnz_s,
+                                int32_t* __restrict__ colind_s, float* __restrict__ val_s) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz_s) return;
+    const int r = row_of_entry(rowptr_s, M, (int)q);
+    const int src = rowptr_p[r] + ((int)q - rowptr_s[r]);
+    colind_s[q] = colind_p[src];
+    if (val_s) val_s[q] = val_p[src];
+}
+
+__global__ void k_split_ltasks(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ is_long,
+                               const int32_t* __restrict__ lpos, int64_t M, int32_t* __restrict__ ltasks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M || !is_long[i]) return;
+    reinterpret_cast<int4*>(ltasks)[lpos[i]] = make_int4((int)i, 1, rowptr_p[i], rowptr_p[i + 1]);
+}
+
+__global__ void k_stage_values_split(const float* __restrict__ val_p, const int32_t* __restrict__ rowptr_p,
+                                     const int32_t* __restrict__ rowptr_s, int M, int64_t nnz_s, int32_t* __restrict__ ev) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz_s) return;
+    int bits = 0x3f800000;
+    if (val_p) {
+        const int r = row_of_entry(rowptr_s, M, (int)q);
+        bits = __float_as_int(val_p[rowptr_p[r] + ((int)q - rowptr_s[r])]);
+    }
+    ev[2 * q + 1] = bits;
+}
+
+}  // namespace
+
+hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
+                                  int limit, StagingTables* t, int32_t** colind_s, float** val_s, hipStream_t st) {
+    *colind_s = nullptr;
+    *val_s = nullptr;
+    if (M <= 0 || nnz <= 0) return hipErrorInvalidValue;
+    Scratch sc(st);
+    GESPMM_TRY(sc.init(0, 0, 16 * (size_t)(M + 1) + (4 << 20)));
+    sc.use(Scratch::kTemp);
+    int32_t *deg_s = nullptr, *is_long = nullptr, *lpos = nullptr;
+    GESPMM_TRY(sc.get(&deg_s, M + 1));
+    GESPMM_TRY(sc.get(&is_long, M + 1));
+    GESPMM_TRY(sc.get(&lpos, M + 1));
+    GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t->rowptr_s), (size_t)(M + 1) * 4));
+    hipLaunchKernelGGL(k_split_degrees, dim3(grid_for(M + 1)), dim3(256), 0, st, rowptr_p, M, limit, deg_s, is_long);
+    GESPMM_TRY(exclusive_scan<int32_t>(sc, deg_s, t->rowptr_s, M + 1, st));
+    GESPMM_TRY(exclusive_scan<int32_t>(sc, is_long, lpos, M + 1, st));
+    int32_t tot[2] = {0, 0};
+    GESPMM_TRY(hipMemcpyAsync(&tot[0], t->rowptr_s + M, 4, hipMemcpyDeviceToHost, st));
+    GESPMM_TRY(hipMemcpyAsync(&tot[1], lpos + M, 4, hipMemcpyDeviceToHost, st));
+    GESPMM_TRY(hipStreamSynchronize(st));
+    t->nnz_s = tot[0];
+    t->nlong = tot[1];
+    GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t->ltasks), (size_t)(t->nlong > 0 ? t->nlong : 1) * 16));
+    GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(colind_s), (size_t)(t->nnz_s > 0 ? t->nnz_s : 1) * 4));
+    if (val_p) GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(val_s), (size_t)(t->nnz_s > 0 ? t->nnz_s : 1) * 4));
+    if (t->nnz_s > 0)
+        hipLaunchKernelGGL(k_split_compact, dim3(grid_for(t->nnz_s)), dim3(256), 0, st, rowptr_p, (const int32_t*)t->rowptr_s,
+                           colind_p, val_p, (int)M, t->nnz_s, *colind_s, *val_s);
+    hipLaunchKernelGGL(k_split_ltasks, dim3(grid_for(M)), dim3(256), 0, st, rowptr_p, (const int32_t*)is_long,
+                       (const int32_t*)lpos, M, t->ltasks);
+    GESPMM_TRY(hipGetLastError());
+    return hipStreamSynchronize(st);  // the scratch goes out of scope
+}
+
 void free_staging(StagingTables* t) {
     if (!t) return;
-    void* ptrs[] = {t->ev, t->hot_cols, t->nhot, t->tasks};
+    void* ptrs[] = {t->ev, t->hot_cols, t->nhot, t->tasks, t->rowptr_s, t->ltasks};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     *t = StagingTables();
@@ -1646,7 +1740,8 @@ void free_staging(StagingTables* t) {
 
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
                                 const float* val_p, const int32_t* perm, int R, int H, StagingTables* out, hipStream_t st) {
-    *out = StagingTables();
+    // (rowptr_p / colind_p / val_p / nnz describe what the staged kernel walks: the clustered matrix, or its copy without hub rows —
+    // `out` then already carries rowptr_s / ltasks / nlong / nnz_s from device_split_long_rows, which stay)
     if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0) return hipErrorInvalidValue;
     const int64_t nblk = (M + R - 1) / R;
     // "far" columns (square matrices only): more than this many blocks away in the clustered order. 0 = off.
@@ -1674,7 +1769,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     GESPMM_TRY(sc.get(&staged, 1));
     GESPMM_TRY(sc.get(&tmp, (int64_t)(sort_bytes ? sort_bytes : 256)));
     if (mark_far) GESPMM_TRY(sc.get(&pos, M));
-    StagingTables t;
+    StagingTables t;  // the four tables built here; merged into *out on success
     auto body = [&]() -> hipError_t {
         GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
         if (mark_far) hipLaunchKernelGGL(k_stage_positions, dim3(grid_for(M)), dim3(256), 0, st, perm, M, pos);
@@ -1707,13 +1802,26 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         free_staging(&t);
         return e;
     }
-    *out = t;
+    out->ev = t.ev;
+    out->hot_cols = t.hot_cols;
+    out->nhot = t.nhot;
+    out->tasks = t.tasks;
+    out->nblocks = t.nblocks;
+    out->staged_fraction = t.staged_fraction;
+    if (!out->rowptr_s) out->nnz_s = nnz;
     return hipSuccess;
 }
 
-hipError_t device_staging_set_values(int32_t* ev, const float* val_p, int64_t nnz, hipStream_t st) {
-    if (nnz <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_stage_values, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, nnz, ev);
+hipError_t device_staging_set_values(const StagingTables& t, const float* val_p, const int32_t* rowptr_p, int64_t M, int64_t nnz,
+                                     hipStream_t st) {
+    if (!t.ev) return hipSuccess;
+    if (t.rowptr_s) {
+        if (t.nnz_s > 0)
+            hipLaunchKernelGGL(k_stage_values_split, dim3(grid_for(t.nnz_s)), dim3(256), 0, st, val_p, rowptr_p,
+                               (const int32_t*)t.rowptr_s, (int)M, t.nnz_s, t.ev);
+    } else if (nnz > 0) {
+        hipLaunchKernelGGL(k_stage_values, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, nnz, t.ev);
+    }
     return hipGetLastError();
 }
 

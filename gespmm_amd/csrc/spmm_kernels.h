@@ -175,6 +175,7 @@ constexpr int kStagedFarUnitRows = 128;  // GESPMM_STAGED_FAR_BLOCKS counts dist
 constexpr int kStagedWaves = 16;
 constexpr int kStagedLdsBytes = 64 * 1024;
 constexpr int kStagedPad = 64;
+constexpr int kStagedMaxRow = 2048;  // longer rows are walked by the streaming kernel's long-row pass, not by one wavefront
 struct StagedArgs {
     const int32_t* rowptr;    // clustered matrix
     const int32_t* ev;        // 2 * (nnz + kStagedPad) words

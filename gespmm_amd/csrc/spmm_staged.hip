@@ -24,7 +24,8 @@
 // Every output element is still ONE fp32 chain over the row's entries in CSR order with one fused multiply-add per entry
 // (spmm_test.cu:182-203 semantics; unweighted matrices carry 1.0f: fma(1, b, acc) == acc + b exactly), so the bits are those
 // of every other variant. Sum reducer, N = 128 or 256, K * N * 4 < 4 GB (32-bit offsets); everything else stays on the
-// streaming kernels.
+// streaming kernels. Rows of more than kStagedMaxRow entries never reach this kernel: the plan empties them in the row pointers it
+// passes here and runs them through the streaming kernel's long-row pass afterwards (plan.cpp: plan_run).
 //
 // The gathers are inline assembly: written as C++ the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read (it
 // cannot see that the two paths never write the same register in the same pass) and one memory access is in flight at a time.

@@ -292,7 +292,7 @@ typedef struct gespmm_plan_options {
 #define GESPMM_PLAN_KERNEL_OUTER 4      /* task-outer kernel: each distinct B row of a task loaded once into registers and applied
                                           to every row of the task that uses it (N >= 64, no long-row pass) */
 #define GESPMM_PLAN_KERNEL_STAGED 5     /* scalar-stream walk + the most used B rows of every block of 96 / 64 clustered rows staged in LDS
-                                          (N = 128 / 256, sum reducer, device analysis, longest row <= 2048); AUTO takes it for clustered
+                                          (N = 128 / 256, sum reducer, device analysis; rows beyond 2048 entries go to the long-row pass); AUTO takes it for clustered
                                           matrices with mean degree >= 12 (N = 128) / >= 5 (N = 256) when >= 40 % of the entries find their
                                           B row staged */
 #define GESPMM_PLAN_KERNEL_LDS_ROWS 2  /* distinct B rows of a task fetched once into LDS (N % 4 == 0, no long-row pass) */

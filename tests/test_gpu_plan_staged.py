@@ -110,24 +110,47 @@ def test_auto_rule_and_full_width_bits_on_a_community_graph(pkg, oracle):
     assert plan.clustered and "kernel=staged-rows" not in plan.describe(), plan.describe()
 
 
-def test_hub_rows_keep_the_streaming_kernels(pkg, oracle):
-    """A row beyond 2048 entries would be one wavefront's serial walk: such matrices are not staged, even on request."""
+def test_hub_rows_are_handed_to_the_long_row_pass(pkg, oracle):
+    """Rows beyond 2048 entries would be one wavefront's serial walk: the staged kernel sees them EMPTY and the streaming kernel
+    gets them as one-row tasks. With GESPMM_FLAG_STRICT_ORDER every row is still one strict chain (bit-exact); without it the hubs
+    take the long-row pass — a re-association held to 1e-4 * sum|a.b| — and every other row keeps its bits."""
     from gespmm_amd import spmm
 
     rng = np.random.RandomState(3)
     M = K = 4000
     degs = rng.randint(1, 30, size=M)
-    degs[17] = 3000
+    hubs = {17: 3000, 128: 2049, 2500: 9000, M - 1: 2600}
+    for r, d in hubs.items():
+        degs[r] = d
+    degs[300] = 2048  # at the limit: stays with the staged kernel
     rowptr = np.zeros(M + 1, dtype=np.int32)
     rowptr[1:] = np.cumsum(degs)
     colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)
     val_h = oracle.hash_val(colind.size, seed=2)
-    B_h = oracle.hash_B(K, 128, seed=3)
-    rp, ci = _dev(rowptr), _dev(colind)
-    plan = spmm.SpmmPlan(rp, ci, K, 128, values=_dev(val_h), reorder=True, kernel="staged", flags=0x100)
-    assert "kernel=staged-rows" not in plan.describe(), plan.describe()
-    got = spmm.csr_spmm(rp, ci, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
-    assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
+    rp, ci, val = _dev(rowptr), _dev(colind), _dev(val_h)
+    for N in (128, 256):
+        B_h = oracle.hash_B(K, N, seed=3 + N)
+        B = _dev(B_h)
+        ref = oracle.spmm(rowptr, colind, val_h, B_h, "fma")
+        plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x100)  # STRICT_ORDER
+        assert "kernel=staged-rows" in plan.describe() and "hub_rows=4" in plan.describe(), plan.describe()
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()
+        assert np.array_equal(bits(got), bits(ref)), N
+        got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan).cpu().numpy()
+        assert np.array_equal(bits(got_u), bits(oracle.spmm(rowptr, colind, None, B_h, "golden"))), N
+        got2 = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()  # values back in (interleaved again through the split map)
+        assert np.array_equal(bits(got2), bits(ref)), N
+        # without the flag: hubs through the long-row pass
+        plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x200)  # SPLIT_LONG_ROWS (small matrix)
+        assert "hub_rows=4" in plan.describe(), plan.describe()
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()
+        others = np.ones(M, dtype=bool)
+        others[list(hubs)] = False
+        assert np.array_equal(bits(got[others]), bits(ref[others])), N
+        for r in hubs:
+            lo, hi = rowptr[r], rowptr[r + 1]
+            bound = 1e-4 * (np.abs(val_h[lo:hi, None].astype(np.float64) * B_h[colind[lo:hi]].astype(np.float64))).sum(0)
+            assert np.all(np.abs(got[r].astype(np.float64) - ref[r].astype(np.float64)) <= bound + 1e-30), (N, r)
 
 
 def _random_local_csr(rng, M, K, max_deg, local, p_empty):
