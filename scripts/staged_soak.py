@@ -21,7 +21,7 @@ for seed in range(first, first + count):
     max_deg = int(rng.choice([1, 3, 17, 40, 120, 300]))
     rowptr, colind = _random_local_csr(rng, M, K, max_deg, local=int(rng.choice([1, 8, 60, 400])), p_empty=float(rng.choice([0.0, 0.1, 0.5])))
     if rng.rand() < 0.2 and M >= 64:
-        r = int(rng.randint(0, M)); n_big = int(rng.choice([1000, 2047, 2048]))
+        r = int(rng.randint(0, M)); n_big = int(rng.choice([1000, 2047, 2048, 2049, 3000, 7000]))
         extra = rng.randint(0, K, size=n_big).astype(np.int32)
         d = n_big - (rowptr[r + 1] - rowptr[r])
         colind = np.concatenate([colind[:rowptr[r]], extra, colind[rowptr[r + 1]:]])
