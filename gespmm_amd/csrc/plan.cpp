@@ -731,6 +731,18 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             // B beyond the L2s (below that every order hits), enough rows to cluster
             reorder = stream_family && M >= (1 << 14) && nnz >= M && b_bytes > (8ll << 20) && mean <= 96 &&
                       nnz <= (1ll << 28);
+        // Dense graphs (the plain call's cache-blocked path): worth clustering only when they have STRONG community structure — a
+        // reddit-sized graph with planted communities modelled at 0.71-0.77 hits runs 3.0 vs 4.0 ms at N = 128 (1.6 vs 2.2 at 64,
+        // 6.5 vs 8.3 at 256) through a clustered plan; modelled at 0.37-0.50 the cache-blocked path wins (4.1 vs 4.9 ms), and on the
+        // structureless stand-in by 2x (profiles/r03/dense_community_audit.log). AUTO runs the analysis and keeps the clustered order
+        // only from 0.65 on; otherwise the tables are dropped and the cache-blocked path stays.
+        bool dense_try = false;
+        if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && !reorder && !on_host && (sel.geo.slab_blocked || mean > 96) &&
+            sel.variant >= GESPMM_VARIANT_CRC && sel.variant <= GESPMM_VARIANT_CRC_CWM8 && M >= (1 << 14) && nnz >= M &&
+            nnz <= (1ll << 28) && b_bytes > (8ll << 20)) {
+            reorder = true;
+            dense_try = true;
+        }
         // the model of the XCD L2s: window = B rows that 3 MiB hold; matrices beyond 2^25 non-zeros: the first 2^22
         // non-zeros of each of the 8 slices are the sample
         const int64_t model_sample = nnz <= (1ll << 25) ? 0 : (1ll << 22);
@@ -774,8 +786,8 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
                 delete p;
                 return (int)e;
             }
-            if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && p->hits_after < p->hits_before + 0.05) {
-                reorder = false;  // the storage order is as good: keep it and pay nothing per launch
+            if (reorder_mode == GESPMM_PLAN_REORDER_AUTO && (p->hits_after < p->hits_before + 0.05 || (dense_try && p->hits_after < 0.65))) {
+                reorder = false;  // the storage order (or the cache-blocked path) is as good: keep it and pay nothing per launch
                 (void)hipFree(p->d_perm);
                 (void)hipFree(p->d_rowptr);
                 (void)hipFree(p->d_colind);
@@ -784,6 +796,7 @@ int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* 
             }
         }
         if (reorder && !on_host) {
+            if (dense_try) p->launch_flags |= GESPMM_FLAG_NO_SLAB_BLOCKED;  // a clustered dense graph runs the streaming kernels
             // ---- task tables (same greedy cut as the host path), values, optional records
             int budget = (opt && opt->task_entries > 0) ? opt->task_entries : default_task_entries(N);
             if (!(opt && opt->task_entries > 0) && budget < 5 * mean) budget = (int)(5 * mean < 512 ? 5 * mean : 512);
@@ -1018,7 +1031,9 @@ static bool plan_prefers_segmented(const gespmm_plan* p, int64_t N) {
     if (p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM) return true;
     if (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return false;
     const int64_t mean_deg = p->M > 0 ? p->nnz / p->M : 0;
-    return p->nnz >= (1 << 20) && N % 4 == 0 && mean_deg >= 16 && p->hits_after >= 0.40 && (N <= 32 || (N > 64 && N <= 128));
+    // (dense clustered graphs, mean degree in the hundreds: segmented also at N = 256 — 6.45 vs 7.18 ms on the reddit-sized community graph)
+    return p->nnz >= (1 << 20) && N % 4 == 0 && mean_deg >= 16 && p->hits_after >= 0.40 &&
+           (N <= 32 || (N > 64 && N <= 128) || (mean_deg >= 128 && N > 64 && N <= 256));
 }
 
 static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream) {

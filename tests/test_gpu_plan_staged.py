@@ -203,3 +203,33 @@ def test_random_matrices_equal_the_plain_call(pkg, oracle, seed):
         want_u = spmm.csr_spmm_no_edge_value(rp, ci, B, cfg={"flags": 0x100})
         got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan)
         assert torch.equal(got_u.view(torch.int32), want_u.view(torch.int32)), (seed, M, K, N, "unweighted")
+
+
+def test_dense_graphs_are_clustered_only_with_strong_communities(pkg, oracle):
+    """Dense graphs take the cache-blocked path; AUTO plans now run the analysis on them too and keep the clustered order only when
+    the L2 model promises >= 65 % hits (a reddit-shaped graph WITH planted communities: 3.0 vs 4.0 ms at full size); the structureless
+    stand-in keeps the cache-blocked path. Same bits either way."""
+    from gespmm_amd import graphs, spmm
+
+    M, nnz = 58240, 28_653_972
+    rp, ci, _ = graphs.community_csr(M, nnz, 72, 8, 330.0, 0.6, 1.5, 1.55, 42, "cuda")
+    val = torch.from_numpy(oracle.hash_val(int(ci.numel()), seed=21)).cuda()
+    for N in (64, 128, 256):
+        B = torch.from_numpy(oracle.hash_B(M, N, seed=N)).cuda()
+        plan = spmm.SpmmPlan(rp, ci, M, N, values=val)
+        d = plan.describe()
+        assert d.startswith("order=clustered") and "slab-blocked" not in d, d
+        after = float(d.split("l2_model=")[1].split()[0].split("->")[1])
+        assert after >= 0.65, d
+        got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+        plain = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x100})
+        assert torch.equal(got.view(torch.int32), plain.view(torch.int32)), N
+        del plan
+    g = graphs.synthetic_graph("reddit-like", seed=42, device="cuda", scale=0.25)
+    plan = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 128)
+    d = plan.describe()
+    assert d.startswith("order=storage") and "kernel=slab-blocked" in d, d
+    B = torch.from_numpy(oracle.hash_B(g["K"], 128, seed=9)).cuda()
+    got = spmm.csr_spmm_no_edge_value(g["rowptr"], g["colind"], B, plan=plan)
+    plain = spmm.csr_spmm_no_edge_value(g["rowptr"], g["colind"], B, cfg={"flags": 0x100})
+    assert torch.equal(got.view(torch.int32), plain.view(torch.int32))
