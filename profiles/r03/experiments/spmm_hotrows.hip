@@ -786,3 +786,140 @@ extern "C" int hotrows_spmm(int H, int waves, int mode, const int32_t* rowptr, c
 #undef CASE
     return -1;
 }
+
+// ----------------------------------------------------------------------------- MODE 30: cluster-blocked LDS walk (dense clustered graphs)
+// A block of R clustered rows uses few distinct B rows when the graph is dense AND clustered (reddit-sized graph with 290 planted communities: 96 rows x
+// 492 entries touch ~1500 distinct columns). The block's distinct columns, ascending, are cut into SLABS of H = 128 rows; the workgroup stages slab after
+// slab in LDS and every wavefront adds, for each of its RPW rows, the row's entries that fall into the staged slab — ascending column order is CSR order
+// for sorted rows, so each output element is still one chain in CSR order. Every gather is an LDS read; accumulators of the RPW rows stay in registers
+// across the slabs.
+struct SlabArgs {
+    const int32_t* split;     // M x (NS + 1): CSR position where row r enters slab s
+    const int32_t* ev;        // {slot, value} per entry
+    const int32_t* perm;
+    const int32_t* ucols;     // distinct columns of every block, ascending
+    const int32_t* uoff;      // nblocks + 1
+    const float* B;
+    float* C;
+    int nblocks, R, NS, M;
+};
+
+template <int H, int WAVES, int RPW, int U, bool MIXED>
+__global__ __launch_bounds__(WAVES * 64) void slab_walk_kernel(SlabArgs a) {
+    __shared__ f2 s_hot[H * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = xcd_contiguous(blockIdx.x, a.nblocks);
+    cint_ptr uoff = (cint_ptr)(uintptr_t)a.uoff;
+    const int u0 = uoff[blk], u1 = uoff[blk + 1];
+    const int nslab = (u1 - u0 + H - 1) / H;
+    const int row0 = blk * a.R + wave * RPW;
+    cint_ptr split = (cint_ptr)(uintptr_t)a.split;
+    cint_ptr ev = (cint_ptr)(uintptr_t)a.ev;
+    const uint32_t loff = (uint32_t)lane * 8u;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f2*)s_hot + loff;
+    float acc[RPW][2];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) acc[j][0] = acc[j][1] = 0.0f;
+    const f4* B4 = reinterpret_cast<const f4*>(a.B);
+    f4* s_hot4 = reinterpret_cast<f4*>(s_hot);
+    for (int s = 0; s < nslab; ++s) {
+        __syncthreads();
+        {
+            const int c0 = u0 + s * H;
+            const int total = ((u1 - c0 < H) ? (u1 - c0) : H) * 32;
+            const int32_t* hc = a.ucols + c0;
+            for (int i0 = 0; i0 < total; i0 += WAVES * 64 * 4) {
+                f4 r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * WAVES * 64 + tid;
+                    const int ic = i < total ? i : total - 1;
+                    r[u] = B4[(size_t)hc[ic >> 5] * 32 + (ic & 31)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * WAVES * 64 + tid;
+                    if (i < total) s_hot4[i] = r[u];
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int r = row0 + j;
+            if (r >= a.M) break;
+            const size_t sp = (size_t)r * (size_t)(a.NS + 1) + (size_t)s;
+            const int kb = split[sp], ke = split[sp + 1];
+            for (int k = kb; k < ke; k += U) {
+                int e[2 * U];
+                f2 bv[U];
+#pragma unroll
+                for (int i = 0; i < 2 * U; ++i) e[i] = ev[(size_t)k * 2 + i];
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const uint32_t la = ((uint32_t)e[2 * i] << 9) + lds0;
+                    if constexpr (MIXED) {  // code < 0: slot of the staged row; else column (gathered from memory)
+                        asm volatile(
+                            "s_cmp_lt_i32 %2, 0\n\t"
+                            "s_cbranch_scc1 1f\n\t"
+                            "global_load_dwordx2 %0, %1, %3\n\t"
+                            "s_branch 2f\n"
+                            "1:\n\t"
+                            "ds_read_b64 %0, %1\n"
+                            "2:"
+                            : "=&v"(bv[i])
+                            : "v"(la), "s"(e[2 * i]), "s"(a.B)
+                            : "memory", "scc");
+                    } else {
+                        asm volatile("ds_read_b64 %0, %1" : "=&v"(bv[i]) : "v"(la) : "memory");
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                             : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7])::"memory");
+                if (k + U <= ke) {
+#pragma unroll
+                    for (int i = 0; i < U; ++i) {
+                        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[j][0]) : "s"(e[2 * i + 1]), "v"(bv[i][0]));
+                        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[j][1]) : "s"(e[2 * i + 1]), "v"(bv[i][1]));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < U; ++i) {
+                        if (k + i < ke) {
+                            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[j][0]) : "s"(e[2 * i + 1]), "v"(bv[i][0]));
+                            asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[j][1]) : "s"(e[2 * i + 1]), "v"(bv[i][1]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    cint_ptr perm = (cint_ptr)(uintptr_t)a.perm;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = row0 + j;
+        if (r < a.M && r < (blk + 1) * a.R) {
+            float* Crow = a.C + (size_t)perm[r] * 128u;
+            f2 out = {acc[j][0], acc[j][1]};
+            asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(loff), "v"(out), "s"(Crow) : "memory");
+        }
+    }
+}
+
+extern "C" int slabwalk_spmm(int R, const int32_t* split, const int32_t* ev, const int32_t* perm, const int32_t* ucols,
+                             const int32_t* uoff, const float* B, float* C, int nblocks, int NS, int M, int mixed, void* stream) {
+    SlabArgs a = {split, ev, perm, ucols, uoff, B, C, nblocks, R, NS, M};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define SW(r, rpw)                                                                                                            \
+    if (R == r) {                                                                                                             \
+        if (mixed) hipLaunchKernelGGL((slab_walk_kernel<128, 16, rpw, 8, true>), dim3((unsigned)nblocks), dim3(16 * 64), 0, st, a);  \
+        else hipLaunchKernelGGL((slab_walk_kernel<128, 16, rpw, 8, false>), dim3((unsigned)nblocks), dim3(16 * 64), 0, st, a);       \
+        return (int)hipGetLastError();                                                                                        \
+    }
+    SW(96, 6) SW(128, 8) SW(64, 4) SW(32, 2) SW(160, 10) SW(192, 12) SW(256, 16)
+#undef SW
+    return -1;
+}
