@@ -1031,9 +1031,10 @@ static bool plan_prefers_segmented(const gespmm_plan* p, int64_t N) {
     if (p->kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM) return true;
     if (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return false;
     const int64_t mean_deg = p->M > 0 ? p->nnz / p->M : 0;
-    // (dense clustered graphs, mean degree in the hundreds: segmented also at N = 256 — 6.45 vs 7.18 ms on the reddit-sized community graph)
+    // (dense clustered graphs, mean degree in the hundreds: segmented also at N = 256 and 512 — 6.36 vs 7.03 ms and 15.5 vs 16.8 ms on the
+    // reddit-sized community graph, profiles/r03/dense_community_audit.log)
     return p->nnz >= (1 << 20) && N % 4 == 0 && mean_deg >= 16 && p->hits_after >= 0.40 &&
-           (N <= 32 || (N > 64 && N <= 128) || (mean_deg >= 128 && N > 64 && N <= 256));
+           (N <= 32 || (N > 64 && N <= 128) || (mean_deg >= 128 && N > 64 && N <= 512));
 }
 
 static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream) {
