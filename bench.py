@@ -324,15 +324,14 @@ def main():
             # ---- the same shape WITH planted communities (the real reddit graph is made of subreddits; the stand-in above has no
             #      structure): AUTO plans analyse dense graphs too and keep the clustered order from 0.65 modelled L2 hits on
             torch.cuda.empty_cache()
-            Mr, nnzr = graphs.SPECS["reddit-like"][:2]
-            rpr, cir, _ = graphs.community_csr(Mr, nnzr, 290, 16, 330.0, 0.6, 1.5, 1.55, 42, dev)
-            g2s = {"M": Mr, "K": Mr, "nnz": int(cir.numel()), "rowptr": rpr, "colind": cir}
+            g2s = graphs.synthetic_graph("reddit-sbm", seed=42, device=dev)
+            rpr, cir = g2s["rowptr"], g2s["colind"]
             val2s = torch.rand(g2s["nnz"], device=dev) - 0.5
             r2s, step2s, B2s, C2s, plan2s = measure_graph(g2s, val2s, N, True, samples=10, keep=True)
             r2s["verified_vs_oracle"] = verify(rpr, cir, val2s, B2s, C2s, nrows=128)
             r2s["plain_call_kernel_us"] = measure_graph(g2s, val2s, N, True, use_plan=False, samples=10)["kernel_us"]
             r2s["note"] = ("232 965 rows, 114.6 M entries, 290 planted communities (~800 rows, ~330 of a row's 492 entries inside), ids "
-                          "shuffled: graphs.community_csr(M, nnz, 290, 16, 330.0)")
+                          "shuffled: graphs.synthetic_graph('reddit-sbm')")
             extra["reddit-sbm_N%d_valued" % N] = r2s
             del g2s, val2s, B2s, C2s, plan2s, step2s, rpr, cir
 

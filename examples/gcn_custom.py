@@ -44,13 +44,13 @@ def load_edges(dataset, device):
     if dataset in ("cora", "citeseer"):
         coo = graphs.read_mtx(os.path.join(ROOT, "tests", "golden", dataset + ".mtx"))
         return np.stack([coo["row"], coo["col"]]).astype(np.int32), coo["nrows"], 500, 7
-    if dataset in ("reddit-like", "com-amazon-sbm", "com-amazon-like", "products-sbm"):
+    if dataset in ("reddit-like", "reddit-sbm", "com-amazon-sbm", "com-amazon-like", "products-sbm"):
         # DGL reddit shape: 602 input features, 41 classes; the co-purchase stand-ins: 100 features, 47 classes (ogbn-products)
         g = graphs.synthetic_graph(dataset, seed=42, device=device)
         rp = g["rowptr"].long()
         rows = torch.repeat_interleave(torch.arange(g["M"], device=device), rp[1:] - rp[:-1])
         ei = torch.stack([rows, g["colind"].long()]).cpu().numpy().astype(np.int32)
-        return (ei, g["M"], 602, 41) if dataset == "reddit-like" else (ei, g["M"], 100, 47)
+        return (ei, g["M"], 602, 41) if dataset.startswith("reddit") else (ei, g["M"], 100, 47)
     raise SystemExit("unknown dataset " + dataset)
 
 

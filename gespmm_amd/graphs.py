@@ -294,6 +294,9 @@ def community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share=0.6, size_ske
 COMMUNITY_SPECS = {
     "com-amazon-sbm": ("com-amazon-like", 75149, 1024, 5.0, 0.6),
     "products-sbm": ("products-like", 51000, 2048, 34.0, 0.6),
+    # the real reddit graph is made of subreddits; the structureless stand-in has none: 290 communities of ~800 rows, ~330 of a row's
+    # 492 entries inside (profiles/r03/dense_community_audit.log)
+    "reddit-sbm": ("reddit-like", 290, 16, 330.0, 0.6),
 }
 
 def synthetic_graph(name, seed=42, device="cpu", locality=0.0, band=2000, scale=1.0):
