@@ -46,6 +46,85 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3
 MIN_KERNEL_SAMPLES = 200  # the reference times 200 launches (ITER, spmm_test.cu:714)
 
+COPY_RATE_GBS = 5600.0  # read + write copy on this chip: profiles/r02/write_bandwidth.log (fill 6.7, read 5.1-6.6, copy 5.6 TB/s)
+LINE_LIMIT = 4096  # the final stdout line stays below this; everything else goes to EXTRA_FILE (and to stderr)
+EXTRA_FILE = os.path.join("profiles", "bench_extra_last.json")
+
+
+def self_launch_argv(n, argv):
+    """argv of `python -m torch.distributed.run` for n local ranks running this file with the same flags."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _r(x, nd=4):
+    """Numbers in the final line: 4 significant decimals are what the sources of these figures carry."""
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full):
+    """The ONE stdout line (< LINE_LIMIT characters): the contract's fields, `roofline` and `cpu_baseline`, and the short
+    headline-grade blocks; `extra`, long descriptions and per-width sweeps stay in the side file named by `extra_file`."""
+    out = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config", {})
+    out["config"] = {k: (v if not isinstance(v, str) else v[:200]) for k, v in cfg.items()
+                     if k in ("workload", "rows_per_gpu", "nnz_per_gpu", "ncols", "partition", "stand_in", "kernel")}
+    out["roofline"] = _pick(full.get("roofline", {}), (
+        "bound", "achieved", "peak", "unit", "frac", "traffic", "l2_hit_rate", "algorithmic_bytes_per_launch", "kernel_us",
+        "launches", "ceiling_frac", "achieved_over_ceiling", "traffic_floor", "ceiling_note", "gather_GBs"))
+    out["roofline"].setdefault("traffic", None)
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c2 = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
+        if isinstance(cb.get("all_cores"), dict):
+            c2["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        out["cpu_baseline"] = c2
+    else:
+        out["cpu_baseline"] = None
+    for k in ("verified_vs_oracle", "plan_ms", "plan_ms_first_creation", "value_incl_plan_over_200_launches", "series", "widths",
+              "reference_kernel", "exchange", "one_gpu_reference", "extra_file"):
+        if full.get(k) is not None:
+            out[k] = _r(full[k])
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("widths", "reference_kernel", "one_gpu_reference", "exchange", "series"):  # never reached by today's fields: a guard
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def emit(full):
+    """Full record -> EXTRA_FILE + stderr; compact line -> stdout (last line, the only one starting with '{')."""
+    path = os.path.join(ROOT, EXTRA_FILE)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["extra_file"] = EXTRA_FILE
+    except OSError as ex:
+        full["extra_file"] = "not written: %s" % ex
+    sys.stderr.write("bench.py full record: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    print(compact_line(full))
+    sys.stdout.flush()
+
 
 def algorithmic_bytes(M, K, N, nnz, valued=True):
     """rowptr + colind (+ val) + B read once + C written once."""
@@ -84,9 +163,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py --gpus N ...`
+        # (one process per GPU; rendezvous on 127.0.0.1, a free port) — the line the ranks print is the same either way
+        os.execv(sys.executable, self_launch_argv(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU path to measure")
     torch.cuda.set_device(local_rank)
@@ -222,6 +304,24 @@ def main():
             return out, step, B, C, plan
         return out
 
+    def ceiling_for(gx, n, frac):
+        """Where the planted structure of a stand-in caps `frac`: every B row fetched ONCE per planted group that refers to it
+        (perfect reuse inside a group, none across: the edges that leave a group go to uniformly drawn rows, and a group's rows
+        are ~170 KB of a 4 MB L2), C written once, the CSR arrays read once — moved at the rate a plain copy reaches."""
+        if "truth_group" not in gx:
+            return {}
+        Mx, nz = gx["M"], gx["nnz"]
+        rp = gx["rowptr"].long()
+        rows = torch.repeat_interleave(torch.arange(Mx, device=rp.device), rp[1:] - rp[:-1])
+        pairs = int(torch.unique(gx["truth_group"][rows] * gx["K"] + gx["colind"].long()).numel())
+        lines_per_row = (4 * n + 127) // 128
+        floor = 128 * lines_per_row * pairs + 4 * Mx * n + 4 * (Mx + 1) + 8 * nz
+        ab = algorithmic_bytes(Mx, gx["K"], n, nz, True)
+        ceil = ab / (floor / COPY_RATE_GBS) / HBM_PEAK_GBS
+        return {"traffic_floor": floor, "ceiling_frac": ceil, "achieved_over_ceiling": frac / ceil,
+                "ceiling_note": "alg bytes / (traffic_floor / %.1f TB/s copy rate) / 8 TB/s; floor = every B row once per planted "
+                                "group that refers to it (%d pairs) + C + CSR" % (COPY_RATE_GBS / 1e3, pairs)}
+
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(pmc_path):  # measured with rocprofv3 --pmc (separate passes), see profiles/README.md
@@ -247,7 +347,7 @@ def main():
         out = run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, make_B, kernel_times_us, timed_region,
                        sync_all, verify)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -272,6 +372,9 @@ def main():
     traffic, traffic_src, l2_hit = traffic_for(tkey) if (args.locality == 0.0 and world == 1) else (None, None, None)
 
     extra = {}
+    series = {}   # headline-grade blocks that stay in the stdout line: the other com-Amazon stand-in (rounds 1-2's headline)
+    widths = {}   # the metric's other widths on the headline graph
+    reference_kernel = None
     if not args.no_extra and world == 1:
         # the plain entry point on the same operands (what a caller without a plan gets; r01's headline)
         def plain():
@@ -284,11 +387,17 @@ def main():
         t2, s2, h2 = traffic_for("%s/N%d/valued/plain" % (graph, N))
         extra["plain_call_N%d_valued" % N] = {"kernel_us": med, "gflops": 2.0 * nnz * N / med / 1e3,
                                               "frac": abytes / med / 1e3 / HBM_PEAK_GBS, "traffic": t2, "l2_hit_rate": h2}
+        widths["N%d_plain_call" % N] = {"kernel_us": med, "frac": abytes / med / 1e3 / HBM_PEAK_GBS}
         del B, C, plan
         for n2 in (32, 512):
             for valued in (True, False):
                 torch.cuda.empty_cache()
-                extra["N%d_%s" % (n2, "valued" if valued else "unweighted")] = measure_graph(g, val, n2, valued, samples=50)
+                rw = measure_graph(g, val, n2, valued, samples=MIN_KERNEL_SAMPLES if valued else 50)
+                extra["N%d_%s" % (n2, "valued" if valued else "unweighted")] = rw
+                if valued:
+                    tw_, _, hw_ = traffic_for("%s/N%d/valued/plan" % (graph, n2))
+                    widths["N%d" % n2] = {"kernel_us": rw["kernel_us"], "gflops": rw["gflops"], "frac": rw["frac"], "traffic": tw_,
+                                          "l2_hit_rate": hw_}
         extra["N%d_unweighted" % N] = measure_graph(g, val, N, False, samples=50)
 
         if graph in ("com-amazon-sbm", "com-amazon-like") and args.locality == 0.0:
@@ -307,6 +416,11 @@ def main():
             r["plain_call_gflops"] = rp_["gflops"]
             r["plain_call_frac"] = rp_["frac"]
             extra["%s_N%d_valued" % (other, N)] = r
+            series[other] = {"kernel_us": r["kernel_us"], "gflops": r["gflops"], "frac": r["frac"], "traffic": r["traffic"],
+                             "l2_hit_rate": r["l2_hit_rate"], "plan_ms": r.get("plan_ms"),
+                             "plain_call_kernel_us": rp_["kernel_us"], "plain_call_frac": rp_["frac"],
+                             "gflops_incl_plan_over_200_launches": r.get("gflops_incl_plan_over_200_launches")}
+            series[other].update({k: v for k, v in ceiling_for(gs, N, r["frac"]).items() if k != "ceiling_note"})
             del gs
 
             # ---- the second graph of BASELINE configs[1]: reddit-shaped x N=128 (cache-blocked path), sampled rows verified
@@ -467,6 +581,9 @@ def main():
                 refk["what"] = ("spmm_test2<float> (CRC + CWM CF2, block (32, 8)) from /root/reference/spmm_test.cu:161-236, "
                                 "hipcc --offload-arch=gfx950 -O3, launched through the reference's spmmWrapper on the null stream")
                 extra["reference_kernels_on_this_gpu_N%d" % N] = refk
+                reference_kernel = {"what": "reference spmm_test2 (hipcc, gfx950) on the same operands",
+                                    "kernel_us": refk["valued"]["kernel_us"], "gflops": refk["valued"]["gflops"],
+                                    "product_bits_equal": refk["product_bits_equal_reference_kernel"]}
                 del Br, Cr, ones, mine
         except Exception as ex:  # noqa: BLE001 - a baseline leg must never take the bench line down
             extra["reference_kernels_on_this_gpu_N%d" % N] = {"skipped": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
@@ -499,10 +616,11 @@ def main():
                           if not args.no_plan else "gespmm_csr_spmm_f32 (no plan)",
                 "partition": "independent replicas, one graph per rank (the row-partitioned experiment is --graph rmat)"
                              if world > 1 else "single GPU",
-                "stand_in": ("com-Amazon-shaped seeded stand-ins (no network): `com-amazon-sbm` = planted communities, clustering "
-                             "coefficient 0.408 (SNAP com-Amazon: 0.397), vertex ids shuffled — the headline since round 3; "
-                             "`com-amazon-like` = structureless (clustering 4e-5), rounds 1-2's headline — measured with the same fields "
-                             "in extra['com-amazon-like_N%d_valued']" % N) if graph.startswith("com-amazon") else graph,
+                "stand_in": ("seeded stand-in for SNAP com-Amazon (no network): planted communities, clustering 0.408 (SNAP: 0.397), "
+                             "ids shuffled; the structureless one (rounds 1-2's headline) is series['com-amazon-like']"
+                             if graph == "com-amazon-sbm" else
+                             "seeded structureless stand-in for SNAP com-Amazon (clustering 4e-5); the planted-community one is "
+                             "series['com-amazon-sbm']") if graph.startswith("com-amazon") else graph,
             },
             "roofline": {
                 "bound": "hbm",
@@ -515,6 +633,7 @@ def main():
                 "l2_hit_rate": l2_hit,
                 "algorithmic_bytes_per_launch": abytes,
                 "kernel_us": head["kernel_us"],
+                "launches": head["launches"],
                 "kernel_us_stat": "median of %d launches, one HIP event pair each" % head["launches"],
                 "kernel_us_mean": head["kernel_us_mean"],
                 "kernel_us_min": head["kernel_us_min"],
@@ -531,9 +650,14 @@ def main():
             "value_incl_plan_over_200_launches": head.get("gflops_incl_plan_over_200_launches"),
             "cpu_baseline": cpu,
             "verified_vs_oracle": verified,
+            "series": {k: {kk: _r(vv) for kk, vv in v.items()} for k, v in series.items()} or None,
+            "widths": {k: {kk: _r(vv) for kk, vv in v.items()} for k, v in widths.items()} or None,
+            "reference_kernel": {kk: _r(vv) for kk, vv in reference_kernel.items()} if reference_kernel else None,
             "extra": extra,
         }
-        print(json.dumps(out))
+        out["roofline"].update(ceiling_for(g, N, head["frac"]))
+        out["config"]["kernel"] = (head.get("plan") or "").split("|")[-1].strip()[:120] if head.get("plan") else "plain call"
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -193,7 +193,7 @@ def synthetic_csr(M, nnz, symmetric=True, gamma=1.5, seed=42, device="cpu", loca
 
 
 def community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share=0.6, size_skew=1.5, gamma=1.55, seed=42,
-                  device="cpu", shuffle=True):
+                  device="cpu", shuffle=True, return_levels=False):
     """Symmetric graph with EXACTLY ``nnz`` stored entries and PLANTED two-level community structure whose
     vertex ids are then shuffled by a seeded random permutation — so any locality has to be found by the
     consumer (row clustering), it is not inherited from the generator.
@@ -209,7 +209,8 @@ def community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share=0.6, size_ske
                 as in synthetic_csr).
 
     Returns (rowptr int32[M+1], colind int32[nnz], planted int64[M]) — ``planted[v]`` orders the vertices by
-    (group, community), i.e. argsort(planted) is the order a perfect community detector would produce.
+    (group, community), i.e. argsort(planted) is the order a perfect community detector would produce. With
+    ``return_levels`` two more int64[M] follow: the community and the group of every vertex (after the shuffle).
     """
     device = torch.device(device)
     gen = torch.Generator(device=device)
@@ -272,17 +273,21 @@ def community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share=0.6, size_ske
     r = keys // M
     c = keys % M
     planted = c2 * nc1 + c1
+    comm_of, group_of = c1, c2
     if shuffle:
         P = torch.randperm(M, generator=gen, device=device)
         r, c = P[r], P[c]
         pl = torch.empty_like(planted)
         pl[P] = planted
         planted = pl
+        comm_of, group_of = planted % nc1, planted // nc1
     r, c = torch.cat([r, c]), torch.cat([c, r])
     order = torch.argsort(r * M + c)
     r, c = r[order], c[order]
     rowptr = torch.zeros(M + 1, dtype=torch.int64, device=device)
     rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=M), 0)
+    if return_levels:
+        return rowptr.to(torch.int32), c.to(torch.int32), planted, comm_of, group_of
     return rowptr.to(torch.int32), c.to(torch.int32), planted
 
 
@@ -311,10 +316,10 @@ def synthetic_graph(name, seed=42, device="cpu", locality=0.0, band=2000, scale=
             nnz -= nnz % 2
             n_comm = max(int(n_comm * scale), 4)
             n_groups = max(int(n_groups * scale), 2)
-        rowptr, colind, planted = community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share, 1.5, gamma, seed,
-                                                device)
+        rowptr, colind, planted, comm_of, group_of = community_csr(M, nnz, n_comm, n_groups, intra_deg, group_share, 1.5,
+                                                                   gamma, seed, device, return_levels=True)
         return {"name": name, "M": M, "K": M, "nnz": int(colind.numel()), "rowptr": rowptr, "colind": colind,
-                "truth": planted}
+                "truth": planted, "truth_community": comm_of, "truth_group": group_of}
     if name == "pubmed-selfloop-like":
         M, nnz, sym, gamma = SPECS["pubmed-like"]
     else:
