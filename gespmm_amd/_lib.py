@@ -68,8 +68,8 @@ EXPORTS = [
     "gespmm_plan_destroy",
     "gespmm_cluster_rows",
     "gespmm_simulate_l2_hits",
-    "gespmm_debug_build_records",
-    "gespmm_debug_build_outer_records",
+    "gespmm_plan_create_v2",
+    "gespmm_plan_policy",
     "gespmm_device_cluster_rows",
     "gespmm_device_l2_model",
     "gespmm_plan_debug_tasks",
@@ -83,9 +83,7 @@ PLAN_ANALYSIS_DEVICE = 0
 PLAN_ANALYSIS_HOST = 1
 PLAN_KERNEL_AUTO = 0
 PLAN_KERNEL_STREAM = 1
-PLAN_KERNEL_LDS_ROWS = 2
 PLAN_KERNEL_SEG_STREAM = 3
-PLAN_KERNEL_OUTER = 4
 PLAN_KERNEL_STAGED = 5
 
 
@@ -97,6 +95,19 @@ class LaunchCfg(Structure):
 class PlanOptions(Structure):
     _fields_ = [("reorder", c_int32), ("task_entries", c_int32), ("row_floor", c_int32), ("threads", c_int32),
                 ("flags", c_int32), ("kernel", c_int32), ("analysis", c_int32)]
+
+
+class PlanPolicyQuery(Structure):
+    _fields_ = [("M", c_int64), ("K", c_int64), ("nnz", c_int64), ("N", c_int64), ("N_launch", c_int64), ("variant", c_int32),
+                ("max_degree", c_int32), ("reorder", c_int32), ("kernel", c_int32), ("analysis", c_int32), ("flags", c_int32),
+                ("task_entries", c_int32), ("row_floor", c_int32), ("hits_before", ctypes.c_double),
+                ("hits_after", ctypes.c_double), ("staged_fraction", ctypes.c_double)]
+
+
+class PlanPolicyAnswer(Structure):
+    _fields_ = [(n, c_int32) for n in ("launch_flags", "analyse", "dense_try", "keep_clustered", "task_entries",
+                                       "group_task_entries", "row_floor", "build_staged", "keep_staged", "shallow_unroll",
+                                       "segmented", "sddmm_route")] + [("model_window", c_int64), ("model_sample", c_int64)]
 
 
 class Coo(Structure):
@@ -163,6 +174,11 @@ def _load():
     lib.gespmm_plan_create.restype = c_int
     lib.gespmm_plan_create.argtypes = [POINTER(c_void_p), p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
                                        POINTER(PlanOptions), p]
+    lib.gespmm_plan_create_v2.restype = c_int
+    lib.gespmm_plan_create_v2.argtypes = [POINTER(c_void_p), p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                          POINTER(PlanOptions), c_int64, p]
+    lib.gespmm_plan_policy.restype = c_int
+    lib.gespmm_plan_policy.argtypes = [POINTER(PlanPolicyQuery), POINTER(PlanPolicyAnswer)]
     lib.gespmm_plan_spmm_f32.restype = c_int
     lib.gespmm_plan_spmm_f32.argtypes = [p, p, p, c_int64, p]
     lib.gespmm_plan_spmm_max_f32.restype = c_int
@@ -201,6 +217,23 @@ class GespmmError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
         super().__init__("%s failed: %s (code %d)" % (where, lib.gespmm_error_string(code).decode(), code))
+
+
+def plan_policy(M, K, nnz, N, max_degree, hits_before=0.0, hits_after=0.0, staged_fraction=0.0, N_launch=0, variant=VARIANT_AUTO,
+                reorder=PLAN_REORDER_AUTO, kernel=PLAN_KERNEL_AUTO, analysis=PLAN_ANALYSIS_DEVICE, flags=0, task_entries=0,
+                row_floor=0):
+    """What a plan would decide for a matrix of this shape (gespmm_plan_policy: host only, no device) — a dict."""
+    q = PlanPolicyQuery(int(M), int(K), int(nnz), int(N), int(N_launch), int(variant), int(max_degree), int(reorder), int(kernel),
+                        int(analysis), int(flags), int(task_entries), int(row_floor), float(hits_before), float(hits_after),
+                        float(staged_fraction))
+    a = PlanPolicyAnswer()
+    check(lib.gespmm_plan_policy(ctypes.byref(q), ctypes.byref(a)), "gespmm_plan_policy")
+    return {n: getattr(a, n) for n, _ in PlanPolicyAnswer._fields_}
+
+
+def release_cached_memory():
+    """Give the analysis stage's cached scratch arena back to the device (gespmm_release_cached_memory)."""
+    lib.gespmm_release_cached_memory()
 
 
 def check(code, where):

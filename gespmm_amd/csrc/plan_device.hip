@@ -302,7 +302,9 @@ struct DAdj {
     const int32_t* w = nullptr;    // nullptr: all ones
 };
 
-constexpr int kDefaultClusterLevels = 3;  // == reorder.cpp (the hierarchy stops paying after three levels: cluster_knobs.log)
+constexpr int kDefaultClusterLevels = 6;  // == reorder.cpp. Levels 4-6 merge little (8872 > 6372 > 5957 > 5932 clusters on the structureless com-Amazon
+                                          // stand-in) yet its plan runs 138.6 instead of 145.1 us at N = 128 (47.4 / 50.0 at 32, 537 / 545 at 512) with them:
+                                          // profiles/r04/like_regression.log; round 3 had cut them for 2 ms of analysis time
 constexpr int kBins = 4;  // degree classes 1..8, 9..64, 65..2048, > 2048
 constexpr int kHashSlots = 4096;
 __device__ inline int bin_of(int d) { return d <= 8 ? 0 : (d <= 64 ? 1 : (d <= 2048 ? 2 : 3)); }

@@ -1,0 +1,192 @@
+// plan_policy.cpp — the rules behind gespmm_plan_create / gespmm_plan_spmm_f32 (see plan_policy.h).
+//
+// Every threshold below was measured on this chip; the log is named next to it. The hold-out audit (graphs from generators
+// this repository did not write: profiles/r04/holdout_audit.log, scripts/holdout_audit.py) is the check that they are not
+// fitted to the stand-ins of gespmm_amd/graphs.py.
+
+#include "plan_policy.h"
+
+#include "../../include/gespmm.h"
+#include "select.h"
+#include "spmm_kernels.h"
+
+namespace gespmm {
+
+// Long-row pass: the plain entry points run it on matrices of >= 2^23 non-zeros, or >= 2^20 with mean degree >= 8
+// (select.cpp: they cannot see the degrees, and the pass costs ~6.5 us when it finds nothing). A plan runs it on the SAME
+// matrices — so its result has the plain call's bits — but only when the longest row it has SEEN is beyond the threshold.
+int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags) {
+    const int64_t mean = M > 0 ? (nnz + M - 1) / M : 0;
+    int64_t threshold = 32 * mean;
+    if (threshold < kLongRowThreshold) threshold = kLongRowThreshold;
+    const bool plain_would = nnz >= kLongRowMinNnz || (nnz >= (1 << 20) && M > 0 && nnz / M >= 8);
+    if (!(user_flags & (GESPMM_FLAG_STRICT_ORDER | GESPMM_FLAG_SPLIT_LONG_ROWS)))
+        user_flags |= (plain_would && max_degree > threshold) ? GESPMM_FLAG_SPLIT_LONG_ROWS : GESPMM_FLAG_STRICT_ORDER;
+    return user_flags;
+}
+
+static bool crc_family(int v) { return v >= GESPMM_VARIANT_CRC && v <= GESPMM_VARIANT_CRC_CWM8; }
+
+AnalysisDecision decide_analysis(const PlanFacts& f) {
+    AnalysisDecision a;
+    a.launch_flags = long_row_flags(f.M, f.nnz, f.max_degree, f.user_flags);
+    const int64_t mean = f.mean_ceil();
+    const bool stream_family = crc_family(f.sel_variant) && !f.slab_blocked;
+    const bool big_enough = f.M >= (1 << 14) && f.nnz >= f.M && f.nnz <= (1ll << 28) && f.b_bytes() > (8ll << 20);
+    if (f.reorder_mode == GESPMM_PLAN_REORDER) {
+        a.analyse = stream_family && f.M > 1 && f.nnz > 0;
+    } else if (f.reorder_mode == GESPMM_PLAN_REORDER_AUTO) {
+        // B beyond the L2s (below that every order hits), enough rows to cluster
+        a.analyse = stream_family && big_enough && mean <= 96;
+        // Dense graphs (the plain call's cache-blocked path): worth clustering only when they have STRONG community
+        // structure — a reddit-sized graph with planted communities modelled at 0.71-0.77 hits runs 3.0 vs 4.0 ms at N = 128
+        // through a clustered plan; modelled at 0.37-0.50 the cache-blocked path wins (4.1 vs 4.9 ms), and on the
+        // structureless stand-in by 2x (profiles/r03/dense_community_audit.log). The analysis runs and keep_clustered_order()
+        // asks for 0.65.
+        if (!a.analyse && !f.host_analysis && (f.slab_blocked || mean > 96) && crc_family(f.sel_variant) && big_enough) {
+            a.analyse = true;
+            a.dense_try = true;
+        }
+    }
+    // the model of the XCD L2s: window = B rows that 3 MiB hold; matrices beyond 2^25 non-zeros: the first 2^22
+    // non-zeros of each of the 8 slices are the sample
+    a.model_sample = f.nnz <= (1ll << 25) ? 0 : (1ll << 22);
+    const int64_t rowb = 4 * (f.N < f.tile_cols ? f.N : f.tile_cols);
+    a.model_window = (3ll << 20) / (rowb > 0 ? rowb : 4);
+    return a;
+}
+
+bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after) {
+    if (f.reorder_mode != GESPMM_PLAN_REORDER_AUTO) return true;
+    // the storage order is as good (already local, or nothing to find): keep it and pay nothing per launch
+    if (hits_after < hits_before + 0.05) return false;
+    if (a.dense_try && hits_after < 0.65) return false;
+    return true;
+}
+
+// Non-zeros per wavefront task. Storage-order launches take ~12 KB of gathered B per task (select.cpp);
+// clustered plans take ~20 KB (40 entries at N = 128, 32 at N >= 256, 80 at N = 64: profiles/r02/plan_task_size_final.log — at
+// N = 128 anything from 40 to 80 entries runs within 1 %, and the smaller task keeps fewer rows in flight per XCD: fabric bytes
+// 1.48x algorithmic at 40 entries, 1.54x at 48, 1.62x at 56, plan_task_size_traffic.log).
+static int default_task_entries(int64_t N) {
+    const int64_t row_bytes = 4 * (N < 256 ? N : 256);
+    int64_t t = (20 << 10) / (row_bytes > 0 ? row_bytes : 4);
+    if (t < 32) t = 32;
+    if (t > 96) t = 96;  // narrow rows (N = 32: 128-byte rows) are latency-bound per row pair: the plain path's 96 entries
+    return (int)t;
+}
+
+PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
+    PlanKernelDecision d;
+    const int64_t mean = f.mean_ceil();
+    const bool te_given = f.opt_task_entries > 0;
+    int budget = te_given ? f.opt_task_entries : default_task_entries(f.N);
+    // ... never fewer than ~5 rows of mean length per task (products-shaped graphs, degree 50: 256-entry tasks at N = 32 run
+    // 1.48 ms, 96-entry tasks 2.33 ms)
+    if (!te_given && budget < 5 * mean) budget = (int)(5 * mean < 512 ? 5 * mean : 512);
+    d.task_entries = budget;
+    d.row_floor = f.opt_row_floor < 0 ? 0 : (f.opt_row_floor > 0 ? f.opt_row_floor : 8);
+    // segmented-stream kernel: a task per lane GROUP, cut by non-zeros alone, half the budget (short rows: 16 entries per lane
+    // group — profiles/r02/plan_seg_task_size.log: 139 us at 16, 146 at 24, 150 at 32 on the com-Amazon stand-in)
+    int gb = budget / 2 > 16 ? budget / 2 : 16;
+    if (te_given) gb = f.opt_task_entries / 2 > 4 ? f.opt_task_entries / 2 : 4;
+    else if (mean < 16) gb = 16;
+    d.group_task_entries = gb;
+    // Staged-rows kernel: worth its tables where a block of clustered rows uses the same B rows again and again
+    // (profiles/r03/staged_rows.log, staged_degree_sweep.log; products-shaped communities: 3.0 vs 3.9 ms at N = 128, 5.8 vs
+    // 7.8 ms at N = 256). At N = 128 a row is half of what a load instruction could carry and short rows are level at best
+    // (com-Amazon-shaped communities: 108 vs 106 us; mean degree 8: 239 vs 236 us; from 12 on: 9-15 % ahead); at N = 256 short
+    // rows win as well (com-Amazon-shaped: 196 vs 208 us; mean degree 8: 416 vs 450 us). Device analysis only.
+    const bool v4 = f.variant == GESPMM_VARIANT_AUTO || f.variant == GESPMM_VARIANT_CRC_CWM4 || f.variant == GESPMM_VARIANT_CRC_CWM8;
+    const bool fits = staged_rows_per_block_lds(f.N) > 0 && f.nnz > 0 && (uint64_t)f.K * (uint64_t)f.N * 4ull < 0xFFFF0000ull;
+    const bool want = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
+                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
+                       f.nnz >= (1 << 20) && v4);
+    d.build_staged = fits && want && !f.host_analysis;
+    // Where the clustered order is modelled to hit L2 (>= 40 % of the gathers) four B rows in flight per lane group beat eight
+    // at up to 128 columns (com-Amazon-shaped communities, N = 128: 105 vs 114 us, N = 64: 48 vs 60 us; at 256+ columns and on
+    // the structureless graph eight stay ahead) — profiles/r02/plan_unroll_geometry.log (short rows only: degree-50 rows want
+    // the depth — products-shaped communities, N = 32: 525 vs 365 us)
+    d.shallow_unroll = hits_after >= 0.40 && f.N <= 128 && mean <= 8 && f.nnz >= (1 << 20) && !(f.user_flags & 0x20000);
+    return d;
+}
+
+bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
+    // not enough reuse inside the blocks: the streaming kernels stay
+    return !(f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && staged_fraction < 0.40);
+}
+
+// Which streaming kernel a clustered plan launches (AUTO rule + the caller's choice).
+//   segmented-stream (one continuous gather stream per lane group): ahead of the batch kernel on clustered matrices with
+//     longer rows at one column tile (products-shaped communities, N = 128: 3.95 vs 4.37 ms; N = 16: 1.06 vs 1.17 ms; N = 32:
+//     1.35 vs 1.38), behind at N = 64 (2.25 vs 2.03);
+//   batch-stream otherwise — on short rows the two are within 2 % of each other at N >= 128 (com-Amazon stand-ins: 138.5 vs
+//     140.1 us at 128, 267.7 vs 261.8 at 256, 574.6 vs 570.4 at 512) and the batch kernel is far ahead below (N = 64: 61 vs 91 us)
+//     and on small graphs (pubmed N = 128: 9.6 vs 13.2 us) — and whenever long rows are split (run_spmm decides that).
+//   (profiles/r02/plan_seg_widths.log; dense clustered graphs, mean degree in the hundreds: segmented also at N = 256 and 512 —
+//   6.36 vs 7.03 ms and 15.5 vs 16.8 ms on the reddit-sized community graph, profiles/r03/dense_community_audit.log)
+bool prefer_segmented(const PlanFacts& f, double hits_after, int64_t N) {
+    if (f.kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM) return true;
+    if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return false;
+    const int64_t mean_deg = f.mean_floor();
+    return f.nnz >= (1 << 20) && N % 4 == 0 && mean_deg >= 16 && hits_after >= 0.40 &&
+           (N <= 32 || (N > 64 && N <= 128) || (mean_deg >= 128 && N > 64 && N <= 512));
+}
+
+// The clustered edge walk pays a scatter pass at the end: worth it where the order is modelled to hit L2 for >= 40 % of the
+// gathers and the rows are >= 256 bytes (com-Amazon-shaped communities, N = 128: 114 vs 151 us COO / 167 us CSR; on the
+// structureless graph or at N = 41 it is equal or slower — profiles/r02/sddmm_plan.log). Otherwise short rows take the COO
+// form on row ids expanded once (the CSR form spends a row search per wavefront: 4-18 %, profiles/r03/sddmm_audit.log) and
+// long rows the CSR call, whose row-walking / cache-blocked forms need no row ids at all.
+int sddmm_route(const PlanFacts& f, bool reordered, double hits_after, int64_t N) {
+    if (!reordered || hits_after < 0.40 || N < 64) return (f.M > 0 && f.nnz / f.M < 32) ? 1 : 0;
+    return 2;
+}
+
+}  // namespace gespmm
+
+extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a) {
+    if (!q || !a || q->M < 0 || q->K < 0 || q->nnz < 0 || q->N < 0) return GESPMM_EINVAL;
+    if (q->variant < GESPMM_VARIANT_AUTO || q->variant >= GESPMM_NUM_VARIANTS || q->reorder < 0 || q->reorder > 2) return GESPMM_EINVAL;
+    gespmm::PlanFacts f;
+    f.M = q->M;
+    f.K = q->K;
+    f.nnz = q->nnz;
+    f.N = q->N;
+    f.variant = q->variant;
+    f.max_degree = q->max_degree;
+    f.reorder_mode = q->reorder;
+    f.kernel_choice = q->kernel;
+    f.host_analysis = q->analysis == GESPMM_PLAN_ANALYSIS_HOST;
+    f.user_flags = q->flags;
+    f.opt_task_entries = q->task_entries;
+    f.opt_row_floor = q->row_floor;
+    gespmm::Selection sel;
+    int max_vec = 4;
+    while (max_vec > 1 && (q->N % max_vec) != 0) max_vec >>= 1;
+    const int lr = gespmm::long_row_flags(q->M, q->nnz, q->max_degree, q->flags);
+    if (gespmm::resolve_geometry(q->M, q->K, q->N > 0 ? q->N : 1, q->nnz, q->variant, max_vec, 0, 0, 0, 0, 0, lr, &sel) != 0)
+        return GESPMM_EINVAL;
+    f.sel_variant = sel.variant;
+    f.slab_blocked = sel.geo.slab_blocked;
+    f.tile_cols = (int64_t)sel.geo.group * sel.geo.vec * sel.geo.strips;
+    const gespmm::AnalysisDecision ad = gespmm::decide_analysis(f);
+    const bool keep = ad.analyse && gespmm::keep_clustered_order(f, ad, q->hits_before, q->hits_after);
+    const gespmm::PlanKernelDecision kd = gespmm::choose_plan_kernel(f, q->hits_after);
+    const int64_t Nl = q->N_launch > 0 ? q->N_launch : q->N;
+    a->launch_flags = ad.launch_flags;
+    a->analyse = ad.analyse;
+    a->dense_try = ad.dense_try;
+    a->keep_clustered = keep;
+    a->task_entries = kd.task_entries;
+    a->group_task_entries = kd.group_task_entries;
+    a->row_floor = (int32_t)kd.row_floor;
+    a->build_staged = keep && kd.build_staged;
+    a->keep_staged = a->build_staged && gespmm::keep_staged_tables(f, q->staged_fraction);
+    a->shallow_unroll = keep && kd.shallow_unroll;
+    a->segmented = keep && !a->keep_staged && gespmm::prefer_segmented(f, q->hits_after, Nl);
+    a->sddmm_route = gespmm::sddmm_route(f, keep, q->hits_after, Nl);
+    a->model_window = ad.model_window;
+    a->model_sample = ad.model_sample;
+    return 0;
+}

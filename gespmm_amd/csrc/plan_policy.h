@@ -1,0 +1,68 @@
+// plan_policy.h — every DECISION the plan object takes, as pure functions of numbers (no HIP calls, no device state).
+//
+// plan.cpp is the mechanism (device passes, tables, launches); this file is the policy. Each rule cites the log it was
+// measured in; tests/test_plan_policy.py pins the answers for the BASELINE shapes and the hold-out graphs
+// (profiles/r04/holdout_audit.log) through the C entry point gespmm_plan_policy().
+#pragma once
+#include <stdint.h>
+
+namespace gespmm {
+
+// What is known before / after the analysis passes.
+struct PlanFacts {
+    int64_t M = 0, K = 0, nnz = 0, N = 0;  // N: the width the plan is made for
+    int variant = -1;                      // the caller's GESPMM_VARIANT_*
+    int sel_variant = 0;                   // what a plain call resolves to (select.cpp)
+    bool slab_blocked = false;             // ... and whether it takes the cache-blocked path (dense graphs)
+    int64_t tile_cols = 0;                 // columns one workgroup tile covers (group x vec x strips)
+    int32_t max_degree = 0;                // longest row (device_validate_csr)
+    int reorder_mode = 0;                  // GESPMM_PLAN_REORDER_*
+    int kernel_choice = 0;                 // GESPMM_PLAN_KERNEL_*
+    bool host_analysis = false;            // GESPMM_PLAN_ANALYSIS_HOST
+    int user_flags = 0;                    // gespmm_plan_options.flags
+    int opt_task_entries = 0, opt_row_floor = 0;
+
+    int64_t mean_ceil() const { return M > 0 ? (nnz + M - 1) / M : 0; }
+    int64_t mean_floor() const { return M > 0 ? nnz / M : 0; }
+    int64_t b_bytes() const { return K * 4 * (N < tile_cols ? N : tile_cols); }  // B as one column tile sees it
+};
+
+// user flags + the long-row decision from the longest row (SPLIT_LONG_ROWS or STRICT_ORDER is always set on return)
+int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags);
+// mean degree from which AUTO considers the staged-rows kernel at width N
+inline int staged_min_mean_degree(int64_t N) { return N >= 256 ? 5 : 12; }
+
+// ---- before the analysis: launch flags, whether to cluster at all, how to model the L2s
+struct AnalysisDecision {
+    int launch_flags = 0;      // user flags + the long-row decision (exact: the plan has seen the longest row)
+    bool analyse = false;      // run clustering + L2 model
+    bool dense_try = false;    // a dense graph: the clustered order is kept only on strong community structure
+    int64_t model_window = 0;  // B rows one XCD's L2 is modelled to hold
+    int64_t model_sample = 0;  // entries per slice the model looks at (0 = all)
+};
+AnalysisDecision decide_analysis(const PlanFacts& f);
+
+// ---- after the model: is the clustered order worth its per-launch indirection?
+bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after);
+
+// ---- a clustered plan: task sizes, unroll depth, which tables to build
+struct PlanKernelDecision {
+    int task_entries = 0;        // non-zeros per wavefront task (batch-stream kernel)
+    int group_task_entries = 0;  // non-zeros per lane-group task (segmented-stream kernel)
+    int64_t row_floor = 0;       // a row counts as at least this many entries when tasks are cut
+    bool build_staged = false;   // build the staged-rows tables for width N
+    bool shallow_unroll = false; // 4 instead of 8 B rows in flight per lane group
+};
+PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after);
+
+// ---- the staged tables exist: does enough of the matrix find its B row staged?
+bool keep_staged_tables(const PlanFacts& f, double staged_fraction);
+
+// ---- per launch (width N_launch may differ from the plan's): segmented-stream instead of batch-stream?
+bool prefer_segmented(const PlanFacts& f, double hits_after, int64_t N_launch);
+
+// ---- SDDMM through the plan: 0 = CSR form on the caller's arrays, 1 = COO form on expanded row ids (storage order),
+//      2 = the plan's clustered edge order + scatter
+int sddmm_route(const PlanFacts& f, bool reordered, double hits_after, int64_t N_launch);
+
+}  // namespace gespmm

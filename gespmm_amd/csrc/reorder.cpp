@@ -216,7 +216,7 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
     std::vector<std::vector<int32_t>> level_labels;  // per level: row-node id of every original row AFTER contraction
 
     int64_t cap = opt.first_cap > 0 ? opt.first_cap : 256;
-    const int max_levels = opt.max_levels > 0 ? opt.max_levels : 3;  // == plan_device.hip (levels 4+ merge little and change no measured time: profiles/r03/cluster_knobs.log)
+    const int max_levels = opt.max_levels > 0 ? opt.max_levels : 6;  // == plan_device.hip kDefaultClusterLevels (profiles/r04/like_regression.log)
     const int sweeps = opt.sweeps > 0 ? opt.sweeps : 5;
 
     for (int level = 0; level < max_levels; ++level) {

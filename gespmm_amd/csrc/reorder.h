@@ -6,7 +6,7 @@ namespace gespmm {
 
 struct ClusterOptions {
     int threads = 0;       // 0: hardware concurrency (results do not depend on it)
-    int max_levels = 0;    // 0: 3
+    int max_levels = 0;    // 0: 6
     int sweeps = 0;        // 0: 5 label-propagation sweeps per level
     int64_t first_cap = 0; // 0: 256 original rows per label at level 0
     int cap_growth = 0;    // 0: x4 per level

@@ -101,72 +101,6 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void*
                                    hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
-// spmm_ldsrow.hip — the plan's kernel for clustered matrices. A task is one fixed-size RECORD of 96 words (plan.cpp):
-//   words 0-3      nrows, nent, ndist, flags (bit 0: the record's single row continues FROM the previous record,
-//                  bit 1: ... INTO the next one — the chain of records of one long row)
-//   words 4-19     C row of each of the (<= 16) rows            } one coalesced load: word 4 + lane
-//   words 20-35    the (<= 16) distinct column ids              }
-//   words 36-67    value of each of the (<= 32) entries (fp32)  }
-//   bytes 272-303  LDS slot (index into the distinct columns) of each entry   } one byte load: 272 + lane
-//   bytes 304-320  first entry of each row (nrows + 1 values)                 }
-constexpr int kRecEntries = 32;
-constexpr int kRecDistinct = 16;
-constexpr int kRecRows = 16;
-constexpr int kRecWords = 96;
-constexpr int kRecOffCrow = 4;
-constexpr int kRecOffDcol = 20;
-constexpr int kRecOffVal = 36;
-constexpr int kRecOffSlotBytes = 68 * 4;
-constexpr int kRecOffRpBytes = 76 * 4;
-static_assert(kRecOffDcol == kRecOffCrow + kRecRows && kRecOffVal == kRecOffDcol + kRecDistinct &&
-                  kRecOffVal + kRecEntries == 68 && kRecRows + kRecDistinct == 32 && kRecEntries == 32 &&
-                  kRecOffRpBytes == kRecOffSlotBytes + kRecEntries,
-              "the kernel reads a record with one word load and one byte load per lane");
-
-struct LdsRowArgs {
-    const int32_t* recs;
-    const float* B;
-    float* C;
-    int32_t nrec;
-    int32_t N;
-    int32_t ntile;  // filled in by the launcher
-    int32_t nblk;   // workgroups per XCD (and column tile)
-    float empty;
-    int32_t debug;  // experiments only (GESPMM_LDSROW_DEBUG): 1 = no row fetches, 2 = no sums, 4 = no C stores
-};
-int ldsrow_group_width(int64_t N);  // lanes per row (4..32), 0 if N is not served (N % 4 != 0)
-hipError_t launch_spmm_ldsrow(const LdsRowArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
-
-// spmm_outer.hip — task-outer kernel of clustered plans. A task is one RECORD of 136 words (plan.cpp):
-//   words 0-3      nrows (<= 8), nent (<= 64), ndist (<= 32), flags (bit 0: continues FROM the previous record, bit 1: INTO the next)
-//   words 4-11     C row of each row             } one word load: word 4 + lane, lanes 0..39
-//   words 12-43    the distinct columns, ascending (or, for a row with unsorted / repeated columns, its entries in CSR order)
-//   words 44-107   value of each entry (fp32), entries in (column, row) order
-//   bytes 432-495  row (0..7) of each entry
-//   bytes 496-528  first entry of each distinct column (ndist + 1 values)
-constexpr int kOutRows = 8;
-constexpr int kOutDistinct = 32;
-constexpr int kOutEntries = 64;
-constexpr int kOutWords = 136;
-constexpr int kOutOffCrow = 4;
-constexpr int kOutOffDcol = 12;
-constexpr int kOutOffVal = 44;
-constexpr int kOutOffRowBytes = 108 * 4;
-constexpr int kOutOffCptrBytes = 124 * 4;
-
-struct OuterArgs {
-    const int32_t* recs;
-    const float* B;
-    float* C;
-    int32_t nrec;
-    int32_t N;
-    int32_t ntile;  // filled in by the launcher
-    int32_t nblk;
-    float empty;
-};
-int outer_vec_width(int64_t N);  // floats per lane (1, 2, 4), 0 if this width is not served
-hipError_t launch_spmm_outer(const OuterArgs& a, bool valued, bool idx64, int reduce, hipStream_t st);
-
 // spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256, sum).
 // plan_device.hip (device_build_staging) writes the tables: blocks of staged_block_rows(N) consecutive rows of the clustered matrix,
 // kStagedWaves tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream

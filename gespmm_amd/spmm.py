@@ -90,8 +90,7 @@ class SpmmPlan:
     next to each other and find the shared B rows in L2 (and, at N = 128 / 256 where blocks of 96 / 64 clustered rows
     reuse their B rows, the tables of the staged-rows kernel: those rows are read from LDS; made for THIS width
     only). Only the processing order changes: the result has the same bits as the plain call.
-    ``kernel``: "auto" | "stream" | "seg-stream" | "staged" | "lds-rows" | "task-outer" (the last two: measured
-    alternatives kept opt-in).
+    ``kernel``: "auto" | "stream" | "seg-stream" | "staged".
 
         plan = SpmmPlan(rowptr, colind, K, N, values=val)      # reorder="auto" | True | False
         out = csr_spmm(rowptr, colind, val, dense, plan=plan)
@@ -117,18 +116,17 @@ class SpmmPlan:
         self._values_version = values._version if values is not None else None
         self.device = dev
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
-        kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "lds-rows": _lib.PLAN_KERNEL_LDS_ROWS,
-                "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM, "task-outer": _lib.PLAN_KERNEL_OUTER,
+        kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM,
                 "staged": _lib.PLAN_KERNEL_STAGED}[kernel]
         where = {"device": _lib.PLAN_ANALYSIS_DEVICE, "host": _lib.PLAN_ANALYSIS_HOST}[analysis]
         opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where)
         self._handle = ctypes.c_void_p()
         M, K_, N_, nnz, var = self.shape
         with _on_device(dev):
-            rc = lib.gespmm_plan_create(ctypes.byref(self._handle), _ptr(rowptr), _ptr(colind),
-                                        _ptr(values) if values is not None else None, M, K_, nnz, N_, var,
-                                        ctypes.byref(opt), _stream(dev))
-        check(rc, "gespmm_plan_create")
+            rc = lib.gespmm_plan_create_v2(ctypes.byref(self._handle), _ptr(rowptr), _ptr(colind),
+                                           _ptr(values) if values is not None else None, M, K_, nnz, N_, var,
+                                           ctypes.byref(opt), ctypes.sizeof(opt), _stream(dev))
+        check(rc, "gespmm_plan_create_v2")
 
     def __del__(self):
         h = getattr(self, "_handle", None)

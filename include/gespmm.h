@@ -55,7 +55,7 @@ extern "C" {
 #endif
 
 #define GESPMM_VERSION_MAJOR 0
-#define GESPMM_VERSION_MINOR 1
+#define GESPMM_VERSION_MINOR 2
 
 /* Negative return codes (positive values are hipError_t). */
 #define GESPMM_EINVAL   (-1)  /* bad argument (null pointer, negative size, unknown variant) */
@@ -259,7 +259,10 @@ int gespmm_csr2csc_f32(const int32_t* rowptr, const int32_t* colind, const float
  *     other, so the B rows they share come from the XCD's L2 instead of crossing the fabric again.
  * The order in which rows are PROCESSED is the only thing a plan changes: each row is still one fp32 chain in
  * its own CSR order written to its own row of C, so gespmm_plan_spmm_f32 returns the same bits as
- * gespmm_csr_spmm_f32 (with the same long-row decision; see GESPMM_FLAG_STRICT_ORDER).
+ * gespmm_csr_spmm_f32: the long-row pass (a re-association of rows beyond 32x the mean degree / 2048 entries) runs under a
+ * plan exactly where the plain call runs it — matrices of >= 2^23 non-zeros, or >= 2^20 with mean degree >= 8 — and, because
+ * the plan has SEEN the longest row, only when such a row exists. GESPMM_FLAG_SPLIT_LONG_ROWS / _STRICT_ORDER in
+ * gespmm_plan_options.flags force it on / off (as they do for the plain call).
  *
  * rowptr / colind / val are DEVICE pointers. A plan that keeps the storage order (small or dense matrices, or
  * reorder = GESPMM_PLAN_NO_REORDER) keeps referring to them, so they must outlive the plan; a clustered plan owns
@@ -280,8 +283,14 @@ typedef struct gespmm_plan_options {
     int32_t threads;       /* host threads for the clustering, 0 = all (the result does not depend on it) */
     int32_t flags;         /* GESPMM_FLAG_* applied to every launch (e.g. GESPMM_FLAG_STRICT_ORDER) */
     int32_t kernel;        /* GESPMM_PLAN_KERNEL_*: which kernel a clustered plan launches */
-    int32_t analysis;      /* GESPMM_PLAN_ANALYSIS_*: where the clustering / L2 model / task cutting run */
+    int32_t analysis;      /* GESPMM_PLAN_ANALYSIS_*: where the clustering / L2 model / task cutting run (since 0.2) */
 } gespmm_plan_options;
+/*
+ * Plan options and versions. Every field's default is 0 and fields are only ever APPENDED. gespmm_plan_create is the 0.1
+ * symbol: it reads the six fields 0.1 had (reorder .. kernel) and nothing beyond them, whatever header the caller was built
+ * with. gespmm_plan_create_v2 takes sizeof(gespmm_plan_options) as the caller's compiler saw it (`opt_bytes`): fields the
+ * caller does not have take their defaults, bytes this library does not know are ignored.
+ */
 
 #define GESPMM_PLAN_ANALYSIS_DEVICE 0  /* on the device (default): no copy of the matrix leaves HBM */
 #define GESPMM_PLAN_ANALYSIS_HOST   1  /* round-2 path: the matrix is copied to the host and clustered there (same order) */
@@ -289,17 +298,19 @@ typedef struct gespmm_plan_options {
 #define GESPMM_PLAN_KERNEL_AUTO     0  /* batch-stream kernel on the task table; segmented-stream for products-shaped rows */
 #define GESPMM_PLAN_KERNEL_STREAM   1  /* batch-stream kernel on the task table */
 #define GESPMM_PLAN_KERNEL_SEG_STREAM 3 /* segmented-stream kernel on a task table per lane group */
-#define GESPMM_PLAN_KERNEL_OUTER 4      /* task-outer kernel: each distinct B row of a task loaded once into registers and applied
-                                          to every row of the task that uses it (N >= 64, no long-row pass) */
+/* (values 2 and 4 belonged to two opt-in kernels of rounds 2-3 — LDS-staged task rows, task-outer — that never beat the
+   streaming kernels; their sources and logs are under profiles/r02/experiments/. gespmm_plan_create answers GESPMM_EINVAL.) */
 #define GESPMM_PLAN_KERNEL_STAGED 5     /* scalar-stream walk + the most used B rows of every block of 96 / 64 clustered rows staged in LDS
                                           (N = 128 / 256, sum reducer, device analysis; rows beyond 2048 entries go to the long-row pass); AUTO takes it for clustered
                                           matrices with mean degree >= 12 (N = 128) / >= 5 (N = 256) when >= 40 % of the entries find their
                                           B row staged */
-#define GESPMM_PLAN_KERNEL_LDS_ROWS 2  /* distinct B rows of a task fetched once into LDS (N % 4 == 0, no long-row pass) */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,
                        int64_t M, int64_t K, int64_t nnz, int64_t N /* width the plan is tuned for */, int variant,
                        const gespmm_plan_options* opt /* may be NULL */, void* stream);
+int gespmm_plan_create_v2(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
+                          int64_t K, int64_t nnz, int64_t N, int variant, const gespmm_plan_options* opt /* may be NULL */,
+                          int64_t opt_bytes /* sizeof(gespmm_plan_options) in the caller */, void* stream);
 /* C[M x N] = A * B through the plan; any N is legal (scratch and task size are tuned for the plan's N). */
 int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, void* stream);
 /* max reducer (unweighted plans only), see gespmm_csr_spmm_max_f32 */
@@ -348,16 +359,32 @@ double gespmm_device_l2_model(const int32_t* rowptr, const int32_t* colind, int6
 int gespmm_plan_debug_tasks(const gespmm_plan* plan, int32_t which, int32_t* out_host, int64_t capacity);
 
 /*
- * Test hook (HOST pointers, no device): the task records a clustered plan cuts for its LDS-staged-rows kernel
- * (layout: csrc/spmm_kernels.h) from a matrix processed in `perm` order, so a CPU test can interpret them against the
- * oracle. *recs_out (nrec x 160 int32) and *src_out (nrec x 64: position of each record entry's value in the caller's
- * value array, -1 = unused) are malloc'ed; free() them.
+ * The plan's POLICY by itself (host only, no device, no matrix): what gespmm_plan_create / gespmm_plan_spmm_f32 decide for a
+ * matrix of this shape once the analysis has produced the numbers in the query (csrc/plan_policy.cpp holds the rules, each
+ * with the log it was measured in). Lets callers and tests ask "what would a plan do" without building one.
  */
-int gespmm_debug_build_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
-                               int32_t task_entries, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out);
-/* The same for the task-outer kernel's records (nrec x 136 int32; src nrec x 64). */
-int gespmm_debug_build_outer_records(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
-                                     int32_t task_entries, int32_t** recs_out, int32_t** src_out, int32_t* nrec_out);
+typedef struct gespmm_plan_policy_query {
+    int64_t M, K, nnz, N;
+    int64_t N_launch;        /* width of the launch asked about (0 = N) */
+    int32_t variant;         /* GESPMM_VARIANT_* */
+    int32_t max_degree;      /* longest row */
+    int32_t reorder, kernel, analysis, flags, task_entries, row_floor; /* as in gespmm_plan_options */
+    double hits_before, hits_after; /* modelled L2 hit rates in storage / clustered order */
+    double staged_fraction;  /* share of the entries whose B row a staged-rows block holds in LDS */
+} gespmm_plan_policy_query;
+typedef struct gespmm_plan_policy_answer {
+    int32_t launch_flags;      /* user flags + GESPMM_FLAG_SPLIT_LONG_ROWS or _STRICT_ORDER */
+    int32_t analyse;           /* clustering + L2 model run at all */
+    int32_t dense_try;         /* dense graph: the clustered order needs >= 0.65 modelled hits */
+    int32_t keep_clustered;    /* ... and is kept, given hits_before / hits_after */
+    int32_t task_entries, group_task_entries, row_floor;
+    int32_t build_staged, keep_staged; /* staged-rows tables are built / kept, given staged_fraction */
+    int32_t shallow_unroll;
+    int32_t segmented;         /* the streaming launch at N_launch takes the segmented-stream kernel */
+    int32_t sddmm_route;       /* 0 CSR call, 1 COO on expanded row ids, 2 clustered edge order + scatter */
+    int64_t model_window, model_sample;
+} gespmm_plan_policy_answer;
+int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);
 
 /*
  * Comparison column, not a product path: the Gunrock app's edge map

@@ -61,7 +61,7 @@ def main():
             plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=False)
             us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
             print("%s N=%d storage-order plan    %8.1f us  frac %.3f" % (name, N, us, abytes / us / 8e6), flush=True)
-            for kernel in ("stream", "seg-stream", "lds-rows", "task-outer"):
+            for kernel in ("stream", "seg-stream"):
                 if kernel == "lds-rows" and N % 4:
                     continue
                 for te in [int(x) for x in args.entries.split(",")]:

@@ -74,7 +74,7 @@ def main():
                 what = "plain flags 0x%x" % fl
                 break
         if what is None:
-            for kernel in ("auto", "stream", "seg-stream", "lds-rows", "task-outer"):
+            for kernel in ("auto", "stream", "seg-stream"):
                 plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=bool(rng.rand() < 0.8), kernel=kernel, flags=strict,
                                      task_entries=int(rng.choice([0, 8, 40, 200])))
                 nplans += 1

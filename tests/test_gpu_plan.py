@@ -21,16 +21,11 @@ def test_clustered_plan_bits_equal_oracle(pkg, oracle, bundled, graph):
     rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
     val_h = oracle.hash_val(g["nnz"], seed=7)
     val = _dev(val_h)
-    for N, kernel in ((3, "auto"), (32, "lds-rows"), (32, "stream"), (100, "lds-rows"), (128, "lds-rows"), (128, "stream"), (128, "seg-stream"), (32, "seg-stream"), (100, "seg-stream"),
-                      (128, "task-outer"), (64, "task-outer"), (256, "task-outer"), (512, "task-outer"), (130, "task-outer"),
-                      (101, "task-outer"),
-                      (260, "lds-rows"), (512, "auto"), (16, "lds-rows"), (64, "lds-rows"), (8, "lds-rows")):
+    for N, kernel in ((3, "auto"), (32, "stream"), (128, "stream"), (128, "seg-stream"), (32, "seg-stream"), (100, "seg-stream"),
+                      (64, "stream"), (256, "seg-stream"), (512, "stream"), (130, "stream"), (101, "stream"), (260, "seg-stream"),
+                      (512, "auto"), (16, "stream"), (8, "seg-stream")):
         plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True, kernel=kernel)
         assert plan.clustered, plan.describe()
-        if kernel == "lds-rows":
-            assert "kernel=lds-rows" in plan.describe(), plan.describe()
-        if kernel == "task-outer":
-            assert "kernel=task-outer" in plan.describe(), plan.describe()
         order = plan.order().numpy()
         assert np.array_equal(np.sort(order), np.arange(g["M"]))
         B_h = oracle.hash_B(g["K"], N, seed=N)
@@ -76,12 +71,7 @@ def test_edge_shapes_rectangular_empty_rows_duplicates(pkg, oracle):
     val_h = oracle.hash_val(g["nnz"], seed=3)
     for N in (1, 7, 64, 132):
         B_h = oracle.hash_B(g["K"], N, seed=N + 1)
-        for te, kernel in ((0, "stream"), (8, "stream"), (1000, "stream"), (0, "lds-rows"), (8, "lds-rows"),
-                           (0, "seg-stream"), (8, "seg-stream"), (1000, "seg-stream"), (0, "task-outer"), (8, "task-outer")):
-            if kernel == "lds-rows" and N % 4:
-                continue
-            if kernel == "task-outer" and N < 64:
-                continue
+        for te, kernel in ((0, "stream"), (8, "stream"), (1000, "stream"), (0, "seg-stream"), (8, "seg-stream"), (1000, "seg-stream")):
             plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=_dev(val_h), reorder=True, task_entries=te, kernel=kernel)
             got = plan.run(None, _dev(B_h)).cpu().numpy()
             ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
@@ -113,7 +103,7 @@ def test_fuzz_plans_against_plain_calls(pkg):
                                 _lib.FLAG_FORCE_IDX64 | _lib.FLAG_SHALLOW_UNROLL]))
         plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=int(rng.choice([0, 16, 64])),
                              flags=_lib.FLAG_STRICT_ORDER | extra,
-                             kernel=str(rng.choice(["auto", "stream", "lds-rows", "seg-stream", "task-outer"])))
+                             kernel=str(rng.choice(["auto", "stream", "seg-stream"])))
         got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
         ref = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_STRICT_ORDER})
         assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (case, M, K, N)
@@ -145,9 +135,7 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     # N = 32 and 512 through plans of their own
     for N in (32, 512):
         Bn = (torch.randint(0, 100, (M, N), device="cuda", dtype=torch.int32) - 50).float() / 100
-        for kernel in ("stream", "lds-rows", "seg-stream", "task-outer"):
-            if kernel == "task-outer" and N < 64:
-                continue
+        for kernel in ("stream", "seg-stream"):
             pn = spmm.SpmmPlan(rp, ci, M, N, values=val, reorder=True, kernel=kernel)
             assert torch.equal(spmm.csr_spmm(rp, ci, val, Bn, plan=pn).view(torch.int32),
                                spmm.csr_spmm(rp, ci, val, Bn).view(torch.int32)), (N, kernel)

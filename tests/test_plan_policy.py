@@ -1,0 +1,74 @@
+"""The plan's POLICY (csrc/plan_policy.cpp) asked through gespmm_plan_policy — host only, no device: one table of
+(shape, analysis numbers) -> decisions for the BASELINE shapes and the hold-out graphs of profiles/r04/holdout_audit.log.
+A threshold that moves shows up here as a changed row, with the log that moved it."""
+import pytest
+
+from gespmm_amd import _lib
+
+SPLIT, STRICT, SHALLOW = _lib.FLAG_SPLIT_LONG_ROWS, _lib.FLAG_STRICT_ORDER, _lib.FLAG_SHALLOW_UNROLL
+
+# name, (M, nnz, N, max_degree, hits_before, hits_after, staged_fraction), expected subset of the answer
+TABLE = [
+    # ---- BASELINE configs (the stand-ins' measured analysis numbers)
+    ("C2a com-amazon-sbm N=128", (334863, 1851744, 128, 120, 0.018, 0.651, 0.0),
+     dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=40, group_task_entries=16, build_staged=0, shallow_unroll=1,
+          segmented=0, launch_flags=STRICT, sddmm_route=2)),
+    ("C2a com-amazon-like N=128", (334863, 1851744, 128, 499, 0.025, 0.176, 0.0),
+     dict(analyse=1, keep_clustered=1, task_entries=40, build_staged=0, shallow_unroll=0, segmented=0, sddmm_route=1)),
+    ("C2a com-amazon-sbm N=32", (334863, 1851744, 32, 120, 0.09, 0.70, 0.0),
+     dict(analyse=1, keep_clustered=1, task_entries=96, shallow_unroll=1, segmented=0)),
+    ("C2a com-amazon-sbm N=512", (334863, 1851744, 512, 120, 0.01, 0.60, 0.0),
+     dict(analyse=1, keep_clustered=1, task_entries=32, shallow_unroll=0, build_staged=0)),
+    ("C2a id-local storage order", (334863, 1851744, 128, 499, 0.60, 0.62, 0.0), dict(analyse=1, keep_clustered=0, segmented=0)),
+    ("C2b reddit-like N=128 (dense, no structure)", (232965, 114615892, 128, 21000, 0.10, 0.30, 0.0),
+     dict(analyse=1, dense_try=1, keep_clustered=0)),
+    ("C2b reddit-sbm N=128 (dense, communities)", (232965, 114615892, 128, 2000, 0.10, 0.72, 0.0),
+     dict(analyse=1, dense_try=1, keep_clustered=1, segmented=1)),
+    ("C3 products-sbm N=128", (2449029, 123718280, 128, 1446, 0.003, 0.840, 0.638),
+     dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=255, build_staged=1, keep_staged=1, segmented=0, model_sample=1 << 22)),
+    ("C3 products-sbm N=32", (2449029, 123718280, 32, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=1)),
+    ("C3 products-sbm N=64", (2449029, 123718280, 64, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=0)),
+    ("C3 products-like N=128 (no structure)", (2449029, 123718280, 128, 30000, 0.003, 0.02, 0.0),
+     dict(analyse=1, keep_clustered=0, launch_flags=SPLIT)),
+    ("C1 cit-hepth N=32 (small: B fits the L2s)", (27770, 352807, 32, 2000, 0.0, 0.0, 0.0), dict(analyse=0, keep_clustered=0, launch_flags=STRICT)),
+    ("C4 pubmed N=128", (19717, 108365, 128, 172, 0.1, 0.5, 0.0), dict(analyse=1, keep_clustered=1, shallow_unroll=0, build_staged=0)),
+    ("C5 rmat-26 shard N=256", (8388608, 134217728, 256, 400000, 0.0, 0.0, 0.0), dict(launch_flags=SPLIT)),
+    # ---- the long-row pass follows the plain call: never below 2^20 entries / mean degree 8 even with a hub row
+    ("hub row in a small matrix", (20000, 100000, 128, 9000, 0.0, 0.0, 0.0), dict(launch_flags=STRICT)),
+    ("hub row, 2^20 entries, mean degree 10", (500000, 4999852, 128, 8968, 0.055, 0.346, 0.0), dict(launch_flags=SPLIT, keep_clustered=1)),
+]
+
+
+@pytest.mark.parametrize("name,shape,expect", TABLE, ids=[t[0] for t in TABLE])
+def test_policy_table(name, shape, expect):
+    M, nnz, N, maxdeg, hb, ha, sf = shape
+    got = _lib.plan_policy(M, M, nnz, N, maxdeg, hb, ha, sf)
+    for k, v in expect.items():
+        if k == "launch_flags":
+            assert got[k] & (SPLIT | STRICT) == v, (name, k, got)
+        else:
+            assert got[k] == v, (name, k, got)
+
+
+def test_policy_respects_the_callers_choices():
+    base = (334863, 334863, 1851744, 128, 120, 0.018, 0.651, 0.0)
+    assert _lib.plan_policy(*base, reorder=_lib.PLAN_NO_REORDER)["analyse"] == 0
+    assert _lib.plan_policy(*base, kernel=_lib.PLAN_KERNEL_SEG_STREAM)["segmented"] == 1
+    assert _lib.plan_policy(*base, kernel=_lib.PLAN_KERNEL_STREAM)["segmented"] == 0
+    forced = _lib.plan_policy(*base, kernel=_lib.PLAN_KERNEL_STAGED)
+    assert forced["build_staged"] == 1 and forced["keep_staged"] == 1  # an explicit choice is not second-guessed
+    assert _lib.plan_policy(*base, kernel=_lib.PLAN_KERNEL_STAGED, analysis=_lib.PLAN_ANALYSIS_HOST)["build_staged"] == 0
+    assert _lib.plan_policy(*base, task_entries=24)["task_entries"] == 24
+    assert _lib.plan_policy(*base, task_entries=24)["group_task_entries"] == 12
+    assert _lib.plan_policy(*base, flags=_lib.FLAG_SPLIT_LONG_ROWS)["launch_flags"] & SPLIT
+    # a launch at another width than the plan's asks the kernel rule with THAT width
+    p = (2449029, 2449029, 123718280, 128, 1446, 0.003, 0.84, 0.2)
+    assert _lib.plan_policy(*p)["keep_staged"] == 0 and _lib.plan_policy(*p)["segmented"] == 1
+    assert _lib.plan_policy(*p, N_launch=64)["segmented"] == 0
+
+
+def test_policy_rejects_bad_queries():
+    with pytest.raises(_lib.GespmmError):
+        _lib.plan_policy(-1, 1, 1, 1, 1)
+    with pytest.raises(_lib.GespmmError):
+        _lib.plan_policy(10, 10, 10, 8, 1, variant=99)
