@@ -627,7 +627,7 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
                                  p->stg.nhot, B, C, p->stg.nblocks};
-        rc = (int)gespmm::launch_spmm_staged(sa, N, reinterpret_cast<hipStream_t>(stream));
+        rc = (int)gespmm::launch_spmm_staged(sa, p->K, N, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0 && p->stg.nlong > 0) {
             // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits
             // them — under GESPMM_FLAG_STRICT_ORDER each is one lane group's chain instead, as everywhere else

@@ -101,7 +101,8 @@ hipError_t launch_spmm_slabblocked(const SpmmArgs& a, const Geometry& geo, void*
                                    hipStream_t st);
 hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStream_t st);
 
-// spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256, sum).
+// spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256 and, as
+// 256-column tiles bound to XCDs, 512 / 1024; sum).
 // plan_device.hip (device_build_staging) writes the tables: blocks of staged_block_rows(N) consecutive rows of the clustered matrix,
 // kStagedWaves tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream
 // `ev` = {code, value bits} per entry (code >= 0: column; code < 0: staged slot in its low bits), padded by kStagedPad entries.
@@ -122,8 +123,9 @@ struct StagedArgs {
     int32_t nblocks;
 };
 int staged_rows_per_block_lds(int64_t N);  // H for this width; 0 = width not served
-int staged_block_rows(int64_t N);          // rows per block: 96 at N = 128, 64 at N = 256 (profiles/r03/staged_rows.log)
-hipError_t launch_spmm_staged(const StagedArgs& a, int64_t N, hipStream_t st);
+int staged_block_rows(int64_t N);          // rows per block: 96 at N = 128, 64 for 256-column tiles (profiles/r03/staged_rows.log)
+bool staged_serves(int64_t K, int64_t N);  // width served and B addressable (32-bit offsets; two 4 GB halves for the tiled widths)
+hipError_t launch_spmm_staged(const StagedArgs& a, int64_t K, int64_t N, hipStream_t st);
 
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form

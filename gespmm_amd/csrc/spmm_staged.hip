@@ -36,6 +36,12 @@
 #include "spmm_device.h"
 #include "spmm_kernels.h"
 
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__) || defined(__gfx942__)
+// (the inline assembly below spells its memory instructions — sc1 / nt modifiers, SGPR-base global loads — for gfx942 / gfx950)
+#else
+#error "spmm_staged.hip is written for gfx950 (gfx942 ISA compatible): its inline assembly does not assemble elsewhere"
+#endif
+
 namespace gespmm {
 
 namespace {
@@ -47,26 +53,48 @@ template <int VEC> struct LaneVec;
 template <> struct LaneVec<2> { using type = float __attribute__((ext_vector_type(2))); };
 template <> struct LaneVec<4> { using type = float __attribute__((ext_vector_type(4))); };
 
-template <int VEC, int U>
+// Wider matrices are COLUMN-TILED (round 4): N = 64 * VEC << TSHIFT, a workgroup computes ONE tile of 64 * VEC columns of its block
+// of rows; tile t is bound to the XCDs whose id is t modulo the tile count (workgroup ids go to XCDs round-robin), so an XCD's L2
+// only ever holds its own tile's columns of B, and inside that XCD group the blocks stay contiguous (xcd_contiguous, generalised).
+// LDS holds the tile's part of the staged rows: H and the block height are those of the tile width, the tables are shared by
+// all tiles. The entry stream is read once per tile.
+// PAGE2: B between 4 and 8 GB (products-shaped x 512 columns: 5.0 GB). The lane's 32-bit offset wraps modulo 4 GB by itself —
+// `code << log2(row bytes)` drops the bit that says which half — and the base pointer is chosen between B and B + 4 GB by
+// that bit of the (scalar) code: two scalar instructions on the memory path, none on the LDS path.
+template <int VEC, int U, int TSHIFT, bool PAGE2>
 __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedArgs a) {
     using vec_t = typename LaneVec<VEC>::type;
-    constexpr int kRowBytes = 256 * VEC;          // N * 4
+    constexpr int kRowBytes = 256 * VEC;          // bytes of a row inside one tile
     constexpr int kRowShift = (VEC == 2) ? 9 : 10;
+    constexpr int kGlobalShift = kRowShift + TSHIFT;  // log2(N * 4): row stride of B and C
     constexpr int H = kStagedLdsBytes / kRowBytes;  // staged rows per block
     constexpr int kRowF4 = kRowBytes / 16;
+    static_assert(kStagedPad >= 3 * U, "the stream is over-read by up to three chunks past a task's end");
+    static_assert(TSHIFT >= 0 && TSHIFT <= 3, "at most one tile per XCD");
     __shared__ f4v s_hot[H * kRowF4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int blk = xcd_contiguous(blockIdx.x, a.nblocks);
+    int blk, tile = 0;
+    if constexpr (TSHIFT == 0) {
+        blk = xcd_contiguous(blockIdx.x, a.nblocks);
+    } else {
+        constexpr int NX = 8 >> TSHIFT;  // XCDs that serve one tile
+        tile = (int)blockIdx.x & ((1 << TSHIFT) - 1);
+        const int x = ((int)blockIdx.x & 7) >> TSHIFT, idx = (int)blockIdx.x >> 3;
+        const int q = a.nblocks / NX, r = a.nblocks % NX;
+        blk = ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+    }
     const int task = blk * kStagedWaves + wave;
     cint_ptr tk = (cint_ptr)(uintptr_t)a.tasks + (size_t)task * 4;
     const int row_first = tk[0], nrows = tk[1], wb = tk[2], we = tk[3];
     cint_ptr rowptr = (cint_ptr)(uintptr_t)a.rowptr + row_first;
     cint_ptr perm = (cint_ptr)(uintptr_t)a.perm + row_first;
     cint_ptr ev = (cint_ptr)(uintptr_t)a.ev + (size_t)wb * 2;  // {code, value bits} per entry
-    const float* Bp = a.B;
+    const float* Bp = a.B + (size_t)tile * (64 * VEC);
+    const float* BpHi = Bp + (1ull << 30);  // + 4 GB (PAGE2)
+    (void)BpHi;
     const uint32_t loff = (uint32_t)lane * (4u * VEC);
     {
         const int total = ((cint_ptr)(uintptr_t)a.nhot)[blk] * kRowF4;
@@ -78,7 +106,7 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
             for (int u = 0; u < 4; ++u) {  // (clamped, not predicated: the four loads stay in flight together)
                 const int i = i0 + u * kStagedWaves * 64 + tid;
                 const int ic = i < total ? i : total - 1;
-                r[u] = B4[(size_t)hc[ic / kRowF4] * kRowF4 + (ic % kRowF4)];
+                r[u] = B4[(((size_t)hc[ic / kRowF4] << TSHIFT) + (size_t)tile) * kRowF4 + (ic % kRowF4)];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -100,7 +128,7 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
     auto flush = [&]() {  // row `cur` is complete: store it, step to the next one (its end and C row were requested a row ago)
-        float* Crow = a.C + (size_t)crow * (size_t)(64 * VEC);
+        float* Crow = a.C + (((size_t)crow << TSHIFT) + (size_t)tile) * (size_t)(64 * VEC);
         vec_t out;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) out[i] = acc[i];
@@ -119,9 +147,34 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
     // nobody near this block will ask for it again — gathered with `nt` so that it does not push the neighbourhood's rows out of L2
     auto gather = [&](int code, vec_t& d) {
         // (the reference to s_hot keeps the staging stores alive: the LDS reads below are invisible to the compiler)
-        const uint32_t voff =
+        // (one tile: the same offset serves both paths — LDS address of the staged row / byte offset of the B row — and the
+        //  compiler keeps one register; tiled: the strides differ)
+        const uint32_t voff_l =
             ((uint32_t)code << kRowShift) + loff + (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f4v*)s_hot;
-        if constexpr (VEC == 2)
+        const uint32_t voff = (TSHIFT == 0) ? voff_l : ((uint32_t)code << kGlobalShift) + loff;
+        if constexpr (PAGE2) {
+            static_assert(!PAGE2 || VEC == 4, "paged bases exist for the 256-column tiles");
+            constexpr int kPageBit = 32 - kGlobalShift;  // bit of the column that selects the 4 GB half
+            uint64_t base;  // scratch SGPR pair: the chosen half's base
+            asm volatile(
+                "s_cmp_lt_i32 %3, 0\n\t"
+                "s_cbranch_scc1 1f\n\t"
+                "s_bitcmp1_b32 %3, %7\n\t"
+                "s_cselect_b64 %1, %6, %4\n\t"
+                "s_bitcmp1_b32 %3, 30\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                "global_load_dwordx4 %0, %2, %1\n\t"
+                "s_branch 2f\n"
+                "3:\n\t"
+                "global_load_dwordx4 %0, %2, %1 nt\n\t"
+                "s_branch 2f\n"
+                "1:\n\t"
+                "ds_read_b128 %0, %5\n"
+                "2:"
+                : "=&v"(d), "=&s"(base)
+                : "v"(voff), "s"(code), "s"(Bp), "v"(voff_l), "s"(BpHi), "n"(kPageBit)
+                : "memory", "scc");
+        } else if constexpr (VEC == 2)
             asm volatile(
                 "s_cmp_lt_i32 %2, 0\n\t"
                 "s_cbranch_scc1 1f\n\t"
@@ -133,10 +186,10 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
                 "global_load_dwordx2 %0, %1, %3 nt\n\t"
                 "s_branch 2f\n"
                 "1:\n\t"
-                "ds_read_b64 %0, %1\n"
+                "ds_read_b64 %0, %4\n"
                 "2:"
                 : "=&v"(d)
-                : "v"(voff), "s"(code), "s"(Bp)
+                : "v"(voff), "s"(code), "s"(Bp), "v"(voff_l)
                 : "memory", "scc");
         else
             asm volatile(
@@ -150,10 +203,10 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
                 "global_load_dwordx4 %0, %1, %3 nt\n\t"
                 "s_branch 2f\n"
                 "1:\n\t"
-                "ds_read_b128 %0, %1\n"
+                "ds_read_b128 %0, %4\n"
                 "2:"
                 : "=&v"(d)
-                : "v"(voff), "s"(code), "s"(Bp)
+                : "v"(voff), "s"(code), "s"(Bp), "v"(voff_l)
                 : "memory", "scc");
     };
     auto fma_row = [&](int vbits, const vec_t& b) {
@@ -205,26 +258,51 @@ __global__ __launch_bounds__(kStagedWaves * 64) void spmm_staged_kernel(StagedAr
 
 }  // namespace
 
+// Width of one column tile (128 or 256 columns) and log2 of the tile count, or 0 / -1 when the width is not served:
+// N = 128, and N = 256 * 2^t for t = 0..2 (the B / C row stride is formed by a shift).
+static int staged_tile_cols(int64_t N, int* tshift) {
+    if (N == 128) { *tshift = 0; return 128; }
+    for (int t = 0; t <= 2; ++t)
+        if (N == (256ll << t)) { *tshift = t; return 256; }
+    *tshift = -1;
+    return 0;
+}
+
 int staged_block_rows(int64_t N) {
     // measured on the products-shaped community graph (us at N = 128 / 256): 64 rows 3286 / 5584, 80: 3122 / 5596, 96: 3012 / 5834,
     // 112: 3120 / 6264, 128: 3065 / 6440 — about as many rows as LDS holds staged rows for the width's row size
-    if (N == 128) return 96;
-    if (N == 256) return 64;
-    return 0;
+    int t;
+    const int tc = staged_tile_cols(N, &t);
+    return tc == 128 ? 96 : (tc == 256 ? 64 : 0);
 }
 
 int staged_rows_per_block_lds(int64_t N) {
-    if (N == 128) return kStagedLdsBytes / 512;
-    if (N == 256) return kStagedLdsBytes / 1024;
-    return 0;
+    int t;
+    const int tc = staged_tile_cols(N, &t);
+    return tc ? kStagedLdsBytes / (tc * 4) : 0;
 }
 
-hipError_t launch_spmm_staged(const StagedArgs& a, int64_t N, hipStream_t st) {
+// B beyond 4 GB: two 4 GB halves (tiled widths only), up to 8 GB.
+bool staged_serves(int64_t K, int64_t N) {
+    int t;
+    if (!staged_tile_cols(N, &t)) return false;
+    const uint64_t bytes = (uint64_t)K * (uint64_t)N * 4ull;
+    return bytes < 0xFFFF0000ull || (t >= 1 && bytes < 0x1FFFF0000ull);
+}
+
+hipError_t launch_spmm_staged(const StagedArgs& a, int64_t K, int64_t N, hipStream_t st) {
     if (a.nblocks <= 0) return hipSuccess;
-    if (N == 128)
-        hipLaunchKernelGGL((spmm_staged_kernel<2, 8>), dim3((unsigned)a.nblocks), dim3(kStagedWaves * 64), 0, st, a);
-    else if (N == 256)
-        hipLaunchKernelGGL((spmm_staged_kernel<4, 8>), dim3((unsigned)a.nblocks), dim3(kStagedWaves * 64), 0, st, a);
+    if (!staged_serves(K, N)) return hipErrorInvalidValue;
+    int t;
+    const int tc = staged_tile_cols(N, &t);
+    const bool paged = (uint64_t)K * (uint64_t)N * 4ull >= 0xFFFF0000ull;
+    const dim3 grid((unsigned)a.nblocks << (t > 0 ? t : 0)), block(kStagedWaves * 64);
+    if (tc == 128) hipLaunchKernelGGL((spmm_staged_kernel<2, 8, 0, false>), grid, block, 0, st, a);
+    else if (tc == 256 && t == 0) hipLaunchKernelGGL((spmm_staged_kernel<4, 8, 0, false>), grid, block, 0, st, a);
+    else if (tc == 256 && t == 1 && !paged) hipLaunchKernelGGL((spmm_staged_kernel<4, 8, 1, false>), grid, block, 0, st, a);
+    else if (tc == 256 && t == 1 && paged) hipLaunchKernelGGL((spmm_staged_kernel<4, 8, 1, true>), grid, block, 0, st, a);
+    else if (tc == 256 && t == 2 && !paged) hipLaunchKernelGGL((spmm_staged_kernel<4, 8, 2, false>), grid, block, 0, st, a);
+    else if (tc == 256 && t == 2 && paged) hipLaunchKernelGGL((spmm_staged_kernel<4, 8, 2, true>), grid, block, 0, st, a);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -18,7 +18,7 @@ TABLE = [
     ("C2a com-amazon-sbm N=32", (334863, 1851744, 32, 120, 0.09, 0.70, 0.0),
      dict(analyse=1, keep_clustered=1, task_entries=96, shallow_unroll=1, segmented=0)),
     ("C2a com-amazon-sbm N=512", (334863, 1851744, 512, 120, 0.01, 0.60, 0.0),
-     dict(analyse=1, keep_clustered=1, task_entries=32, shallow_unroll=0, build_staged=0)),
+     dict(analyse=1, keep_clustered=1, task_entries=32, shallow_unroll=0, build_staged=1)),  # 256-column tiles since round 4
     ("C2a id-local storage order", (334863, 1851744, 128, 499, 0.60, 0.62, 0.0), dict(analyse=1, keep_clustered=0, segmented=0)),
     ("C2b reddit-like N=128 (dense, no structure)", (232965, 114615892, 128, 21000, 0.10, 0.30, 0.0),
      dict(analyse=1, dense_try=1, keep_clustered=0)),
@@ -28,6 +28,18 @@ TABLE = [
      dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=255, build_staged=1, keep_staged=1, segmented=0, model_sample=1 << 22)),
     ("C3 products-sbm N=32", (2449029, 123718280, 32, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=1)),
     ("C3 products-sbm N=64", (2449029, 123718280, 64, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=0)),
+    ("C3 products-sbm N=512", (2449029, 123718280, 512, 1446, 0.001, 0.833, 0.503), dict(keep_clustered=1, build_staged=1, keep_staged=1)),
+    # ---- hold-out graphs (profiles/r04/holdout_audit.log): the rows that moved thresholds in round 4
+    ("LFR mu=0.1 N=128: share 0.565 loses 21 % staged", (300000, 4717400, 128, 306, 0.041, 0.768, 0.565),
+     dict(keep_clustered=1, build_staged=1, keep_staged=0, segmented=0)),
+    ("LFR mu=0.1 N=256: share 0.44 loses 5 % staged", (300000, 4717400, 256, 306, 0.021, 0.763, 0.440), dict(build_staged=1, keep_staged=0, segmented=0)),
+    ("geometric N=128: share 0.94 wins", (600000, 7175884, 128, 30, 0.010, 0.910, 0.937), dict(build_staged=1, keep_staged=1)),
+    ("small-world N=256: share 0.77 wins", (1000000, 11001376, 256, 18, 0.003, 0.815, 0.767), dict(build_staged=1, keep_staged=1)),
+    ("dense LFR mu=0.3 N=128: batch kernel at 0.52 hits", (300000, 15383642, 128, 619, 0.035, 0.519, 0.27), dict(keep_staged=0, segmented=0)),
+    ("dense LFR mu=0.3 N=32", (300000, 15383642, 32, 619, 0.136, 0.572, 0.0), dict(segmented=0)),
+    ("dense LFR mu=0.3 N=256: segmented at mid hit rates", (300000, 15383642, 256, 619, 0.018, 0.487, 0.196), dict(keep_staged=0, segmented=1)),
+    ("Holme-Kim m=5 N=128 (hubs: long-row pass)", (500000, 4999852, 128, 8968, 0.055, 0.346, 0.341), dict(keep_clustered=1, keep_staged=0, launch_flags=SPLIT)),
+    ("skewed RMAT: storage order already hits", (524288, 12582912, 128, 181863, 0.558, 0.559, 0.0), dict(analyse=1, keep_clustered=0)),
     ("C3 products-like N=128 (no structure)", (2449029, 123718280, 128, 30000, 0.003, 0.02, 0.0),
      dict(analyse=1, keep_clustered=0, launch_flags=SPLIT)),
     ("C1 cit-hepth N=32 (small: B fits the L2s)", (27770, 352807, 32, 2000, 0.0, 0.0, 0.0), dict(analyse=0, keep_clustered=0, launch_flags=STRICT)),
