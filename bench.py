@@ -158,7 +158,11 @@ def main():
     import torch.distributed as dist
 
     import gespmm_amd  # noqa: F401
-    from gespmm_amd import graphs, spmm
+    from gespmm_amd import _lib, graphs, spmm
+
+    # this run creates products-sized plans several times in a row: keep their ~10 GB analysis arena between them (the library's
+    # default keeps 1 GiB; a multi-GB hipMalloc was seen to take seconds now and then: profiles/r03/plan_repeat.log)
+    _lib.set_cached_memory_limit(16 << 30)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

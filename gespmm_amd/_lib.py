@@ -70,6 +70,8 @@ EXPORTS = [
     "gespmm_simulate_l2_hits",
     "gespmm_plan_create_v2",
     "gespmm_plan_policy",
+    "gespmm_plan_tune",
+    "gespmm_set_cached_memory_limit",
     "gespmm_device_cluster_rows",
     "gespmm_device_l2_model",
     "gespmm_plan_debug_tasks",
@@ -179,6 +181,10 @@ def _load():
                                           POINTER(PlanOptions), c_int64, p]
     lib.gespmm_plan_policy.restype = c_int
     lib.gespmm_plan_policy.argtypes = [POINTER(PlanPolicyQuery), POINTER(PlanPolicyAnswer)]
+    lib.gespmm_plan_tune.restype = c_int
+    lib.gespmm_plan_tune.argtypes = [p, p, p, c_int64, c_int32, p]
+    lib.gespmm_set_cached_memory_limit.restype = None
+    lib.gespmm_set_cached_memory_limit.argtypes = [c_int64]
     lib.gespmm_plan_spmm_f32.restype = c_int
     lib.gespmm_plan_spmm_f32.argtypes = [p, p, p, c_int64, p]
     lib.gespmm_plan_spmm_max_f32.restype = c_int
@@ -232,8 +238,15 @@ def plan_policy(M, K, nnz, N, max_degree, hits_before=0.0, hits_after=0.0, stage
 
 
 def release_cached_memory():
-    """Give the analysis stage's cached scratch arena back to the device (gespmm_release_cached_memory)."""
+    """Give the analysis stage's cached scratch arenas back to the devices (gespmm_release_cached_memory)."""
     lib.gespmm_release_cached_memory()
+
+
+def set_cached_memory_limit(nbytes):
+    """Largest analysis arena the library keeps between plans, per device (default 1 GiB; larger arenas are freed when the plan
+    is made). A caller that builds many large plans in a row raises it (products-sized graphs: ~10 GB) and calls
+    release_cached_memory() when done."""
+    lib.gespmm_set_cached_memory_limit(int(nbytes))
 
 
 def check(code, where):

@@ -77,6 +77,9 @@ struct gespmm_plan {
     // staged-rows kernel (spmm_staged.hip): tables for width N (plan_device.hip: device_build_staging)
     gespmm::StagingTables stg;
     double staging_seconds = 0.0;
+    // gespmm_plan_tune: measured kernel times on the caller's operands (us; < 0: candidate not available)
+    bool tuned = false;
+    double tune_us[3] = {-1.0, -1.0, -1.0};  // batch-stream, segmented-stream, staged-rows
 };
 
 namespace {
@@ -254,6 +257,36 @@ int gespmm_plan_debug_tasks(const gespmm_plan* p, int32_t which, int32_t* out_ho
     const int64_t take = n < capacity ? n : capacity;
     if (take > 0 && out_host && hipMemcpy(out_host, d, (size_t)take * 16, hipMemcpyDeviceToHost) != hipSuccess) return GESPMM_EINVAL;
     return n;
+}
+
+// Tables of the staged-rows kernel for the plan's width (plan_device.hip). Hub rows (one wavefront would walk such a row
+// alone) are taken out: the staged kernel sees them empty, the streaming kernel's long-row pass gets them as one-row tasks
+// (plan_run). Leaves p->stg empty when there is nothing but hub rows.
+static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
+    const auto ts = std::chrono::steady_clock::now();
+    const int64_t M = p->M, K = p->K, nnz = p->nnz, N = p->N;
+    const int H = gespmm::staged_rows_per_block_lds(N);
+    hipError_t e = hipSuccess;
+    const int32_t* rp_s = p->d_rowptr;
+    const int32_t* ci_s = p->d_colind;
+    const float* val_s = p->valued ? p->d_val : nullptr;
+    int32_t* ci_tmp = nullptr;
+    float* val_tmp = nullptr;
+    int64_t nnz_s = nnz;
+    if (p->max_degree > gespmm::kStagedMaxRow) {
+        e = gespmm::device_split_long_rows(M, nnz, p->d_rowptr, p->d_colind, val_s, gespmm::kStagedMaxRow, &p->stg, &ci_tmp, &val_tmp, st);
+        rp_s = p->stg.rowptr_s;
+        ci_s = ci_tmp;
+        val_s = val_tmp;
+        nnz_s = p->stg.nnz_s;
+    }
+    if (e == hipSuccess && nnz_s > 0)
+        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, gespmm::staged_block_rows(N), H, &p->stg, st);
+    if (ci_tmp) (void)hipFree(ci_tmp);
+    if (val_tmp) (void)hipFree(val_tmp);
+    if (e == hipSuccess && !p->stg.ev) gespmm::free_staging(&p->stg);  // (nothing but hub rows)
+    p->staging_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+    return e;
 }
 
 // gespmm_plan_create_v2: `opt_bytes` = sizeof(gespmm_plan_options) as the CALLER was compiled with; fields beyond it take
@@ -435,39 +468,13 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             lap("values");
-            // ---- staged-rows kernel (choose_plan_kernel says when): hub rows are taken out, the tables are built, and kept when
-            //      enough entries find their B row staged
-            {
-                const int H = gespmm::staged_rows_per_block_lds(N);
-                if (e == hipSuccess && kd.build_staged) {
-                    const auto ts = std::chrono::steady_clock::now();
-                    // hub rows (one wavefront would walk such a row alone) are taken out: the staged kernel sees them empty, the
-                    // streaming kernel's long-row pass gets them as one-row tasks (plan_run)
-                    const int32_t* rp_s = p->d_rowptr;
-                    const int32_t* ci_s = p->d_colind;
-                    const float* val_s = p->valued ? p->d_val : nullptr;
-                    int32_t* ci_tmp = nullptr;
-                    float* val_tmp = nullptr;
-                    int64_t nnz_s = nnz;
-                    if (p->max_degree > gespmm::kStagedMaxRow) {
-                        e = gespmm::device_split_long_rows(M, nnz, p->d_rowptr, p->d_colind, val_s, gespmm::kStagedMaxRow, &p->stg,
-                                                           &ci_tmp, &val_tmp, st);
-                        rp_s = p->stg.rowptr_s;
-                        ci_s = ci_tmp;
-                        val_s = val_tmp;
-                        nnz_s = p->stg.nnz_s;
-                    }
-                    if (e == hipSuccess && nnz_s > 0)
-                        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, gespmm::staged_block_rows(N), H,
-                                                         &p->stg, st);
-                    if (ci_tmp) (void)hipFree(ci_tmp);
-                    if (val_tmp) (void)hipFree(val_tmp);
-                    if (e == hipSuccess && !p->stg.ev) gespmm::free_staging(&p->stg);  // (nothing but hub rows)
-                    p->staging_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
-                    if (e == hipSuccess && p->stg.ev && !gespmm::keep_staged_tables(f, p->stg.staged_fraction))
-                        gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay
-                    lap("staging tables");
-                }
+            // ---- staged-rows kernel (choose_plan_kernel says when): the tables are built, and kept when enough entries find
+            //      their B row staged
+            if (e == hipSuccess && kd.build_staged) {
+                e = build_staging_tables(p, st);
+                if (e == hipSuccess && p->stg.ev && !gespmm::keep_staged_tables(f, p->stg.staged_fraction))
+                    gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay
+                lap("staging tables");
             }
             if (e != hipSuccess) {
                 free_device(p);
@@ -621,6 +628,7 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
                             p->variant == GESPMM_VARIANT_CRC_CWM8;
     // staged-rows kernel: its tables exist (the plan decided at creation), same width, sum reducer, 16-byte operands
     const bool staged = p->reordered && p->stg.ev && N == p->N && reduce == gespmm::kReduceSum && variant_v4 &&
+                        (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO || p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED) &&
                         (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     if (staged) {
@@ -663,6 +671,66 @@ int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N,
 
 int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, float empty_value, void* stream) {
     return plan_run(plan, B, C, N, gespmm::kReduceMax, empty_value, stream);
+}
+
+// Which kernel, MEASURED: the candidates of a clustered plan — batch-stream, segmented-stream and (at the plan's width) staged-rows —
+// run on the caller's operands, `reps` launches each between a pair of events; the fastest becomes the plan's kernel. Every
+// candidate produces the same bits, so C holds the product afterwards whatever wins. The static rules of plan_policy.cpp
+// stay the default; this is for callers that would rather pay a few launches than trust a threshold (the hold-out audit,
+// profiles/r04/holdout_audit.log, is where the rules and the measurement are compared).
+int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_t reps, void* stream) {
+    if (!p || N <= 0 || !B || !C) return GESPMM_EINVAL;
+    if (N != p->N) return GESPMM_EINVAL;  // the tables are made for one width
+    if (!p->reordered) return 0;          // a storage-order plan has one launch path
+    if (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO && !p->tuned) return 0;  // the caller's explicit choice stands
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GESPMM_EINVAL;
+    (void)hipGetLastError();
+    if (reps <= 0) reps = 3;
+    if (reps > 50) reps = 50;
+    hipError_t e = hipSuccess;
+    const bool v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 || p->variant == GESPMM_VARIANT_CRC_CWM8;
+    if (!p->stg.ev && p->analysis == GESPMM_PLAN_ANALYSIS_DEVICE && v4 && p->nnz > 0 && gespmm::staged_serves(p->K, p->N)) {
+        e = build_staging_tables(p, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return (int)e;
+    }
+    const int cand[3] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED};
+    int best = -1, rc = 0;
+    for (int c = 0; c < 3 && rc == 0; ++c) {
+        p->tune_us[c] = -1.0;
+        if (c == 1 && !p->d_gtasks) continue;
+        if (c == 2 && !(p->stg.ev && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && v4)) continue;
+        p->kernel_choice = p->facts.kernel_choice = cand[c];
+        rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // warm: code objects, split points, L2 state
+        if (rc == 0) rc = (int)hipEventRecord(e0, st);
+        for (int r = 0; r < reps && rc == 0; ++r) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
+        if (rc == 0) rc = (int)hipEventRecord(e1, st);
+        if (rc == 0) rc = (int)hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (rc == 0) rc = (int)hipEventElapsedTime(&ms, e0, e1);
+        if (rc != 0) break;
+        p->tune_us[c] = (double)ms * 1e3 / reps;
+        if (best < 0 || p->tune_us[c] < p->tune_us[best]) best = c;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != 0 || best < 0) {
+        p->kernel_choice = p->facts.kernel_choice = GESPMM_PLAN_KERNEL_AUTO;
+        return rc;
+    }
+    p->kernel_choice = p->facts.kernel_choice = cand[best];
+    p->tuned = true;
+    if (best != 2 && p->stg.ev) gespmm::free_staging(&p->stg);  // the tables are ~16 bytes per entry: not kept for a kernel that lost
+    if (best != 2) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // (C is the winner's product either way: same bits)
+    return rc;
 }
 
 // SDDMM on the plan's pattern: out[e] = <D1[row(e), :], D2[col(e), :]> for every edge e of the CALLER's CSR (out in the
@@ -782,11 +850,15 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
                      p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
+        char tuned[160] = "";
+        if (p->tuned)
+            snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f]", p->tune_us[0], p->tune_us[1],
+                     p->tune_us[2]);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "
-                     "analysis=%.4fs on the %s (clustering %.4fs) | %s",
+                     "analysis=%.4fs on the %s (clustering %.4fs)%s | %s",
                      p->stats.levels, lv, p->ntasks, p->task_entries, p->ngtasks, p->max_degree, p->hits_before, p->hits_after,
-                     p->analysis_seconds, p->analysis == GESPMM_PLAN_ANALYSIS_HOST ? "host" : "device", p->cluster_seconds, kern);
+                     p->analysis_seconds, p->analysis == GESPMM_PLAN_ANALYSIS_HOST ? "host" : "device", p->cluster_seconds, tuned, kern);
     } else {
         n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.3fs | %s",
                      p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, what);
@@ -796,6 +868,8 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
 }
 
 void gespmm_release_cached_memory(void) { gespmm::release_cached_arena(); }
+
+void gespmm_set_cached_memory_limit(int64_t bytes) { gespmm::set_arena_cache_limit((long long)bytes); }
 
 void gespmm_plan_destroy(gespmm_plan* p) {
     if (!p) return;

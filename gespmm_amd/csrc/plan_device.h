@@ -72,7 +72,9 @@ hipError_t device_staging_set_values(const StagingTables& t, const float* val_p,
                                      hipStream_t st);
 void free_staging(StagingTables* t);
 
-// Frees the analysis arena kept for the next plan (up to 1/16 of the device memory, at most 16 GiB; GESPMM_ARENA_CACHE_MB).
+// Frees the analysis arenas kept for the next plan (one per device, up to the limit below).
 void release_cached_arena();
+// Largest arena kept between plans, per device (default 1 GiB, or GESPMM_ARENA_CACHE_MB; negative: back to that default).
+void set_arena_cache_limit(long long bytes);
 
 }  // namespace gespmm

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -71,78 +72,113 @@ namespace {
 // passes. Blocks up to 1/16 of the device's memory (at most 16 GiB; GESPMM_ARENA_CACHE_MB) are kept for the next plan: a multi-GB
 // hipMalloc was seen to take SECONDS now and then — after another library returned memory to the driver, or for no visible reason
 // (profiles/r03/plan_repeat.log: the same 87 ms analysis took 1.9-3.6 s once in every few plans while its arena was a private block).
+// Round 4: one cache entry PER DEVICE, a default cap of 1 GiB (a products-sized arena is ~10 GB: invisible to
+// PyTorch's allocator, it must not stay behind by default — gespmm_set_cached_memory_limit / GESPMM_ARENA_CACHE_MB raise the
+// cap for callers that build large plans in a row), and no hipMalloc / hipFree while the lock is held.
+constexpr int kArenaDevices = 16;
+std::atomic<long long> g_arena_cap{-1};
 static size_t arena_cache_cap() {
-    static const size_t cap = []() -> size_t {
+    const long long set = g_arena_cap.load();
+    if (set >= 0) return (size_t)set;
+    static const size_t env_cap = []() -> size_t {
         if (getenv("GESPMM_ARENA_CACHE_MB")) return (size_t)atoll(getenv("GESPMM_ARENA_CACHE_MB")) << 20;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4096 << 20;
-        const size_t sixteenth = total_b / 16, top = (size_t)16384 << 20;
-        return sixteenth < top ? sixteenth : top;
+        return (size_t)1 << 30;
     }();
-    return cap;
+    return env_cap;
 }
 struct ArenaCache {
     std::mutex lock;
     void* block = nullptr;
     size_t bytes = 0;
-    int device = -1;
     bool busy = false;
 };
-ArenaCache g_arena;
+ArenaCache g_arena[kArenaDevices];
 
 hipError_t arena_acquire(size_t bytes, void** out, bool* cached) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    *cached = false;
+    if (dev < 0 || dev >= kArenaDevices) return hipMalloc(out, bytes);
+    ArenaCache& c = g_arena[dev];
+    void* stale = nullptr;
+    bool reserve = false;
     {
-        std::lock_guard<std::mutex> guard(g_arena.lock);
-        if (!g_arena.busy) {
-            if (g_arena.block && (g_arena.device != dev || g_arena.bytes < bytes)) {
-                (void)hipFree(g_arena.block);
-                g_arena.block = nullptr;
-                g_arena.bytes = 0;
-            }
-            if (!g_arena.block && bytes <= arena_cache_cap()) {
-                e = hipMalloc(&g_arena.block, bytes);
-                if (e != hipSuccess) {
-                    g_arena.block = nullptr;
-                    return e;
-                }
-                g_arena.bytes = bytes;
-                g_arena.device = dev;
-            }
-            if (g_arena.block) {
-                g_arena.busy = true;
-                *out = g_arena.block;
+        std::lock_guard<std::mutex> guard(c.lock);
+        if (!c.busy) {
+            if (c.block && c.bytes >= bytes) {
+                c.busy = true;
+                *out = c.block;
                 *cached = true;
                 return hipSuccess;
             }
+            stale = c.block;  // too small: replaced (or dropped) below, outside the lock
+            c.block = nullptr;
+            c.bytes = 0;
+            if (bytes <= arena_cache_cap()) c.busy = reserve = true;  // this thread fills the slot
         }
     }
-    *cached = false;  // larger than the cache keeps, or another thread is analysing: a private block
-    return hipMalloc(out, bytes);
+    if (stale) (void)hipFree(stale);
+    void* p = nullptr;
+    e = hipMalloc(&p, bytes);
+    if (reserve) {
+        std::lock_guard<std::mutex> guard(c.lock);
+        if (e == hipSuccess) {
+            c.block = p;
+            c.bytes = bytes;
+            *cached = true;
+        } else {
+            c.busy = false;
+        }
+    }
+    if (e == hipSuccess) *out = p;
+    return e;  // !reserve: larger than the cache keeps, or another thread is analysing on this device: a private block
 }
 
 }  // namespace
 
-// Drops the cached analysis arena (gespmm_release_cached_memory): the next plan allocates a new one.
+// Drops the cached analysis arenas (gespmm_release_cached_memory): the next plan allocates a new one.
 void release_cached_arena() {
-    std::lock_guard<std::mutex> guard(g_arena.lock);
-    if (!g_arena.busy && g_arena.block) {
-        (void)hipFree(g_arena.block);
-        g_arena.block = nullptr;
-        g_arena.bytes = 0;
+    for (int d = 0; d < kArenaDevices; ++d) {
+        void* stale = nullptr;
+        {
+            std::lock_guard<std::mutex> guard(g_arena[d].lock);
+            if (!g_arena[d].busy && g_arena[d].block) {
+                stale = g_arena[d].block;
+                g_arena[d].block = nullptr;
+                g_arena[d].bytes = 0;
+            }
+        }
+        if (stale) (void)hipFree(stale);
     }
 }
+
+void set_arena_cache_limit(long long bytes) { g_arena_cap.store(bytes < 0 ? -1 : bytes); }
 
 namespace {
 
 void arena_release(void* p, bool cached) {
-    if (cached) {
-        std::lock_guard<std::mutex> guard(g_arena.lock);
-        g_arena.busy = false;
-    } else {
+    if (!cached) {
         (void)hipFree(p);
+        return;
+    }
+    for (int d = 0; d < kArenaDevices; ++d) {
+        void* stale = nullptr;
+        bool mine = false;
+        {
+            std::lock_guard<std::mutex> guard(g_arena[d].lock);
+            if (g_arena[d].block == p) {
+                mine = true;
+                g_arena[d].busy = false;
+                if (g_arena[d].bytes > arena_cache_cap()) {  // the cap was lowered meanwhile
+                    stale = p;
+                    g_arena[d].block = nullptr;
+                    g_arena[d].bytes = 0;
+                }
+            }
+        }
+        if (stale) (void)hipFree(stale);
+        if (mine) return;
     }
 }
 

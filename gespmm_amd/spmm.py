@@ -134,9 +134,22 @@ class SpmmPlan:
             lib.gespmm_plan_destroy(h)
             self._handle = ctypes.c_void_p()
 
+    def tune(self, dense, out=None, reps=3):
+        """Kernel choice by measurement (gespmm_plan_tune): the plan's candidate kernels run ``reps`` times each on ``dense`` and the
+        fastest is kept; returns the product (same bits whichever wins). ``dense`` must have the plan's width."""
+        _need(dense, "dense", torch.float32, 2)
+        M, K, N, _, _ = self.shape
+        if tuple(dense.shape) != (K, N):
+            raise ValueError("tune() needs dense of shape (K, N) = (%d, %d)" % (K, N))
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        with _on_device(self.device):
+            check(lib.gespmm_plan_tune(self._handle, _ptr(dense), _ptr(out), N, int(reps), _stream(self.device)), "gespmm_plan_tune")
+        return out
+
     def describe(self):
-        buf = ctypes.create_string_buffer(1024)
-        n = lib.gespmm_plan_describe(self._handle, buf, 1024)
+        buf = ctypes.create_string_buffer(1400)
+        n = lib.gespmm_plan_describe(self._handle, buf, 1400)
         if n < 0:
             check(int(n), "gespmm_plan_describe")
         return buf.value.decode()

@@ -314,6 +314,14 @@ int gespmm_plan_create_v2(gespmm_plan** plan, const int32_t* rowptr, const int32
                           int64_t opt_bytes /* sizeof(gespmm_plan_options) in the caller */, void* stream);
 /* C[M x N] = A * B through the plan; any N is legal (scratch and task size are tuned for the plan's N). */
 int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, void* stream);
+/*
+ * Kernel choice by MEASUREMENT instead of by rule: runs the candidates of a clustered plan (batch-stream, segmented-stream,
+ * and staged-rows where the width is served) `reps` (0 = 3) times each on these operands, synchronously, and fixes the plan
+ * on the fastest; C holds the product afterwards (every candidate gives the same bits). N must be the plan's width. A no-op
+ * for storage-order plans and plans created with an explicit kernel. Not under stream capture. gespmm_plan_describe reports
+ * the measured times.
+ */
+int gespmm_plan_tune(gespmm_plan* plan, const float* B, float* C, int64_t N, int32_t reps, void* stream);
 /* max reducer (unweighted plans only), see gespmm_csr_spmm_max_f32 */
 int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, float empty_value, void* stream);
 /* SDDMM on the plan's pattern, out[nnz] in the caller's CSR edge order (same bits as gespmm_sddmm_csr_f32); a clustered
@@ -327,7 +335,11 @@ int gespmm_plan_get_order(const gespmm_plan* plan, int32_t* perm_host);
 /* One line of text: order, cluster hierarchy, tasks, modelled L2 hit rate before -> after, analysis time, launch. */
 int gespmm_plan_describe(const gespmm_plan* plan, char* out, int64_t capacity);
 void gespmm_plan_destroy(gespmm_plan* plan);
-/* The analysis stage keeps its scratch arena (<= 1/16 of the device memory and <= 16 GiB; GESPMM_ARENA_CACHE_MB changes the cap) for the next plan; this gives it back. */
+/* The analysis stage keeps its scratch arena for the next plan — one per device, up to a limit of 1 GiB by default
+ * (GESPMM_ARENA_CACHE_MB overrides the default; a products-sized analysis takes ~10 GB, freed when the plan is made unless the
+ * limit says otherwise). gespmm_set_cached_memory_limit changes the limit (bytes; negative = default), gespmm_release_cached_memory
+ * gives the kept arenas back. */
+void gespmm_set_cached_memory_limit(int64_t bytes);
 void gespmm_release_cached_memory(void);
 
 /*

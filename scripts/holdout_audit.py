@@ -109,6 +109,10 @@ def main():
             t_auto = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan), iters)
             same = torch.equal(C.view(torch.int32), ref.view(torch.int32))
             desc = plan.describe()
+            # the same plan after gespmm_plan_tune (kernel choice by measurement)
+            plan.tune(B, out=C, reps=3)
+            t_tuned = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan), iters)
+            same = same and torch.equal(C.view(torch.int32), ref.view(torch.int32))
             del plan
             alts = {}
             for order in (True, False):
@@ -138,8 +142,9 @@ def main():
             flag = "  <-- AUTO %.0f %% behind %s" % (100 * (ratio - 1), best_k if best_t < t_plain else "plain") if ratio > 1.05 else ""
             m = desc.split("l2_model=")[1].split(" ")[0] if "l2_model=" in desc else "-"
             kern = desc.split("|")[-1].strip().split(" (")[0][:70]
-            print("  N=%-3d plain %9.1f  AUTO %9.1f us (x%.2f, bits %s, analysis %.3fs, %s, l2_model %s, %s)%s" %
-                  (N, t_plain, t_auto, t_plain / t_auto, "same" if same else "REASSOC", dt, desc.split(" ")[0], m, kern, flag), flush=True)
+            print("  N=%-3d plain %9.1f  AUTO %9.1f  AUTO+tune %9.1f us (x%.2f, bits %s, analysis %.3fs, %s, l2_model %s, %s)%s" %
+                  (N, t_plain, t_auto, t_tuned, t_plain / t_auto, "same" if same else "REASSOC", dt, desc.split(" ")[0], m, kern, flag),
+                  flush=True)
             print("        " + "  ".join("%s %s%s" % (k, ("%.1f" % v[0]) if v[0] is not None else "n/a", (" " + v[1]) if v[1] else "")
                                          for k, v in alts.items()), flush=True)
             del B, C, ref

@@ -248,3 +248,50 @@ def test_kept_split_points_are_not_reused_across_operand_alignments(pkg, oracle)
     c = spmm.csr_spmm(rp, ci, val, B, plan=plan)            # aligned again
     for got in (a, b, c):
         assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+
+
+def test_tune_measures_the_candidates_and_keeps_the_bits(pkg, oracle, bundled):
+    """gespmm_plan_tune: the candidate kernels of a clustered plan are timed on the caller's operands and the fastest is kept;
+    whichever wins, the product has the oracle's bits; an explicit kernel choice is left alone; another width is refused."""
+    from gespmm_amd import _lib, spmm
+
+    g = bundled["pubmed"]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=7)
+    val = _dev(val_h)
+    for N in (128, 96, 512):
+        B_h = oracle.hash_B(g["K"], N, seed=N)
+        B = _dev(B_h)
+        ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
+        plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True)
+        got = plan.tune(B, reps=2).cpu().numpy()
+        d = plan.describe()
+        assert "tuned[us: batch-stream=" in d, d
+        times = [float(x.split("=")[1]) for x in d.split("tuned[us: ")[1].split("]")[0].split()]
+        assert times[0] > 0 and times[1] > 0 and (times[2] > 0) == (N in (128, 512)), d  # staged-rows only where the width is served
+        assert np.array_equal(bits(got), bits(ref)), (N, d)
+        again = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()  # launches after the tune: the kept kernel
+        assert np.array_equal(bits(again), bits(ref)), (N, d)
+        plan.tune(B)  # tuning twice is allowed (new measurement)
+        with pytest.raises(_lib.GespmmError):  # another width than the plan's
+            _lib.check(_lib.lib.gespmm_plan_tune(plan._handle, B.data_ptr(), B.data_ptr(), N + 4, 1, None), "gespmm_plan_tune")
+    explicit = spmm.SpmmPlan(rp, ci, g["K"], 128, values=val, reorder=True, kernel="seg-stream")
+    explicit.tune(_dev(oracle.hash_B(g["K"], 128, seed=1)))
+    assert "tuned[" not in explicit.describe()
+    storage = spmm.SpmmPlan(rp, ci, g["K"], 128, values=val, reorder=False)
+    storage.tune(_dev(oracle.hash_B(g["K"], 128, seed=1)))
+    assert "tuned[" not in storage.describe()
+
+
+def test_cached_memory_limit_and_release(pkg):
+    from gespmm_amd import _lib, graphs, spmm
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda", scale=0.25)
+    torch.cuda.synchronize()
+    for limit in (0, 1 << 30, -1):  # 0: nothing is kept between plans
+        _lib.set_cached_memory_limit(limit)
+        for _ in range(2):
+            plan = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 128)
+            assert plan.clustered
+            del plan
+        _lib.release_cached_memory()
