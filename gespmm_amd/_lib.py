@@ -109,7 +109,7 @@ class PlanPolicyQuery(Structure):
 class PlanPolicyAnswer(Structure):
     _fields_ = [(n, c_int32) for n in ("launch_flags", "analyse", "dense_try", "keep_clustered", "task_entries",
                                        "group_task_entries", "row_floor", "build_staged", "keep_staged", "shallow_unroll",
-                                       "segmented", "sddmm_route")] + [("model_window", c_int64), ("model_sample", c_int64)]
+                                       "segmented", "sddmm_route", "narrow_vec4")] + [("model_window", c_int64), ("model_sample", c_int64)]
 
 
 class Coo(Structure):

@@ -79,7 +79,8 @@ struct gespmm_plan {
     double staging_seconds = 0.0;
     // gespmm_plan_tune: measured kernel times on the caller's operands (us; < 0: candidate not available)
     bool tuned = false;
-    double tune_us[3] = {-1.0, -1.0, -1.0};  // batch-stream, segmented-stream, staged-rows
+    double tune_us[4] = {-1.0, -1.0, -1.0, -1.0};  // batch-stream, segmented-stream, staged-rows, batch-stream with 4 floats per lane (N <= 64)
+    int narrow_vec = -1;  // -1: plan_policy decides per launch; 0 / 1: fixed by gespmm_plan_tune
 };
 
 namespace {
@@ -649,11 +650,12 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         return rc;
     }
     if (p->reordered) {
-        // (which streaming kernel: prefer_segmented, plan_policy.cpp)
+        // (which streaming kernel: prefer_segmented; which lane geometry at narrow widths: narrow_vec4 — plan_policy.cpp)
         const bool seg = gespmm::prefer_segmented(p->facts, p->hits_after, N);
-        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg};
+        const bool vec4 = p->narrow_vec >= 0 ? (p->narrow_vec == 1 && N == p->N) : gespmm::narrow_vec4(p->facts, p->hits_after, N);
+        gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg && !vec4};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
-                              p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
+                              vec4 ? GESPMM_VARIANT_CRC_CWM4 : p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
     } else {
         rc = gespmm::run_spmm(p->rowptr, p->colind, p->valued ? p->val : nullptr, B, C, p->M, p->K, N, p->nnz, p->variant,
                               &cfg, reduce, empty, stream, ws, ws_bytes, nullptr);
@@ -702,13 +704,15 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
         if (e0) (void)hipEventDestroy(e0);
         return (int)e;
     }
-    const int cand[3] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED};
+    const int cand[4] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STREAM};
     int best = -1, rc = 0;
-    for (int c = 0; c < 3 && rc == 0; ++c) {
+    for (int c = 0; c < 4 && rc == 0; ++c) {
         p->tune_us[c] = -1.0;
         if (c == 1 && !p->d_gtasks) continue;
         if (c == 2 && !(p->stg.ev && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && v4)) continue;
+        if (c == 3 && !(p->variant == GESPMM_VARIANT_AUTO && N <= 64 && N % 4 == 0)) continue;
         p->kernel_choice = p->facts.kernel_choice = cand[c];
+        p->narrow_vec = c == 3 ? 1 : 0;
         rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // warm: code objects, split points, L2 state
         if (rc == 0) rc = (int)hipEventRecord(e0, st);
         for (int r = 0; r < reps && rc == 0; ++r) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
@@ -724,9 +728,11 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     (void)hipEventDestroy(e1);
     if (rc != 0 || best < 0) {
         p->kernel_choice = p->facts.kernel_choice = GESPMM_PLAN_KERNEL_AUTO;
+        p->narrow_vec = -1;
         return rc;
     }
     p->kernel_choice = p->facts.kernel_choice = cand[best];
+    p->narrow_vec = best == 3 ? 1 : 0;
     p->tuned = true;
     if (best != 2 && p->stg.ev) gespmm::free_staging(&p->stg);  // the tables are ~16 bytes per entry: not kept for a kernel that lost
     if (best != 2) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // (C is the winner's product either way: same bits)
@@ -836,9 +842,10 @@ int gespmm_plan_get_order(const gespmm_plan* p, int32_t* perm_host) {
 int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
     if (!p || !out || capacity <= 0) return GESPMM_EINVAL;
     char what[256] = "";
-    const bool seg = p->reordered && p->d_gtasks && gespmm::prefer_segmented(p->facts, p->hits_after, p->N);
+    const bool vec4d = p->reordered && (p->narrow_vec >= 0 ? p->narrow_vec == 1 : gespmm::narrow_vec4(p->facts, p->hits_after, p->N));
+    const bool seg = p->reordered && p->d_gtasks && !vec4d && gespmm::prefer_segmented(p->facts, p->hits_after, p->N);
     gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags | (p->reordered ? ((seg ? GESPMM_FLAG_SEG_STREAM : GESPMM_FLAG_BATCH_STREAM) | GESPMM_FLAG_NO_SLAB_BLOCKED) : 0)};
-    gespmm_describe_launch(p->M, p->K, p->N, p->nnz, p->variant, &cfg, what, sizeof what);
+    gespmm_describe_launch(p->M, p->K, p->N, p->nnz, vec4d ? GESPMM_VARIANT_CRC_CWM4 : p->variant, &cfg, what, sizeof what);
     int n;
     if (p->reordered) {
         char lv[128] = "";
@@ -850,10 +857,10 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
                      p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
-        char tuned[160] = "";
+        char tuned[200] = "";
         if (p->tuned)
-            snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f]", p->tune_us[0], p->tune_us[1],
-                     p->tune_us[2]);
+            snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f batch-stream-V4=%.1f]", p->tune_us[0],
+                     p->tune_us[1], p->tune_us[2], p->tune_us[3]);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "
                      "analysis=%.4fs on the %s (clustering %.4fs)%s | %s",

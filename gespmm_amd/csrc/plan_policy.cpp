@@ -149,6 +149,16 @@ bool prefer_segmented(const PlanFacts& f, double hits_after, int64_t N) {
     return false;
 }
 
+// N <= 64: select.cpp gives every column its own lane (V = 1: 32 lanes per row at N = 32, two rows per gather instruction) — right
+// for every graph measured with rows of 10+ entries (LFR N = 32: 78 vs 110 us with V = 4; products-shaped: 327 vs 365) and for
+// miss-bound short rows (structureless com-Amazon stand-in: 48.6 vs 53.1). Short rows that HIT L2 are bound by the number of
+// gather instructions instead: V = 4 carries 8 rows per instruction — com-Amazon-shaped communities, mean degree 5.5: 37.1 vs
+// 44.6 us at N = 32, 49.6 vs 62.5 at N = 64 (profiles/r04/narrow_vec_rule.log). Same condition as the shallow unroll above.
+bool narrow_vec4(const PlanFacts& f, double hits_after, int64_t N) {
+    return f.variant == GESPMM_VARIANT_AUTO && N <= 64 && N >= 16 && N % 4 == 0 && hits_after >= 0.40 && f.mean_ceil() <= 8 &&
+           f.nnz >= (1 << 20);
+}
+
 // The clustered edge walk pays a scatter pass at the end: worth it where the order is modelled to hit L2 for >= 40 % of the
 // gathers and the rows are >= 256 bytes (com-Amazon-shaped communities, N = 128: 114 vs 151 us COO / 167 us CSR; on the
 // structureless graph or at N = 41 it is equal or slower — profiles/r02/sddmm_plan.log). Otherwise short rows take the COO
@@ -201,6 +211,7 @@ extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan
     a->keep_staged = a->build_staged && gespmm::keep_staged_tables(f, q->staged_fraction);
     a->shallow_unroll = keep && kd.shallow_unroll;
     a->segmented = keep && !a->keep_staged && gespmm::prefer_segmented(f, q->hits_after, Nl);
+    a->narrow_vec4 = keep && gespmm::narrow_vec4(f, q->hits_after, Nl);
     a->sddmm_route = gespmm::sddmm_route(f, keep, q->hits_after, Nl);
     a->model_window = ad.model_window;
     a->model_sample = ad.model_sample;

@@ -61,6 +61,10 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction);
 // ---- per launch (width N_launch may differ from the plan's): segmented-stream instead of batch-stream?
 bool prefer_segmented(const PlanFacts& f, double hits_after, int64_t N_launch);
 
+// ---- per launch at N_launch <= 64: four floats per lane (8 lanes per 32 columns = 8 rows per gather instruction) instead of the
+//      one-lane-per-column geometry AUTO takes at narrow widths
+bool narrow_vec4(const PlanFacts& f, double hits_after, int64_t N_launch);
+
 // ---- SDDMM through the plan: 0 = CSR form on the caller's arrays, 1 = COO form on expanded row ids (storage order),
 //      2 = the plan's clustered edge order + scatter
 int sddmm_route(const PlanFacts& f, bool reordered, double hits_after, int64_t N_launch);

@@ -316,7 +316,7 @@ int gespmm_plan_create_v2(gespmm_plan** plan, const int32_t* rowptr, const int32
 int gespmm_plan_spmm_f32(gespmm_plan* plan, const float* B, float* C, int64_t N, void* stream);
 /*
  * Kernel choice by MEASUREMENT instead of by rule: runs the candidates of a clustered plan (batch-stream, segmented-stream,
- * and staged-rows where the width is served) `reps` (0 = 3) times each on these operands, synchronously, and fixes the plan
+ * staged-rows where the width is served, and at N <= 64 the batch-stream kernel with 4 floats per lane) `reps` (0 = 3) times each on these operands, synchronously, and fixes the plan
  * on the fastest; C holds the product afterwards (every candidate gives the same bits). N must be the plan's width. A no-op
  * for storage-order plans and plans created with an explicit kernel. Not under stream capture. gespmm_plan_describe reports
  * the measured times.
@@ -395,6 +395,7 @@ typedef struct gespmm_plan_policy_answer {
     int32_t shallow_unroll;
     int32_t segmented;         /* the streaming launch at N_launch takes the segmented-stream kernel */
     int32_t sddmm_route;       /* 0 CSR call, 1 COO on expanded row ids, 2 clustered edge order + scatter */
+    int32_t narrow_vec4;       /* the launch at N_launch <= 64 takes 4 floats per lane (variant 3) instead of 1 */
     int64_t model_window, model_sample;
 } gespmm_plan_policy_answer;
 int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);

@@ -7,15 +7,16 @@
  * Every function cites the reference lines it follows (paths relative to
  * hgyhungry/ge-spmm). The restatement is deliberately the slow, literal form.
  *
- * Pinning status (see DESIGN.md "Oracle"):
- *   - loader:  pinned against the reference's own recorded data — the nnz that
- *     matrix_id_info.xlsx implies for cora/citeseer/pubmed (time x throughput =
- *     2*nnz*N) and the M/nnz/first/last/max-degree facts SURVEY.md §8(c2)
- *     obtained from the unmodified reference loader (tests/golden/known_answers.json).
- *   - SpMM / SDDMM arithmetic: the reference ships NO golden vectors and its only
- *     check (spmm_test.cu:671-698) is compiled out and needs CUDA; the CUDA sources
- *     cannot be built here (no nvcc/cuSPARSE). PARITY UNPINNED against reference
- *     outputs; the restatement is cross-checked against scipy (float64) instead.
+ * Pinning status: PINNED to the reference itself since round 3.
+ *   - host side: oracle/make_ref.sh compiles the reference's own lines from /root/reference where they lie (loader
+ *     util.hpp / mmio.hpp, COO->CSR spmm_test.cu:557-581, B init 586-594, CPU golden loop 595-605) into
+ *     oracle/_ref/libref_host.so; tests/test_ref_pin.py holds this file to it bit for bit (3 bundled graphs,
+ *     hand-made edge fixtures, seeded random files; valued and unweighted, 4 widths + edge shapes);
+ *   - device arithmetic: the reference's CUDA kernels (spmm_test0..4, the torch-op kernels) compiled by hipcc for
+ *     gfx950 into oracle/_ref/libref_kernels.so; tests/test_gpu_ref_kernels.py holds the `fma` mode below — and the
+ *     product — to their output on the same MI355X bit for bit (13 widths, all methods);
+ *   - SDDMM: the reference's sddmm.cu does not compile as shipped (sddmm.cpp:65) — tolerance class, restated from
+ *     the kernels; cross-checked against float64.
  */
 #include <math.h>
 #include <stdint.h>

@@ -69,6 +69,7 @@ if [ -x "$HIPCC" ]; then
     "$HIPCC" $HIPFLAGS -c "$HERE/ref_kernels_torch.hip" -o "$TMP/k_torch.o"
     "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_kernels.so" "$TMP/k_test.o" "$TMP/k_torch.o"
     echo "built oracle/_ref/libref_kernels.so (reference CUDA kernels, hipcc gfx950) from $REF"
+    date -u +"built %Y-%m-%dT%H:%M:%SZ from $REF" > "$OUT/built.stamp"  # tests/test_gpu_ref_kernels.py: present => the libraries must load
 else
     echo "hipcc not found: oracle/_ref/libref_kernels.so not rebuilt"
 fi

@@ -259,7 +259,7 @@ def test_tune_measures_the_candidates_and_keeps_the_bits(pkg, oracle, bundled):
     rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
     val_h = oracle.hash_val(g["nnz"], seed=7)
     val = _dev(val_h)
-    for N in (128, 96, 512):
+    for N in (128, 96, 512, 32):
         B_h = oracle.hash_B(g["K"], N, seed=N)
         B = _dev(B_h)
         ref = oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")
@@ -268,7 +268,9 @@ def test_tune_measures_the_candidates_and_keeps_the_bits(pkg, oracle, bundled):
         d = plan.describe()
         assert "tuned[us: batch-stream=" in d, d
         times = [float(x.split("=")[1]) for x in d.split("tuned[us: ")[1].split("]")[0].split()]
-        assert times[0] > 0 and times[1] > 0 and (times[2] > 0) == (N in (128, 512)), d  # staged-rows only where the width is served
+        assert len(times) == 4 and times[0] > 0 and times[1] > 0, d
+        assert (times[2] > 0) == (N in (128, 512)), d  # staged-rows only where the width is served
+        assert (times[3] > 0) == (N == 32), d          # 4 floats per lane is a candidate at N <= 64
         assert np.array_equal(bits(got), bits(ref)), (N, d)
         again = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()  # launches after the tune: the kept kernel
         assert np.array_equal(bits(again), bits(ref)), (N, d)

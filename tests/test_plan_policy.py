@@ -12,11 +12,13 @@ TABLE = [
     # ---- BASELINE configs (the stand-ins' measured analysis numbers)
     ("C2a com-amazon-sbm N=128", (334863, 1851744, 128, 120, 0.018, 0.651, 0.0),
      dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=40, group_task_entries=16, build_staged=0, shallow_unroll=1,
-          segmented=0, launch_flags=STRICT, sddmm_route=2)),
+          segmented=0, launch_flags=STRICT, sddmm_route=2, narrow_vec4=0)),
     ("C2a com-amazon-like N=128", (334863, 1851744, 128, 499, 0.025, 0.176, 0.0),
      dict(analyse=1, keep_clustered=1, task_entries=40, build_staged=0, shallow_unroll=0, segmented=0, sddmm_route=1)),
     ("C2a com-amazon-sbm N=32", (334863, 1851744, 32, 120, 0.09, 0.70, 0.0),
-     dict(analyse=1, keep_clustered=1, task_entries=96, shallow_unroll=1, segmented=0)),
+     dict(analyse=1, keep_clustered=1, task_entries=96, shallow_unroll=1, segmented=0, narrow_vec4=1)),  # 37.1 vs 44.6 us
+    ("C2a com-amazon-like N=32 (misses: one lane per column)", (334863, 1851744, 32, 499, 0.092, 0.222, 0.0), dict(keep_clustered=1, narrow_vec4=0)),
+    ("LFR mu=0.1 N=32 (rows of 16: one lane per column)", (300000, 4717400, 32, 306, 0.144, 0.786, 0.0), dict(keep_clustered=1, narrow_vec4=0, segmented=0)),
     ("C2a com-amazon-sbm N=512", (334863, 1851744, 512, 120, 0.01, 0.60, 0.0),
      dict(analyse=1, keep_clustered=1, task_entries=32, shallow_unroll=0, build_staged=1)),  # 256-column tiles since round 4
     ("C2a id-local storage order", (334863, 1851744, 128, 499, 0.60, 0.62, 0.0), dict(analyse=1, keep_clustered=0, segmented=0)),
