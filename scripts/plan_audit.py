@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """AUTO plans against the plain call on a grid of graphs and widths: does the analysis stage ever lose?
-    python scripts/plan_audit.py"""
+    python scripts/plan_audit.py [--baseline profiles/r03/plan_audit.log]
+
+With --baseline every (graph, N) is also compared with the same line of an earlier log: the measure is plan / plain of the SAME
+run (boxes differ by a few per cent in absolute time, the plain call is the yardstick that travels); a line whose ratio is more
+than 3 % worse than the baseline's is marked REGRESSION and the script exits 1 (the structureless stand-in's plan
+lost 5 % between rounds 2 and 3 and nobody noticed because the headline had moved to another graph)."""
 import os
+import re
 import sys
 import time
 
@@ -13,6 +19,15 @@ import gespmm_amd  # noqa: F401,E402
 from gespmm_amd import graphs, spmm  # noqa: E402
 
 dev = torch.device("cuda")
+
+BASE = {}
+if "--baseline" in sys.argv:
+    with open(sys.argv[sys.argv.index("--baseline") + 1]) as fh:
+        for ln in fh:
+            m = re.match(r"(.+?)\s+N=(\d+)\s+plain\s+([0-9.]+) us\s+plan\s+([0-9.]+) us", ln)
+            if m:
+                BASE[(m.group(1).strip(), int(m.group(2)))] = float(m.group(4)) / float(m.group(3))
+REGRESSIONS = []
 
 
 def timeit(fn, iters):
@@ -78,9 +93,16 @@ for name, g in cases():
             kern += " (streaming kernels of the same plan: %.1f us, x%.2f)" % (best, best / t_plan)
             if t_plan > 1.03 * best:
                 flag += "  <-- staged loses"
+        prev = BASE.get((name, N))
+        if prev is not None and nnz >= (1 << 20) and t_plan / t_plain > 1.03 * prev:  # (small graphs: launch-latency noise)
+            flag += "  <-- REGRESSION: plan/plain %.3f, baseline %.3f" % (t_plan / t_plain, prev)
+            REGRESSIONS.append((name, N))
         print("%-46s N=%-3d plain %9.1f us  plan %9.1f us  x%.2f  bits=%s  analysis %.2fs  %s %s%s" %
               (name, N, t_plain, t_plan, t_plain / t_plan, "same" if same else "LONG-ROW-REASSOC", dt,
                plan.describe().split(" ")[0], kern, flag), flush=True)
         del plan, B, C, ref
     del g
     torch.cuda.empty_cache()
+if BASE:
+    print("# against the baseline log: %d line(s) compared, %d regression(s) %s" % (len(BASE), len(REGRESSIONS), REGRESSIONS or ""))
+    sys.exit(1 if REGRESSIONS else 0)
