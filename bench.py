@@ -98,11 +98,11 @@ def compact_line(full):
     else:
         out["cpu_baseline"] = None
     for k in ("verified_vs_oracle", "plan_ms", "plan_ms_first_creation", "value_incl_plan_over_200_launches", "series", "widths",
-              "reference_kernel", "exchange", "one_gpu_reference", "extra_file"):
+              "reference_kernel", "other_configs", "exchange", "one_gpu_reference", "extra_file"):
         if full.get(k) is not None:
             out[k] = _r(full[k])
     line = json.dumps(out, separators=(",", ":"))
-    for drop in ("widths", "reference_kernel", "one_gpu_reference", "exchange", "series"):  # never reached by today's fields: a guard
+    for drop in ("other_configs", "widths", "reference_kernel", "one_gpu_reference", "exchange", "series"):  # never reached by today's fields: a guard
         if len(line) < LINE_LIMIT:
             break
         out.pop(drop, None)
@@ -392,6 +392,14 @@ def main():
         extra["plain_call_N%d_valued" % N] = {"kernel_us": med, "gflops": 2.0 * nnz * N / med / 1e3,
                                               "frac": abytes / med / 1e3 / HBM_PEAK_GBS, "traffic": t2, "l2_hit_rate": h2}
         widths["N%d_plain_call" % N] = {"kernel_us": med, "frac": abytes / med / 1e3 / HBM_PEAK_GBS}
+        if plan is not None:  # the same plan after gespmm_plan_tune (kernel choice by measurement instead of by rule)
+            t0 = time.perf_counter()
+            plan.tune(B, out=C, reps=3)
+            torch.cuda.synchronize()
+            tune_ms = (time.perf_counter() - t0) * 1e3
+            medt = statistics.median(kernel_times_us(step, MIN_KERNEL_SAMPLES))
+            extra["headline_plan_after_tune"] = {"kernel_us": medt, "frac": abytes / medt / 1e3 / HBM_PEAK_GBS, "tune_ms": tune_ms,
+                                                 "plan": plan.describe()}
         del B, C, plan
         for n2 in (32, 512):
             for valued in (True, False):
@@ -465,25 +473,27 @@ def main():
                 plan3 = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], 128, values=val3)
                 torch.cuda.synchronize()
                 sweep = {"plan_ms": (time.perf_counter() - t0) * 1e3, "plan": plan3.describe()}
-                # (the staged-rows kernel's tables are made for ONE width: N = 256 gets a plan of its own)
-                tw = []
-                for _ in range(2):
-                    plan3w = None
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    plan3w = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], 256, values=val3)
-                    torch.cuda.synchronize()
-                    tw.append((time.perf_counter() - t0) * 1e3)
-                sweep["plan_N256_ms"] = min(tw)
-                sweep["plan_N256_ms_each"] = tw
-                sweep["plan_N256"] = plan3w.describe()
+                # (the staged-rows kernel's tables are made for ONE width: N = 256 and N = 512 get plans of their own)
+                wide = {}
+                for nw in (256, 512):
+                    tw = []
+                    for _ in range(2):
+                        wide[nw] = None
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        wide[nw] = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], nw, values=val3)
+                        torch.cuda.synchronize()
+                        tw.append((time.perf_counter() - t0) * 1e3)
+                    sweep["plan_N%d_ms" % nw] = min(tw)
+                    sweep["plan_N%d_ms_each" % nw] = tw
+                    sweep["plan_N%d" % nw] = wide[nw].describe()
                 for n3 in (16, 32, 64, 128, 256, 512):
                     torch.cuda.empty_cache()
                     B3 = make_B(g3["K"], n3)
                     C3 = torch.empty((g3["M"], n3), dtype=torch.float32, device=dev)
                     ab3 = algorithmic_bytes(g3["M"], g3["K"], n3, g3["nnz"], True)
                     row = {"roof_gflops": roof_gflops(g3["M"], g3["K"], n3, g3["nnz"], True)}
-                    for label, pl in (("plain", None), ("plan", plan3w if n3 == 256 else plan3)):
+                    for label, pl in (("plain", None), ("plan", wide.get(n3, plan3))):
                         def st3():
                             spmm.csr_spmm(g3["rowptr"], g3["colind"], val3, B3, variant=args.variant, out=C3, plan=pl)
                         for _ in range(2):
@@ -491,15 +501,15 @@ def main():
                         med3 = statistics.median(kernel_times_us(st3, 10))
                         row[label] = {"kernel_us": med3, "gflops": 2.0 * g3["nnz"] * n3 / med3 / 1e3,
                                       "achieved_GBs": ab3 / med3 / 1e3, "frac": ab3 / med3 / 1e3 / HBM_PEAK_GBS}
-                    if pname == "products-sbm" and n3 == 128:  # counters of this launch: scripts/gpu_profile_r03b.sh
-                        tb, tsrc, thit = traffic_for("products-sbm/N128/valued/plan")
+                    if pname == "products-sbm" and n3 in (128, 512):  # counters of this launch: scripts/gpu_profile_r04.sh
+                        tb, tsrc, thit = traffic_for("products-sbm/N%d/valued/plan" % n3)
                         row["plan"].update({"traffic": tb, "traffic_source": tsrc, "l2_hit_rate": thit,
                                             "traffic_GBs": (tb / row["plan"]["kernel_us"] / 1e3) if tb else None,
                                             "algorithmic_bytes_per_launch": ab3})
                     sweep["N%d" % n3] = row
                     del B3, C3
                 extra["%s_sweep_valued" % pname] = sweep
-                del g3, val3, plan3, plan3w
+                del g3, val3, plan3, wide
 
             # ---- BASELINE configs[0] and [3]: the small graphs (launch-latency territory), unweighted as the reference's driver and
             #      its GCN run them; plain call and plan
@@ -657,6 +667,7 @@ def main():
             "series": {k: {kk: _r(vv) for kk, vv in v.items()} for k, v in series.items()} or None,
             "widths": {k: {kk: _r(vv) for kk, vv in v.items()} for k, v in widths.items()} or None,
             "reference_kernel": {kk: _r(vv) for kk, vv in reference_kernel.items()} if reference_kernel else None,
+            "other_configs": other_configs(extra) or None,
             "extra": extra,
         }
         out["roofline"].update(ceiling_for(g, N, head["frac"]))
@@ -665,6 +676,24 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs(extra):
+    """BASELINE configs 1-5 beside the headline, one number each (kernel time through the library's own choice, frac of the
+    HBM roofline); everything else about them is in the side file."""
+    out = {}
+
+    def put(name, e):
+        if isinstance(e, dict) and "kernel_us" in e:
+            out[name] = {"ms": _r(e["kernel_us"] / 1e3, 2), "frac": _r(e.get("frac"), 2)}
+
+    for k, e in extra.items():
+        if k.startswith(("reddit-", "cit-hepth", "pubmed", "rmat-")):
+            put(k.replace("_valued", "").replace("_unweighted", ""), e)
+        if k.endswith("_sweep_valued"):
+            out[k.replace("_sweep_valued", "_plan_ms")] = {w: _r(r["plan"]["kernel_us"] / 1e3, 2) for w, r in e.items()
+                                                          if isinstance(r, dict) and "plan" in r and isinstance(r["plan"], dict)}
+    return out
 
 
 def csrc_fingerprint():

@@ -65,6 +65,8 @@ def test_final_line_stays_small_and_complete(log):
     full["reference_kernel"] = {"what": "x" * 60, "kernel_us": 276.123456, "gflops": 1715.123456, "product_bits_equal": True}
     full["roofline"].update({"ceiling_frac": 0.531234567, "achieved_over_ceiling": 0.851234567, "traffic_floor": 474000000,
                              "ceiling_note": "y" * 200, "launches": 200})
+    if "extra" in full:
+        full["other_configs"] = bench.other_configs(full["extra"])
     full["extra_file"] = bench.EXTRA_FILE
     line = bench.compact_line(full)
     assert len(line) < bench.LINE_LIMIT == 4096 and "\n" not in line
