@@ -22,7 +22,7 @@ python scripts/update_traffic_json.py \
   com-amazon-sbm/N32/valued/plan=gpurun_out/pmc_bench_sbm_plan_N32/summary.csv com-amazon-sbm/N512/valued/plan=gpurun_out/pmc_bench_sbm_plan_N512/summary.csv \
   products-sbm/N128/valued/plan=gpurun_out/pmc_products_sbm_staged/summary.csv products-sbm/N512/valued/plan=gpurun_out/pmc_products_sbm_staged_N512/summary.csv \
   > gpurun_out/r04/update_traffic.log 2>&1
-cp profiles/hbm_traffic.json gpurun_out/r04/hbm_traffic.json
+sed -i "s#gpurun_out/pmc_#profiles/r04/pmc_#g" profiles/hbm_traffic.json; cp profiles/hbm_traffic.json gpurun_out/r04/hbm_traffic.json
 for t in bench_sbm_plan bench_sbm_plain bench_like_plan bench_like_plain bench_sbm_plan_N32 bench_sbm_plan_N512 products_sbm_staged products_sbm_staged_N512; do
   echo "== $t"; grep -E "FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum|TCC_MISS_sum|TCC_EA0_RDREQ_sum" gpurun_out/pmc_$t/summary.csv | cut -d, -f1,6- | cut -c1-200; grep -E "spmm_" gpurun_out/pmc_$t/kernel_stats.csv | cut -c1-200; done
 P=/tmp/prof_bench; rm -rf $P; mkdir -p $P

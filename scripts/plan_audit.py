@@ -4,7 +4,7 @@
 
 With --baseline every (graph, N) is also compared with the same line of an earlier log: the measure is plan / plain of the SAME
 run (boxes differ by a few per cent in absolute time, the plain call is the yardstick that travels); a line whose ratio is more
-than 3 % worse than the baseline's is marked REGRESSION and the script exits 1 (the structureless stand-in's plan
+than 3 % worse than the baseline's AND whose plan time is more than 2 % worse is marked REGRESSION and the script exits 1 (the structureless stand-in's plan
 lost 5 % between rounds 2 and 3 and nobody noticed because the headline had moved to another graph)."""
 import os
 import re
@@ -26,7 +26,7 @@ if "--baseline" in sys.argv:
         for ln in fh:
             m = re.match(r"(.+?)\s+N=(\d+)\s+plain\s+([0-9.]+) us\s+plan\s+([0-9.]+) us", ln)
             if m:
-                BASE[(m.group(1).strip(), int(m.group(2)))] = float(m.group(4)) / float(m.group(3))
+                BASE[(m.group(1).strip(), int(m.group(2)))] = (float(m.group(4)) / float(m.group(3)), float(m.group(4)))
 REGRESSIONS = []
 
 
@@ -94,8 +94,10 @@ for name, g in cases():
             if t_plan > 1.03 * best:
                 flag += "  <-- staged loses"
         prev = BASE.get((name, N))
-        if prev is not None and nnz >= (1 << 20) and t_plan / t_plain > 1.03 * prev:  # (small graphs: launch-latency noise)
-            flag += "  <-- REGRESSION: plan/plain %.3f, baseline %.3f" % (t_plan / t_plain, prev)
+        # both measures must be worse: the ratio (robust against a slower box) and the plan's own time (robust against a noisy plain
+        # figure in either log); small graphs are launch-latency noise
+        if prev is not None and nnz >= (1 << 20) and t_plan / t_plain > 1.03 * prev[0] and t_plan > 1.02 * prev[1]:
+            flag += "  <-- REGRESSION: plan/plain %.3f (%.1f us), baseline %.3f (%.1f us)" % (t_plan / t_plain, t_plan, prev[0], prev[1])
             REGRESSIONS.append((name, N))
         print("%-46s N=%-3d plain %9.1f us  plan %9.1f us  x%.2f  bits=%s  analysis %.2fs  %s %s%s" %
               (name, N, t_plain, t_plan, t_plain / t_plan, "same" if same else "LONG-ROW-REASSOC", dt,
