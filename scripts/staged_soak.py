@@ -1,5 +1,6 @@
 """Soak of the staged-rows kernel: seeded random matrices (square / rectangular, local + far columns, empty rows, repeats, rows up to the 2048-entry
-limit) through a forced staged plan against the plain call's strict-order bits, valued and unweighted, N = 128 and 256.
+limit) through a forced staged plan against the plain call's strict-order bits, valued and unweighted, N = 128, 256 and (round 4: 256-column
+tiles) 512 / 1024; every fifth seed also runs gespmm_plan_tune on an AUTO plan at N = 32 / 64 / 128 (any candidate may win: same bits).
     python scripts/staged_soak.py [first_seed] [count]"""
 import sys, time
 import numpy as np
@@ -30,7 +31,7 @@ for seed in range(first, first + count):
         continue
     rp, ci = torch.from_numpy(rowptr).cuda(), torch.from_numpy(colind).cuda()
     val = torch.from_numpy((rng.rand(colind.size).astype(np.float32) - 0.5)).cuda()
-    for N in (128, 256):
+    for N in (128, 256, 512) + ((1024,) if seed % 7 == 0 else ()):
         B = torch.from_numpy((rng.rand(K, N).astype(np.float32) - 0.5)).cuda()
         plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x100)
         staged += "kernel=staged-rows" in plan.describe()
@@ -42,5 +43,16 @@ for seed in range(first, first + count):
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("unweighted", seed, M, K, N, max_deg, plan.describe())
         checked += 2
         del plan
+    if seed % 5 == 0:
+        for N in (32, 64, 128):
+            B = torch.from_numpy((rng.rand(K, N).astype(np.float32) - 0.5)).cuda()
+            plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, flags=0x100)
+            want = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x100})
+            got = plan.tune(B, reps=1)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("tune", seed, M, K, N, plan.describe())
+            got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("after tune", seed, M, K, N, plan.describe())
+            checked += 2
+            del plan
 print("staged soak: seeds %d..%d, %d products compared bit for bit (%d plans on the staged-rows kernel), %.0f s: all equal"
       % (first, first + count - 1, checked, staged, time.time() - t0))

@@ -233,3 +233,57 @@ def test_dense_graphs_are_clustered_only_with_strong_communities(pkg, oracle):
     got = spmm.csr_spmm_no_edge_value(g["rowptr"], g["colind"], B, plan=plan)
     plain = spmm.csr_spmm_no_edge_value(g["rowptr"], g["colind"], B, cfg={"flags": 0x100})
     assert torch.equal(got.view(torch.int32), plain.view(torch.int32))
+
+
+def test_b_beyond_4gb_takes_the_two_halves_base(pkg, oracle):
+    """N = 512 with K * N * 4 between 4 and 8 GB (products-shaped: 5.0 GB): the lane's 32-bit offset wraps modulo 4 GB and the base
+    pointer is chosen between B and B + 4 GB by a bit of the scalar code. Columns on both sides of the boundary, and within a row of
+    it; staged and gathered entries on both sides; bits = the plain call's strict-order bits."""
+    from gespmm_amd import spmm
+
+    N = 512
+    K = 2_300_000  # 4.71 GB of B; the 4 GB boundary is at row 2 097 152
+    M = 40_000
+    boundary = (1 << 32) // (N * 4)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * (1 << 30):
+        pytest.skip("needs ~6 GB of device memory")
+    rng = np.random.RandomState(5)
+    degs = rng.randint(4, 40, size=M)
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    rows = np.repeat(np.arange(M), degs)
+    # three kinds of columns: a window that follows the row (reused inside a block: staged), spread over BOTH halves; uniform over K;
+    # and the rows right at the boundary
+    near = (boundary - 20_000 + rows + rng.randint(-40, 41, size=rows.size)) % K
+    anywhere = rng.randint(0, K, size=rows.size)
+    edge = boundary + rng.randint(-2, 3, size=rows.size)
+    pick = rng.rand(rows.size)
+    colind = np.where(pick < 0.6, near, np.where(pick < 0.95, anywhere, edge)).astype(np.int32)
+    assert (colind < boundary).any() and (colind >= boundary).any()
+    rp, ci = _dev(rowptr), _dev(colind)
+    val = _dev(oracle.hash_val(colind.size, seed=9))
+    B = torch.empty((K, N), dtype=torch.float32, device="cuda")
+    step = 1 << 18
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    for r0 in range(0, K, step):  # values that differ between the halves at the same offset (a wrong base would show)
+        r1 = min(K, r0 + step)
+        B[r0:r1] = (torch.randint(0, 100, (r1 - r0, N), generator=g, device="cuda", dtype=torch.int32) - 50).float() / 100
+    plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x100)
+    d = plan.describe()
+    assert "kernel=staged-rows" in d, d
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    want = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x100})
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    # sampled rows against the oracle too (the plain call above takes 64-bit offsets: another code path, same bits)
+    rows_s = rng.choice(M, 64, replace=False)
+    v_h, B_rows = val.cpu().numpy(), None
+    for r in rows_s:
+        lo, hi = rowptr[r], rowptr[r + 1]
+        cols = colind[lo:hi]
+        Bs = B[torch.from_numpy(cols.astype(np.int64)).cuda()].cpu().numpy()
+        ref = oracle.spmm(np.array([0, hi - lo], dtype=np.int32), np.arange(hi - lo, dtype=np.int32), v_h[lo:hi], Bs, "fma")
+        assert np.array_equal(bits(got[r:r + 1].cpu().numpy()), bits(ref)), r
+    # beyond 8 GB the staged kernel is not offered: the plan falls back to the streaming kernels
+    assert pkg._lib.plan_policy(M, 4_300_000, colind.size, 512, 40, 0.0, 0.9, 0.9, kernel=pkg._lib.PLAN_KERNEL_STAGED)["build_staged"] == 0
