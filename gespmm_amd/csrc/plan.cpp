@@ -683,8 +683,9 @@ int gespmm_plan_spmm_max_f32(gespmm_plan* plan, const float* B, float* C, int64_
 int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_t reps, void* stream) {
     if (!p || N <= 0 || !B || !C) return GESPMM_EINVAL;
     if (N != p->N) return GESPMM_EINVAL;  // the tables are made for one width
-    if (!p->reordered) return 0;          // a storage-order plan has one launch path
-    if (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO && !p->tuned) return 0;  // the caller's explicit choice stands
+    // a storage-order plan has one launch path, and the caller's explicit choice stands: nothing to measure, but C = A * B as promised
+    if (!p->reordered || (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO && !p->tuned))
+        return plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return GESPMM_EINVAL;

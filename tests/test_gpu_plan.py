@@ -277,11 +277,14 @@ def test_tune_measures_the_candidates_and_keeps_the_bits(pkg, oracle, bundled):
         plan.tune(B)  # tuning twice is allowed (new measurement)
         with pytest.raises(_lib.GespmmError):  # another width than the plan's
             _lib.check(_lib.lib.gespmm_plan_tune(plan._handle, B.data_ptr(), B.data_ptr(), N + 4, 1, None), "gespmm_plan_tune")
+    # nothing to measure for an explicit kernel or a storage-order plan — but the product is still returned
+    B1_h = oracle.hash_B(g["K"], 128, seed=1)
+    ref1 = oracle.spmm(g["rowptr"], g["colind"], val_h, B1_h, "fma")
     explicit = spmm.SpmmPlan(rp, ci, g["K"], 128, values=val, reorder=True, kernel="seg-stream")
-    explicit.tune(_dev(oracle.hash_B(g["K"], 128, seed=1)))
+    assert np.array_equal(bits(explicit.tune(_dev(B1_h)).cpu().numpy()), bits(ref1))
     assert "tuned[" not in explicit.describe()
     storage = spmm.SpmmPlan(rp, ci, g["K"], 128, values=val, reorder=False)
-    storage.tune(_dev(oracle.hash_B(g["K"], 128, seed=1)))
+    assert np.array_equal(bits(storage.tune(_dev(B1_h)).cpu().numpy()), bits(ref1))
     assert "tuned[" not in storage.describe()
 
 
