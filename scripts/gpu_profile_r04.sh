@@ -30,11 +30,13 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o b -- p
 f=$(find $P -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/r04/bench_default_kernel_stats.csv
 ( time python bench.py > gpurun_out/r04/bench_round4.log 2> gpurun_out/r04/bench_round4.err ) 2> gpurun_out/r04/bench_round4.time
 cp profiles/bench_extra_last.json gpurun_out/r04/bench_extra_round4.json
+# the multi-GPU mode as a one-rank RCCL run (the form the driver launches for N > 1), RMAT scale 24
+( time python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --graph rmat --rmat-scale 24 --steps 5 --warmup 2 ) > gpurun_out/r04/bench_rmat24_torchrun1.log 2>&1
 timeout 1500 python scripts/plan_audit.py --baseline profiles/r03/plan_audit.log > gpurun_out/r04/plan_audit.log 2>&1; echo "plan_audit rc=$?" >> gpurun_out/r04/plan_audit.log
 if [ -d profiles/r04/holdout ] && ls profiles/r04/holdout/*.npz > /dev/null 2>&1; then
   timeout 1800 python scripts/holdout_audit.py 2>&1 | grep -v "amdgpu.ids\|^W2026" > gpurun_out/r04/holdout_audit.log
 fi
 timeout 1800 python scripts/holdout_audit.py --standins --widths 32 64 128 256 512 2>&1 | grep -v "amdgpu.ids\|^W2026" > gpurun_out/r04/standin_audit.log
 timeout 2400 python -m pytest tests -m gpu -q -rs > gpurun_out/r04/pytest_gpu_final.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04/pytest_gpu_final.log
-tail -1 gpurun_out/r04/bench_round4.log | cut -c1-4000; cat gpurun_out/r04/bench_round4.time
+tail -1 gpurun_out/r04/bench_round4.log | cut -c1-4000; cat gpurun_out/r04/bench_round4.time; grep "^{" gpurun_out/r04/bench_rmat24_torchrun1.log | cut -c1-1500
 tail -4 gpurun_out/r04/plan_audit.log | cut -c1-300; grep "<--\|worst" gpurun_out/r04/holdout_audit.log gpurun_out/r04/standin_audit.log | cut -c1-300; tail -4 gpurun_out/r04/pytest_gpu_final.log | cut -c1-300
