@@ -27,6 +27,8 @@ re-implemented (the reference imports them from torch_geometric, op.py:75).
 With ``cached=True`` — which already promises a static graph for the cached normalisation — GCNConv
 also keeps one SpmmPlan per direction (the analysis stage: sparse graphs are row-clustered once and launched from a
 task table, dense graphs keep the split points of the cache-blocked path; results keep their bits).
+``GCNConv(..., cached=True, tune_plans=True)`` (extension, off by default) additionally lets each plan pick its kernel by MEASUREMENT on the
+first forward's operands (``SpmmPlan.tune``: a few extra launches once per direction; not under stream capture — run one eager step first).
 The reference's ``normalize=False`` branch raises TypeError (``rowptr.shape(0)``,
 op.py:133-134); here it does what the branch evidently intends: no scaling.
 """
@@ -106,6 +108,7 @@ class GCNConv(torch.nn.Module):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.improved, self.cached, self.normalize = improved, cached, normalize
+        self.tune_plans = bool(kwargs.pop("tune_plans", False))
         self.weight = Parameter(torch.empty(in_channels, out_channels))
         self.bias = Parameter(torch.empty(out_channels)) if bias else None
         if not bias:
@@ -155,6 +158,15 @@ class GCNConv(torch.nn.Module):
                 n = rowptr.numel() - 1
                 self.cached_plans = (key, (_spmm.SpmmPlan(rowptr, colind, colptr.numel() - 1, h.shape[1]),
                                            _spmm.SpmmPlan(colptr, rowind, n, h.shape[1])))
+                if self.tune_plans and not torch.cuda.is_current_stream_capturing():
+                    with torch.no_grad():  # kernel choice by measurement, once per direction (same bits whichever wins)
+                        fwd, bwd = self.cached_plans[1]
+                        if edge_weight_csr is not None:
+                            fwd._sync_inputs(rowptr, colind, edge_weight_csr, h.detach(), fwd.shape[4])
+                        out0 = fwd.tune(h.detach().contiguous())
+                        if edge_weight_csc is not None:
+                            bwd._sync_inputs(colptr, rowind, edge_weight_csc, out0, bwd.shape[4])
+                        bwd.tune(out0)
             plans = self.cached_plans[1]
         h = SPMMFunction.apply(rowptr, colind, colptr, rowind, h, edge_weight_csr, edge_weight_csc, False, plans)
         if self.normalize:

@@ -122,13 +122,14 @@ def test_edge_weight_gradient_extension(pkg, graph):
     assert torch.allclose(x.grad.double(), dense.T @ gout.double(), atol=1e-4)
 
 
+@pytest.mark.parametrize("tune", (False, True))
 @pytest.mark.parametrize("weighted", (False, True))
-def test_gcnconv_matches_dense_restatement(pkg, graph, weighted):
+def test_gcnconv_matches_dense_restatement(pkg, graph, weighted, tune):
     from gespmm_amd import GCNConv
 
     g = graph
     torch.manual_seed(0)
-    conv = GCNConv(40, 16, cached=True, normalize=True).cuda()
+    conv = GCNConv(40, 16, cached=True, normalize=True, tune_plans=tune).cuda()  # (tune_plans: kernel choice by measurement, same results)
     with torch.no_grad():
         conv.bias.uniform_(-0.1, 0.1)
     x = torch.randn(g["n_v"], 40, device="cuda", requires_grad=True)
