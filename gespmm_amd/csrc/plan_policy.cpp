@@ -135,17 +135,20 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
 //   6.36 vs 7.03 ms and 15.5 vs 16.8 ms on the reddit-sized community graph, profiles/r03/dense_community_audit.log)
 //   Hold-out audit (round 4, profiles/r04/holdout_audit.log): with mean degree 51 but only 0.52-0.57 modelled hits (LFR, mu = 0.3) the batch
 //   kernel is 6-8 % ahead at N = 32 / 128 where the planted-community graph (0.84 hits) has the segmented one 7-11 % ahead — the
-//   continuous stream pays off when most gathers are L2 hits: 0.70 asked for, not 0.40. At 129-256 columns the segmented kernel is
-//   3-7 % ahead on mid-range hit rates (LFR mu = 0.3 / 0.5, dense LFR: 0.27-0.52) and 12-13 % behind on high ones with short rows
+//   continuous stream pays off when most gathers are L2 hits: 0.70 asked for, not 0.40. At 129-512 columns the segmented kernel is
+//   2-8 % ahead on mid-range hit rates (LFR mu = 0.3 / 0.5, dense LFR: 0.27-0.52) and 12-13 % behind on high ones with short rows
 //   (geometric, small-world: 0.8-0.9).
 bool prefer_segmented(const PlanFacts& f, double hits_after, int64_t N) {
     if (f.kernel_choice == GESPMM_PLAN_KERNEL_SEG_STREAM) return true;
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return false;
     const int64_t mean_deg = f.mean_floor();
-    if (!(f.nnz >= (1 << 20) && N % 4 == 0 && mean_deg >= 16)) return false;
+    if (!(f.nnz >= (1 << 20) && N % 4 == 0)) return false;
+    // (mid-range hit rates beyond 128 columns: LFR mu = 0.3 / 0.5 and the dense LFR graph, 3-8 % at N = 256 and 2-7 % at 512;
+    //  their mean degree is 15.7-15.9: the ceiling is asked for 16 here)
+    if (N > 128 && N <= 512 && f.mean_ceil() >= 16 && hits_after >= 0.25 && hits_after < 0.60) return true;
+    if (mean_deg < 16) return false;
     if ((N <= 32 || (N > 64 && N <= 128)) && hits_after >= 0.70) return true;
     if (mean_deg >= 128 && N > 64 && N <= 512 && hits_after >= 0.40) return true;
-    if (N > 128 && N <= 256 && hits_after >= 0.25 && hits_after < 0.60) return true;
     return false;
 }
 

@@ -38,6 +38,8 @@
 //   --no-vendor     skip the rocSPARSE comparison column
 //   --plan          time the launches through a gespmm plan (the analysis stage: built once per width before the timed
 //                   loop, its time printed; same results) — with --validate the planned product is checked as well
+//   --tune          with --plan: the plan's kernel is chosen by gespmm_plan_tune (candidates timed on the driver's operands) before the
+//                   timed loop; the tuning time is printed with the plan
 //   --describe      print what the library launches for each N (gespmm_describe_launch)
 //   --cache dir     keep the parsed matrix as a binary file in `dir` and reuse it next time
 //
@@ -209,7 +211,7 @@ int main(int argc, char** argv) {
     int method = GESPMM_VARIANT_CRC_CWM2;
     int iters = 200;
     bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true, describe = false;
-    bool atomic_baseline = false, use_plan = false;
+    bool atomic_baseline = false, use_plan = false, tune_plan = false;
     unsigned seed = 0;
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
@@ -237,13 +239,14 @@ int main(int argc, char** argv) {
         else if (a == "--describe") describe = true;
         else if (a == "--atomic-baseline") atomic_baseline = true;
         else if (a == "--plan") use_plan = true;
+        else if (a == "--tune") use_plan = tune_plan = true;
         else if (a == "--cache") cache_dir = next("--cache");
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
     if (!mtx_path) {
         fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
-                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--plan] [--no-vendor] [--describe] [--out path]\n", argv[0]);
+                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--plan] [--tune] [--no-vendor] [--describe] [--out path]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (iters < 1) iters = 1;
@@ -453,9 +456,10 @@ int main(int argc, char** argv) {
             CHECK_GE(gespmm_plan_create(&plan, g.indptr_dev, g.indices_dev, g.data_dev, M, K, nnz, N,
                                         method == GESPMM_VARIANT_NAIVE || method == GESPMM_VARIANT_PARREDUCE ? GESPMM_VARIANT_AUTO : method,
                                         nullptr, nullptr));
+            if (tune_plan) CHECK_GE(gespmm_plan_tune(plan, g.B_dev, g.C_dev, N, 3, nullptr));
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            char what[512];
-            if (gespmm_plan_describe(plan, what, sizeof what) > 0) printf("N=%d plan (%.3f s): %s\n", N, secs, what);
+            char what[768];
+            if (gespmm_plan_describe(plan, what, sizeof what) > 0) printf("N=%d plan (%.3f s%s): %s\n", N, secs, tune_plan ? ", tuned" : "", what);
         }
         auto launch = [&]() {
             return plan ? gespmm_plan_spmm_f32(plan, g.B_dev, g.C_dev, N, nullptr)
