@@ -64,7 +64,7 @@ struct StagingTables {
 hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
                                   int limit, StagingTables* t, int32_t** colind_s, float** val_s, hipStream_t st);
 // perm (clustered position -> original row; may be NULL): on square matrices a column whose own row is processed more than
-// GESPMM_STAGED_FAR_BLOCKS (default 64) x 128 rows away is marked "far" (bit 30 of its code): gathered with `nt`.
+// GESPMM_STAGED_FAR_BLOCKS (default 0 = no marks; round 3: 64) x 128 rows away is marked "far" (bit 30 of its code): gathered with `nt`.
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
                                 const float* val_p, const int32_t* perm, int R, int H, StagingTables* out, hipStream_t st);
 // val_p: values in the clustered matrix's entry order (NULL: 1.0f); rowptr_p: its row pointers (used when hub rows were split off)

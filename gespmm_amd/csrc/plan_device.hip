@@ -1782,8 +1782,12 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     // `out` then already carries rowptr_s / ltasks / nlong / nnz_s from device_split_long_rows, which stay)
     if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0) return hipErrorInvalidValue;
     const int64_t nblk = (M + R - 1) / R;
-    // "far" columns (square matrices only): more than this many blocks away in the clustered order. 0 = off.
-    static const int far_env = getenv("GESPMM_STAGED_FAR_BLOCKS") ? atoi(getenv("GESPMM_STAGED_FAR_BLOCKS")) : 64;
+    // "far" columns (square matrices only): more than this many blocks away in the clustered order, gathered `nt`. OFF by default since round 4:
+    // the marks had bought 12 % on the products-shaped graph when they went in (128-row blocks, round 3); with the per-width block heights and
+    // six clustering levels they are level there at N = 128 / 512 and COST 4 % at N = 256, 6-8 % at quarter size, 7-9 % on the com-Amazon-shaped
+    // graph at N = 256 / 512 and 4-7 % on LFR (profiles/r04/far_marks_by_graph.log, two interleaved rounds). GESPMM_STAGED_FAR_BLOCKS = 64
+    // brings them back for experiments.
+    static const int far_env = getenv("GESPMM_STAGED_FAR_BLOCKS") ? atoi(getenv("GESPMM_STAGED_FAR_BLOCKS")) : 0;
     const bool mark_far = perm && M == K && far_env > 0 && K < (1 << 22);
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < K) ++bits;

@@ -303,7 +303,7 @@ typedef struct gespmm_plan_options {
 #define GESPMM_PLAN_KERNEL_STAGED 5     /* scalar-stream walk + the most used B rows of every block of 96 / 64 clustered rows staged in LDS
                                           (N = 128, 256, 512 or 1024 — 256-column tiles bound to XCDs beyond 256; sum reducer, device
                                           analysis; rows beyond 2048 entries go to the long-row pass). AUTO takes it for clustered
-                                          matrices with mean degree >= 12 (N = 128) / >= 5 (wider) when >= 60 % (N = 128) / 48 % of
+                                          matrices with mean degree >= 12 (N = 128) / >= 5 (wider) when >= 60 % (N = 128) / 42 % of
                                           the entries find their B row staged (csrc/plan_policy.cpp: hold-out audit) */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,

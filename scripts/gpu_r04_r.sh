@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r04
+timeout 1500 python profiles/r04/experiments/far_marks_by_graph.py 2>&1 | grep -v "amdgpu.ids\|^W2026" > gpurun_out/r04/far_marks_by_graph.log
+cat gpurun_out/r04/far_marks_by_graph.log

@@ -34,7 +34,8 @@ TABLE = [
     # ---- hold-out graphs (profiles/r04/holdout_audit.log): the rows that moved thresholds in round 4
     ("LFR mu=0.1 N=128: share 0.565 loses 21 % staged", (300000, 4717400, 128, 306, 0.041, 0.768, 0.565),
      dict(keep_clustered=1, build_staged=1, keep_staged=0, segmented=0)),
-    ("LFR mu=0.1 N=256: share 0.44 loses 5 % staged", (300000, 4717400, 256, 306, 0.021, 0.763, 0.440), dict(build_staged=1, keep_staged=0, segmented=0)),
+    ("LFR mu=0.1 N=256: share 0.44 level (x0.99; x0.93 at 512) without the nt marks", (300000, 4717400, 256, 306, 0.021, 0.763, 0.440), dict(build_staged=1, keep_staged=1)),
+    ("LFR mu=0.3 N=256: share 0.33 loses 13 % staged", (300000, 4759166, 256, 305, 0.021, 0.521, 0.332), dict(build_staged=1, keep_staged=0, segmented=1)),
     ("geometric N=128: share 0.94 wins", (600000, 7175884, 128, 30, 0.010, 0.910, 0.937), dict(build_staged=1, keep_staged=1)),
     ("small-world N=256: share 0.77 wins", (1000000, 11001376, 256, 18, 0.003, 0.815, 0.767), dict(build_staged=1, keep_staged=1)),
     ("dense LFR mu=0.3 N=128: batch kernel at 0.52 hits", (300000, 15383642, 128, 619, 0.035, 0.519, 0.27), dict(keep_staged=0, segmented=0)),
@@ -42,7 +43,7 @@ TABLE = [
     ("dense LFR mu=0.3 N=256: segmented at mid hit rates", (300000, 15383642, 256, 619, 0.018, 0.487, 0.196), dict(keep_staged=0, segmented=1)),
     ("dense LFR mu=0.3 N=512: segmented at mid hit rates", (300000, 15383642, 512, 619, 0.018, 0.487, 0.196), dict(keep_staged=0, segmented=1)),
     ("LFR mu=0.5 N=256: segmented (mean degree 15.9)", (300000, 4777356, 256, 309, 0.021, 0.269, 0.199), dict(keep_staged=0, segmented=1)),
-    ("LFR mu=0.1 N=256: batch kernel at 0.76 hits", (300000, 4717400, 256, 306, 0.021, 0.763, 0.30), dict(keep_staged=0, segmented=0)),
+    ("LFR mu=0.1 N=256 with a low share: batch kernel at 0.76 hits", (300000, 4717400, 256, 306, 0.021, 0.763, 0.30), dict(keep_staged=0, segmented=0)),
     ("Holme-Kim m=5 N=128 (hubs: long-row pass)", (500000, 4999852, 128, 8968, 0.055, 0.346, 0.341), dict(keep_clustered=1, keep_staged=0, launch_flags=SPLIT)),
     ("skewed RMAT: storage order already hits", (524288, 12582912, 128, 181863, 0.558, 0.559, 0.0), dict(analyse=1, keep_clustered=0)),
     ("C3 products-like N=128 (no structure)", (2449029, 123718280, 128, 30000, 0.003, 0.02, 0.0),
