@@ -67,12 +67,15 @@ bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double 
 // Non-zeros per wavefront task. Storage-order launches take ~12 KB of gathered B per task (select.cpp);
 // clustered plans take ~20 KB (40 entries at N = 128, 32 at N >= 256, 80 at N = 64: profiles/r02/plan_task_size_final.log — at
 // N = 128 anything from 40 to 80 entries runs within 1 %, and the smaller task keeps fewer rows in flight per XCD: fabric bytes
-// 1.48x algorithmic at 40 entries, 1.54x at 48, 1.62x at 56, plan_task_size_traffic.log).
+// 1.48x algorithmic at 40 entries, 1.54x at 48, 1.62x at 56, plan_task_size_traffic.log). Round 4 re-swept the sizes on the stand-ins
+// and the hold-out graphs (profiles/r04/constants_resweep.log): N = 128 / 512 confirmed; at N = 32 the cap of 96 entries cost 3-11 %
+// on EVERY graph (128-192 entries: com-Amazon-shaped 34.9 vs 36.7 us, structureless 45.5 vs 49.2, LFR 70-71 vs 78-80, geometric 100 vs
+// 106) — the cap is 192 now (N = 32: 160 entries).
 static int default_task_entries(int64_t N) {
     const int64_t row_bytes = 4 * (N < 256 ? N : 256);
     int64_t t = (20 << 10) / (row_bytes > 0 ? row_bytes : 4);
     if (t < 32) t = 32;
-    if (t > 96) t = 96;  // narrow rows (N = 32: 128-byte rows) are latency-bound per row pair: the plain path's 96 entries
+    if (t > 192) t = 192;
     return (int)t;
 }
 
@@ -82,8 +85,10 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
     const bool te_given = f.opt_task_entries > 0;
     int budget = te_given ? f.opt_task_entries : default_task_entries(f.N);
     // ... never fewer than ~5 rows of mean length per task (products-shaped graphs, degree 50: 256-entry tasks at N = 32 run
-    // 1.48 ms, 96-entry tasks 2.33 ms)
-    if (!te_given && budget < 5 * mean) budget = (int)(5 * mean < 512 ? 5 * mean : 512);
+    // 1.48 ms, 96-entry tasks 2.33 ms) — up to 256 columns; beyond (two or more column tiles per row) 2 rows: 5 cost 4 % at N = 512
+    // on the LFR and products-shaped graphs (constants_resweep.log: 832 vs 869 us, 3743 vs 3916)
+    const int64_t min_rows = f.N > 256 ? 2 : 5;
+    if (!te_given && budget < min_rows * mean) budget = (int)(min_rows * mean < 512 ? min_rows * mean : 512);
     d.task_entries = budget;
     d.row_floor = f.opt_row_floor < 0 ? 0 : (f.opt_row_floor > 0 ? f.opt_row_floor : 8);
     // segmented-stream kernel: a task per lane GROUP, cut by non-zeros alone, half the budget (short rows: 16 entries per lane

@@ -16,7 +16,7 @@ TABLE = [
     ("C2a com-amazon-like N=128", (334863, 1851744, 128, 499, 0.025, 0.176, 0.0),
      dict(analyse=1, keep_clustered=1, task_entries=40, build_staged=0, shallow_unroll=0, segmented=0, sddmm_route=1)),
     ("C2a com-amazon-sbm N=32", (334863, 1851744, 32, 120, 0.09, 0.70, 0.0),
-     dict(analyse=1, keep_clustered=1, task_entries=96, shallow_unroll=1, segmented=0, narrow_vec4=1)),  # 37.1 vs 44.6 us
+     dict(analyse=1, keep_clustered=1, task_entries=160, shallow_unroll=1, segmented=0, narrow_vec4=1)),  # V = 4: 37.1 vs 44.6 us; 160 entries: 34.9 vs 36.7
     ("C2a com-amazon-like N=32 (misses: one lane per column)", (334863, 1851744, 32, 499, 0.092, 0.222, 0.0), dict(keep_clustered=1, narrow_vec4=0)),
     ("LFR mu=0.1 N=32 (rows of 16: one lane per column)", (300000, 4717400, 32, 306, 0.144, 0.786, 0.0), dict(keep_clustered=1, narrow_vec4=0, segmented=0)),
     ("C2a com-amazon-sbm N=512", (334863, 1851744, 512, 120, 0.01, 0.60, 0.0),
@@ -30,7 +30,7 @@ TABLE = [
      dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=255, build_staged=1, keep_staged=1, segmented=0, model_sample=1 << 22)),
     ("C3 products-sbm N=32", (2449029, 123718280, 32, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=1)),
     ("C3 products-sbm N=64", (2449029, 123718280, 64, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=0)),
-    ("C3 products-sbm N=512", (2449029, 123718280, 512, 1446, 0.001, 0.833, 0.503), dict(keep_clustered=1, build_staged=1, keep_staged=1)),
+    ("C3 products-sbm N=512", (2449029, 123718280, 512, 1446, 0.001, 0.833, 0.503), dict(keep_clustered=1, build_staged=1, keep_staged=1, task_entries=102)),
     # ---- hold-out graphs (profiles/r04/holdout_audit.log): the rows that moved thresholds in round 4
     ("LFR mu=0.1 N=128: share 0.565 loses 21 % staged", (300000, 4717400, 128, 306, 0.041, 0.768, 0.565),
      dict(keep_clustered=1, build_staged=1, keep_staged=0, segmented=0)),
