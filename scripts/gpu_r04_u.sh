@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r04
+timeout 2400 python profiles/r04/experiments/constants_resweep2.py 2>&1 | grep -v "amdgpu.ids\|^W2026" > gpurun_out/r04/constants_resweep2.log
+cat gpurun_out/r04/constants_resweep2.log | cut -c1-260
