@@ -300,3 +300,47 @@ def test_cached_memory_limit_and_release(pkg):
             assert plan.clustered
             del plan
         _lib.release_cached_memory()
+
+
+def test_plan_options_by_size(pkg, bundled):
+    """gespmm_plan_create is the 0.1 symbol: it reads the six fields 0.1 had and nothing beyond them (a caller built against the old
+    header passes a 24-byte struct); gespmm_plan_create_v2 reads what the caller's sizeof says, rejects sizes that are not a multiple of
+    4, takes defaults for fields the caller does not have and ignores bytes it does not know."""
+    import ctypes
+
+    from gespmm_amd import _lib
+
+    lib = _lib.lib
+    g = bundled["pubmed"]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    M, K, nnz = g["M"], g["K"], g["nnz"]
+
+    class Big(ctypes.Structure):  # a FUTURE header: the known fields + two more
+        _fields_ = [(n, ctypes.c_int32) for n in ("reorder", "task_entries", "row_floor", "threads", "flags", "kernel", "analysis", "x1", "x2")]
+
+    def create(fn, opt, *size):
+        h = ctypes.c_void_p()
+        rc = fn(ctypes.byref(h), rp.data_ptr(), ci.data_ptr(), None, M, K, nnz, 128, -1, ctypes.cast(ctypes.byref(opt), ctypes.POINTER(_lib.PlanOptions)),
+                *size, None)
+        if rc == 0:
+            buf = ctypes.create_string_buffer(1024)
+            lib.gespmm_plan_describe(h, buf, 1024)
+            lib.gespmm_plan_destroy(h)
+            return rc, buf.value.decode()
+        return rc, ""
+
+    garbage = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, 12345, -7, 99)
+    rc, d = create(lib.gespmm_plan_create, garbage)  # 0.1 symbol: `analysis` = 12345 is never looked at
+    assert rc == 0 and "order=clustered" in d and "on the device" in d, (rc, d)
+    rc, _ = create(lib.gespmm_plan_create_v2, garbage, ctypes.sizeof(_lib.PlanOptions))  # 28 bytes: `analysis` IS read -> invalid
+    assert rc == -1, rc  # GESPMM_EINVAL
+    ok = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, -7, 99)
+    rc, d = create(lib.gespmm_plan_create_v2, ok, ctypes.sizeof(Big))  # a bigger struct than this library knows: the tail is ignored
+    assert rc == 0 and "on the host" in d, (rc, d)
+    rc, d = create(lib.gespmm_plan_create_v2, ok, 24)  # an old caller through the new symbol: analysis takes its default
+    assert rc == 0 and "on the device" in d, (rc, d)
+    rc, _ = create(lib.gespmm_plan_create_v2, ok, 26)
+    assert rc != 0
+    removed = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, 2, 0, 0, 0)  # GESPMM_PLAN_KERNEL_LDS_ROWS of rounds 2-3: gone
+    rc, _ = create(lib.gespmm_plan_create, removed)
+    assert rc != 0
