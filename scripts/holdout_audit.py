@@ -135,6 +135,14 @@ def main():
                         note += "(share %s)" % d2.split("staged_entries=")[1].split(" ")[0]
                     alts["%s/%s" % ("clustered" if order else "storage", kern)] = (t2, note)
                     del p2
+            if nnz / M > 96:  # dense graphs: the clustered order is reachable only without the cache-blocked path
+                from gespmm_amd import _lib
+                for kern in ("stream", "seg-stream"):
+                    p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=kern, flags=_lib.FLAG_NO_SLAB_BLOCKED)
+                    t2 = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p2), iters)
+                    ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
+                    alts["clustered-noslab/%s" % kern] = (t2, ("" if ok else "BITS-DIFFER ") + "(model %s)" % p2.describe().split("l2_model=")[1].split(" ")[0])
+                    del p2
             best_k, best_t = min(((k, v[0]) for k, v in alts.items() if v[0] is not None), key=lambda kv: kv[1])
             best_t = min(best_t, t_plain)
             ratio = t_auto / best_t

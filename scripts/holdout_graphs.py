@@ -25,6 +25,11 @@ CASES = {
                                                 max_community=1000, seed=13, max_iters=5000),
     "lfr-dense-mu0.3": lambda: nx.LFR_benchmark_graph(300000, 2.5, 1.5, 0.3, average_degree=40, max_degree=600, min_community=100,
                                                       max_community=2000, seed=14, max_iters=5000),
+    # dense LFR (the reddit-shaped regime: mean degree in the hundreds): does the 0.65 rule for dense graphs hold off the stand-in?
+    "lfr-verydense-mu0.2": lambda: nx.LFR_benchmark_graph(100000, 2.5, 1.5, 0.2, average_degree=250, max_degree=1500, min_community=500,
+                                                          max_community=5000, seed=15, max_iters=5000),
+    "lfr-verydense-mu0.5": lambda: nx.LFR_benchmark_graph(100000, 2.5, 1.5, 0.5, average_degree=250, max_degree=1500, min_community=500,
+                                                          max_community=5000, seed=16, max_iters=5000),
     # Holme-Kim: preferential attachment + triad formation: triangles WITHOUT communities
     "holme-kim-m5": lambda: nx.powerlaw_cluster_graph(500000, 5, 0.6, seed=21),
     "holme-kim-m16": lambda: nx.powerlaw_cluster_graph(400000, 16, 0.6, seed=22),

@@ -45,6 +45,12 @@ TABLE = [
     ("LFR mu=0.5 N=256: segmented (mean degree 15.9)", (300000, 4777356, 256, 309, 0.021, 0.269, 0.199), dict(keep_staged=0, segmented=1)),
     ("LFR mu=0.1 N=256 with a low share: batch kernel at 0.76 hits", (300000, 4717400, 256, 306, 0.021, 0.763, 0.30), dict(keep_staged=0, segmented=0)),
     ("Holme-Kim m=5 N=128 (hubs: long-row pass)", (500000, 4999852, 128, 8968, 0.055, 0.346, 0.341), dict(keep_clustered=1, keep_staged=0, launch_flags=SPLIT)),
+    ("Barabasi-Albert N=32: +0.047 modelled hits is worth the order", (500000, 5999928, 32, 2726, 0.112, 0.159, 0.0), dict(analyse=1, keep_clustered=1)),
+    ("very dense LFR mu=0.5 N=32: no cache-blocked path at this width, judged like a sparse graph", (100000, 33022008, 32, 1626, 0.312, 0.453, 0.0),
+     dict(analyse=1, dense_try=0, keep_clustered=1)),
+    ("very dense LFR mu=0.5 N=128: 0.23 modelled hits against the cache-blocked path", (100000, 33022008, 128, 1626, 0.080, 0.226, 0.0),
+     dict(analyse=1, dense_try=1, keep_clustered=0)),
+    ("very dense LFR mu=0.2 N=64: 0.68", (100000, 32419866, 64, 1597, 0.157, 0.684, 0.0), dict(analyse=1, keep_clustered=1)),
     ("skewed RMAT: storage order already hits", (524288, 12582912, 128, 181863, 0.558, 0.559, 0.0), dict(analyse=1, keep_clustered=0)),
     ("C3 products-like N=128 (no structure)", (2449029, 123718280, 128, 30000, 0.003, 0.02, 0.0),
      dict(analyse=1, keep_clustered=0, launch_flags=SPLIT)),
