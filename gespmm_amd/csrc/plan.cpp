@@ -266,7 +266,7 @@ int gespmm_plan_debug_tasks(const gespmm_plan* p, int32_t which, int32_t* out_ho
 static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
     const auto ts = std::chrono::steady_clock::now();
     const int64_t M = p->M, K = p->K, nnz = p->nnz, N = p->N;
-    const int H = gespmm::staged_rows_per_block_lds(N);
+    const gespmm::StagedShape shape = gespmm::staged_shape(N);
     hipError_t e = hipSuccess;
     const int32_t* rp_s = p->d_rowptr;
     const int32_t* ci_s = p->d_colind;
@@ -282,7 +282,7 @@ static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
         nnz_s = p->stg.nnz_s;
     }
     if (e == hipSuccess && nnz_s > 0)
-        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, gespmm::staged_block_rows(N), H, &p->stg, st);
+        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, shape.rows, shape.slots, shape.waves, &p->stg, st);
     if (ci_tmp) (void)hipFree(ci_tmp);
     if (val_tmp) (void)hipFree(val_tmp);
     if (e == hipSuccess && !p->stg.ev) gespmm::free_staging(&p->stg);  // (nothing but hub rows)
@@ -635,7 +635,7 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
-                                 p->stg.nhot, B, C, p->stg.nblocks};
+                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, 0, nullptr};
         rc = (int)gespmm::launch_spmm_staged(sa, p->K, N, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0 && p->stg.nlong > 0) {
             // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits

@@ -41,14 +41,15 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
 
 // Tables of spmm_staged.hip for the clustered matrix (rowptr_p / colind_p / val_p = the plan's row-permuted copy; val_p NULL:
 // unweighted, the stream carries 1.0f): blocks of R rows, per block the <= H columns its entries use most often
-// (>= 2 uses), kStagedWaves tasks, and the interleaved {code, value} stream. staged_fraction = share of the entries whose B row
+// (>= 2 uses), `waves` tasks, and the interleaved {code, value} stream. staged_fraction = share of the entries whose B row
 // comes from LDS. Deterministic (ties in column order). The four arrays are hipMalloc blocks owned by the caller (free_staging).
 struct StagingTables {
     int32_t* ev = nullptr;        // 2 * (nnz_s + kStagedPad) words
     int32_t* hot_cols = nullptr;  // nblocks * H
     int32_t* nhot = nullptr;      // nblocks
-    int32_t* tasks = nullptr;     // nblocks * kStagedWaves int4
+    int32_t* tasks = nullptr;     // nblocks * waves int4
     int32_t nblocks = 0;
+    int32_t waves = 0;            // wavefronts (tasks) per block
     double staged_fraction = 0.0;
     // hub rows (device_split_long_rows): the staged kernel walks a copy of the row pointers in which they are EMPTY, and they
     // are handed to the streaming kernel's long-row pass as one-row tasks. NULL / 0: no such rows, the plan's own row pointers.
@@ -63,10 +64,9 @@ struct StagingTables {
 // tables are built; val_s NULL when val_p is) and the one-row tasks of the rows taken out.
 hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
                                   int limit, StagingTables* t, int32_t** colind_s, float** val_s, hipStream_t st);
-// perm (clustered position -> original row; may be NULL): on square matrices a column whose own row is processed more than
-// GESPMM_STAGED_FAR_BLOCKS (default 0 = no marks; round 3: 64) x 128 rows away is marked "far" (bit 30 of its code): gathered with `nt`.
+// perm (clustered position -> original row; may be NULL) is unused since round 5 (the `nt` marks of round 3 are gone).
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, const int32_t* perm, int R, int H, StagingTables* out, hipStream_t st);
+                                const float* val_p, const int32_t* perm, int R, int H, int waves, StagingTables* out, hipStream_t st);
 // val_p: values in the clustered matrix's entry order (NULL: 1.0f); rowptr_p: its row pointers (used when hub rows were split off)
 hipError_t device_staging_set_values(const StagingTables& t, const float* val_p, const int32_t* rowptr_p, int64_t M, int64_t nnz,
                                      hipStream_t st);

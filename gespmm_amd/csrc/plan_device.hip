@@ -1544,14 +1544,8 @@ __global__ void k_stage_iota(int32_t* __restrict__ out, int64_t n) {
     if (i < n) out[i] = (int32_t)i;
 }
 
-__global__ void k_stage_positions(const int32_t* __restrict__ perm, int64_t M, int32_t* __restrict__ pos) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) pos[perm[i]] = (int32_t)i;
-}
-
 __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict__ blkoff, const int32_t* __restrict__ keys,
-                                                       const int32_t* __restrict__ idx, int H, int R, const int32_t* __restrict__ pos,
-                                                       int far_blocks, int32_t* __restrict__ code,
+                                                       const int32_t* __restrict__ idx, int H, int32_t* __restrict__ code,
                                                        int32_t* __restrict__ hot_cols, int32_t* __restrict__ nhot,
                                                        unsigned long long* __restrict__ staged_entries) {
     using BlockScan = rocprim::block_scan<int, 256>;
@@ -1611,11 +1605,7 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
         if (f_gt) slot = base_gt + (ex & 0xffff);
         else if (f_eq && base_eq + (ex >> 16) < quota) slot = ngt + base_eq + (ex >> 16);
         if (len > 0) {
-            int c = slot >= 0 ? (int)(0x80000000u | (unsigned)slot) : key;
-            if (slot < 0 && pos) {  // square matrix: B row `key` is also row `key` of the matrix — how far away is it processed?
-                const long long d = (long long)(pos[key] / kStagedFarUnitRows) - (long long)(blk * R / kStagedFarUnitRows);
-                if (d > far_blocks || d < -far_blocks) c |= 1 << 30;
-            }
+            const int c = slot >= 0 ? (int)(0x80000000u | (unsigned)slot) : key;
             for (int i = 0; i < len; ++i) code[idx[p + i]] = c;
             if (slot >= 0) {
                 hot_cols[blk * H + slot] = key;
@@ -1631,7 +1621,8 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
     if ((tid & 63) == 0 && mine) atomicAdd(staged_entries, mine);
 }
 
-__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int32_t* __restrict__ tasks) {
+__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int kStagedWaves,
+                              int32_t* __restrict__ tasks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk * kStagedWaves) return;
     const int64_t blk = i / kStagedWaves;
@@ -1777,18 +1768,15 @@ void free_staging(StagingTables* t) {
 }
 
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, const int32_t* perm, int R, int H, StagingTables* out, hipStream_t st) {
+                                const float* val_p, const int32_t* perm, int R, int H, int waves, StagingTables* out, hipStream_t st) {
     // (rowptr_p / colind_p / val_p / nnz describe what the staged kernel walks: the clustered matrix, or its copy without hub rows —
     // `out` then already carries rowptr_s / ltasks / nlong / nnz_s from device_split_long_rows, which stay)
-    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0) return hipErrorInvalidValue;
+    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0 || waves <= 0 || waves > kStagedMaxWaves) return hipErrorInvalidValue;
+    const int kStagedWaves = waves;
     const int64_t nblk = (M + R - 1) / R;
-    // "far" columns (square matrices only): more than this many blocks away in the clustered order, gathered `nt`. OFF by default since round 4:
-    // the marks had bought 12 % on the products-shaped graph when they went in (128-row blocks, round 3); with the per-width block heights and
-    // six clustering levels they are level there at N = 128 / 512 and COST 4 % at N = 256, 6-8 % at quarter size, 7-9 % on the com-Amazon-shaped
-    // graph at N = 256 / 512 and 4-7 % on LFR (profiles/r04/far_marks_by_graph.log, two interleaved rounds). GESPMM_STAGED_FAR_BLOCKS = 64
-    // brings them back for experiments.
-    static const int far_env = getenv("GESPMM_STAGED_FAR_BLOCKS") ? atoi(getenv("GESPMM_STAGED_FAR_BLOCKS")) : 0;
-    const bool mark_far = perm && M == K && far_env > 0 && K < (1 << 22);
+    // (Round 3 marked columns whose own row sits far away in the clustered order and gathered them `nt`; level or harmful once the block
+    // heights and the clustering depth had settled — profiles/r04/far_marks_by_graph.log — and removed in round 5.)
+    (void)perm;
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < K) ++bits;
     size_t sort_bytes = 0;
@@ -1800,7 +1788,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     Scratch sc(st);
     GESPMM_TRY(sc.init(0, 0, 16 * (size_t)nnz + 4 * (size_t)(M + nblk) + sort_bytes + (8 << 20)));
     sc.use(Scratch::kTemp);
-    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr, *pos = nullptr;
+    int32_t *blkoff = nullptr, *keys = nullptr, *idx_in = nullptr, *idx_out = nullptr, *code = nullptr;
     unsigned long long* staged = nullptr;
     char* tmp = nullptr;
     GESPMM_TRY(sc.get(&blkoff, nblk + 1));
@@ -1810,11 +1798,9 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     GESPMM_TRY(sc.get(&code, nnz));
     GESPMM_TRY(sc.get(&staged, 1));
     GESPMM_TRY(sc.get(&tmp, (int64_t)(sort_bytes ? sort_bytes : 256)));
-    if (mark_far) GESPMM_TRY(sc.get(&pos, M));
     StagingTables t;  // the four tables built here; merged into *out on success
     auto body = [&]() -> hipError_t {
         GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
-        if (mark_far) hipLaunchKernelGGL(k_stage_positions, dim3(grid_for(M)), dim3(256), 0, st, perm, M, pos);
         hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, R, blkoff);
         hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
         GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, sort_bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
@@ -1825,10 +1811,10 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.nhot), (size_t)nblk * 4));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.tasks), (size_t)nblk * kStagedWaves * 16));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + kStagedPad) * 8));
-        GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0, (size_t)nblk * H * 4, st));
+        GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0xFF, (size_t)nblk * H * 4, st));  // unused slots: -1 (the kernel copies nothing for them)
         hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
-                           (const int32_t*)idx_out, H, R, (const int32_t*)pos, far_env, code, t.hot_cols, t.nhot, staged);
-        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, R, t.tasks);
+                           (const int32_t*)idx_out, H, code, t.hot_cols, t.nhot, staged);
+        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, R, kStagedWaves, t.tasks);
         hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz + kStagedPad)), dim3(256), 0, st, (const int32_t*)code, val_p, nnz,
                            nnz + kStagedPad, t.ev);
         GESPMM_TRY(hipGetLastError());
@@ -1849,6 +1835,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     out->nhot = t.nhot;
     out->tasks = t.tasks;
     out->nblocks = t.nblocks;
+    out->waves = waves;
     out->staged_fraction = t.staged_fraction;
     if (!out->rowptr_s) out->nnz_s = nnz;
     return hipSuccess;

@@ -133,7 +133,7 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     //                      (without the `nt` marks of round 3, which cost this tile width 4-9 %: holdout_audit.log after far_marks_by_graph.log)
     // (round 3 asked for 0.40 at both widths: fitted on the planted-community generator alone, 20-41 % behind on the LFR graphs)
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return true;
-    return staged_fraction >= (staged_rows_per_block_lds(f.N) >= 128 ? 0.60 : 0.42);
+    return staged_fraction >= (f.N == 128 ? 0.60 : 0.42);  // (128-column tiles : 256-column tiles)
 }
 
 // Which streaming kernel a clustered plan launches (AUTO rule + the caller's choice).

@@ -104,26 +104,35 @@ hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStre
 // spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256 and, as
 // 256-column tiles bound to XCDs, 512 / 1024; sum).
 // plan_device.hip (device_build_staging) writes the tables: blocks of staged_block_rows(N) consecutive rows of the clustered matrix,
-// kStagedWaves tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream
+// `waves` tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream
 // `ev` = {code, value bits} per entry (code >= 0: column; code < 0: staged slot in its low bits), padded by kStagedPad entries.
-constexpr int kStagedFarUnitRows = 128;  // GESPMM_STAGED_FAR_BLOCKS counts distances in units of this many rows
-constexpr int kStagedWaves = 16;
-constexpr int kStagedLdsBytes = 64 * 1024;
+constexpr int kStagedMaxWaves = 16;      // wavefronts per block: 4, 8 or 16 (StagedShape)
+constexpr int kStagedLdsPerWave = 4096;  // bytes of staged B rows per wavefront of the block (16 wavefronts: 64 KB)
 constexpr int kStagedPad = 64;
 constexpr int kStagedMaxRow = 2048;  // longer rows are walked by the streaming kernel's long-row pass, not by one wavefront
 struct StagedArgs {
     const int32_t* rowptr;    // clustered matrix
     const int32_t* ev;        // 2 * (nnz + kStagedPad) words
     const int32_t* perm;      // C row of clustered row i
-    const int32_t* tasks;     // nblocks * kStagedWaves int4
-    const int32_t* hot_cols;  // nblocks * H (H = staged_rows_per_block_lds(N))
+    const int32_t* tasks;     // nblocks * waves int4
+    const int32_t* hot_cols;  // nblocks * H (H = staged_shape(N).slots)
     const int32_t* nhot;      // nblocks
     const float* B;
     float* C;
     int32_t nblocks;
+    int32_t waves;            // wavefronts (= tasks) per block the tables were built for
+    int32_t debug;            // experiments only (GESPMM_STAGED_DEBUG): 1 = skip the staging copy, 2 = every gather from LDS — WRONG results;
+                              // 4 = phase clocks summed into dbg_clk
+    unsigned long long* dbg_clk;
 };
-int staged_rows_per_block_lds(int64_t N);  // H for this width; 0 = width not served
-int staged_block_rows(int64_t N);          // rows per block: 96 at N = 128, 64 for 256-column tiles (profiles/r03/staged_rows.log)
+// Shape of a block at width N: `waves` wavefronts (0 = width not served) own `rows` consecutive rows of the clustered matrix and
+// stage up to `slots` B rows (waves x 4 KB of LDS). GESPMM_STAGED_WAVES / GESPMM_STAGED_ROWS override it for experiments.
+struct StagedShape {
+    int waves, rows, slots;
+};
+StagedShape staged_shape(int64_t N);
+inline int staged_rows_per_block_lds(int64_t N) { return staged_shape(N).slots; }  // H for this width; 0 = width not served
+inline int staged_block_rows(int64_t N) { return staged_shape(N).rows; }
 bool staged_serves(int64_t K, int64_t N);  // width served and B addressable (32-bit offsets; two 4 GB halves for the tiled widths)
 hipError_t launch_spmm_staged(const StagedArgs& a, int64_t K, int64_t N, hipStream_t st);
 

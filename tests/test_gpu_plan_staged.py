@@ -287,34 +287,3 @@ def test_b_beyond_4gb_takes_the_two_halves_base(pkg, oracle):
         assert np.array_equal(bits(got[r:r + 1].cpu().numpy()), bits(ref)), r
     # beyond 8 GB the staged kernel is not offered: the plan falls back to the streaming kernels
     assert pkg._lib.plan_policy(M, 4_300_000, colind.size, 512, 40, 0.0, 0.9, 0.9, kernel=pkg._lib.PLAN_KERNEL_STAGED)["build_staged"] == 0
-
-
-def test_far_marks_keep_the_bits(pkg):
-    """`nt` gathers for far columns are off by default since round 4 (profiles/r04/far_marks_by_graph.log); the marked path stays in the
-    kernel behind GESPMM_STAGED_FAR_BLOCKS (read once per process, hence the subprocess) and must still give the plain call's bits."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys
-sys.path.insert(0, %r)
-import torch
-import gespmm_amd
-from gespmm_amd import graphs, spmm
-g = graphs.synthetic_graph("products-sbm", seed=42, device="cuda", scale=0.02)
-rp, ci, K, M, nnz = g["rowptr"], g["colind"], g["K"], g["M"], g["nnz"]
-val = torch.rand(nnz, device="cuda") - 0.5
-for N in (128, 256, 512):
-    B = torch.rand(K, N, device="cuda") - 0.5
-    p = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x100)
-    assert "kernel=staged-rows" in p.describe(), p.describe()
-    got = spmm.csr_spmm(rp, ci, val, B, plan=p)
-    want = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": 0x100})
-    assert torch.equal(got.view(torch.int32), want.view(torch.int32)), N
-print("far marks ok")
-''' % root
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GESPMM_STAGED_FAR_BLOCKS="2"), capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "far marks ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
