@@ -136,6 +136,144 @@ def roof_gflops(M, K, N, nnz, valued=True):
     return min(2.0 * nnz * N / (ab / (HBM_PEAK_GBS * 1e9)) / 1e9, FP32_VALU_PEAK_TFLOPS * 1e3)
 
 
+class BenchEnv:
+    """What the measured code needs from its surroundings: the device, the process group, event timing, seeded operands, the
+    sampled-row checker — and the PRODUCT itself (`make_plan` / `product`). main() builds it on a HIP device with the library as
+    the product; tests/test_graphs_and_dist.py builds it on the host under gloo with its checker injected as the product, so that
+    every N > 1 branch of run_rmat() (rank-local generation, equal / ragged B shards, the panel pipeline, the record) runs in the
+    CPU suite before an 8-GPU node ever sees it. bench.py itself never supplies a host product."""
+
+    def __init__(self, torch, dist, dev, world, rank, use_dist, variant=-1, product=None, make_plan=None, on_local_product=None):
+        self.torch, self.dist, self.dev = torch, dist, torch.device(dev)
+        self.world, self.rank, self.use_dist, self.variant = world, rank, use_dist, variant
+        self.cuda = self.dev.type == "cuda"
+        self._product, self._make_plan, self.on_local_product = product, make_plan, on_local_product
+        self.injected_product = product  # handed to PanelPipeline (None = the HIP path)
+
+    # ---- the product
+    def make_plan(self, rowptr, colind, K, N, val):
+        if self._make_plan is not None:
+            return self._make_plan(rowptr, colind, K, N, val)
+        if self._product is not None:
+            return None
+        from gespmm_amd import spmm
+
+        return spmm.SpmmPlan(rowptr, colind, K, N, variant=self.variant, values=val, reorder=False)
+
+    def product(self, rowptr, colind, val, B, out, plan=None):
+        if self._product is not None:
+            return self._product(rowptr, colind, val, B, out)
+        from gespmm_amd import spmm
+
+        return spmm.csr_spmm(rowptr, colind, val, B, variant=self.variant, out=out, plan=plan)
+
+    # ---- device plumbing
+    def device_sync(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def sync_all(self):
+        self.device_sync()
+        if self.use_dist:
+            self.dist.barrier()
+            self.device_sync()
+
+    def empty_cache(self):
+        if self.cuda:
+            self.torch.cuda.empty_cache()
+
+    def free_bytes(self):
+        if self.cuda:
+            return self.torch.cuda.mem_get_info(self.dev)[0]
+        return 1 << 62
+
+    def generator(self, seed):
+        g = self.torch.Generator(device=self.dev)
+        g.manual_seed(seed)
+        return g
+
+    def make_B(self, K, N, seed=None):
+        torch = self.torch
+        gB = self.generator(1000 + N if seed is None else seed)
+        out = torch.empty((K, N), dtype=torch.float32, device=self.dev)
+        step = max(1, (1 << 28) // max(N, 1))  # bounded int32 temporaries for the 64-GiB operands
+        for r0 in range(0, K, step):
+            r1 = min(K, r0 + step)
+            # reference value set: float(r % 100 - 50) / 100 (spmm_test.cu:586-594)
+            out[r0:r1] = (torch.randint(0, 100, (r1 - r0, N), generator=gB, device=self.dev, dtype=torch.int32) - 50).float() / 100
+        return out
+
+    def kernel_times_us(self, fn, n):
+        """Each launch between its own pair of HIP events on the launch stream (the torch current stream IS the stream
+        handed to the C ABI). (Host environment of the CPU suite: wall clock per call.)"""
+        torch = self.torch
+        n = max(int(n), 1)
+        if not self.cuda:
+            out = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                fn()
+                out.append((time.perf_counter() - t0) * 1e6)
+            return out
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        torch.cuda.synchronize()
+        for i in range(n):
+            starts[i].record()
+            fn()
+            ends[i].record()
+        torch.cuda.synchronize()
+        return [s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends)]
+
+    def max_over_ranks(self, seconds):
+        if not self.use_dist:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_region(self, fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        self.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.sync_all()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def verify(self, rowptr, colind, val, B, C, nrows=512, tolerant=False):
+        """Sampled rows against the CPU oracle (checker only, outside every timed region): bit for bit; with `tolerant`
+        (matrices whose hub rows take the long-row pass, a re-association) rows that differ must be within
+        1e-4 * max(|ref|, sum |a*b|) and the counts are reported."""
+        torch, dev = self.torch, self.dev
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import numpy as np
+
+        import oracle_py
+
+        M = rowptr.numel() - 1
+        rng = np.random.RandomState(0)
+        rows = np.sort(rng.choice(M, min(nrows, M), replace=False))
+        rph = rowptr.cpu().numpy()
+        sub_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
+        sub_ptr[1:] = np.cumsum(rph[rows + 1] - rph[rows])
+        sel = torch.from_numpy(np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows]).astype(np.int64)).to(dev)
+        cih = colind[sel].cpu().numpy()
+        vh = val[sel].cpu().numpy() if val is not None else None
+        cols_u, inv = np.unique(cih, return_inverse=True)  # only the B rows these CSR rows touch travel to the host
+        Bsub = B[torch.from_numpy(cols_u.astype(np.int64)).to(dev)].cpu().numpy()
+        ref = oracle_py.spmm(sub_ptr, inv.astype(np.int32), vh, Bsub, "fma")
+        got = C[torch.from_numpy(rows).to(dev)].cpu().numpy()
+        same = (got.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
+        if not tolerant:
+            return bool(same.all())
+        scale = oracle_py.spmm_abs(sub_ptr, inv.astype(np.int32), vh, Bsub)
+        close = (np.abs(got - ref) <= 1e-4 * np.maximum(np.abs(ref), scale) + 1e-12).all(axis=1)
+        return {"rows": int(len(rows)), "bit_exact": int(same.sum()), "within_1e-4": int((close & ~same).sum()),
+                "failed": int((~close).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +290,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--panel-cols", type=int, default=128, help="column panel of the exchange/compute pipeline")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the several-GPU run (nccl = RCCL on ROCm)")
     args = ap.parse_args()
 
     import torch
@@ -179,87 +318,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # torchrun with 1 process still exercises RCCL
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
 
     graph = args.graph or ("rmat" if world > 1 else "com-amazon-sbm")
     strong = graph == "rmat"
     N = args.ncols or (256 if strong else 128)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def make_B(K, N, seed=None):
-        gB = torch.Generator(device=dev)
-        gB.manual_seed(1000 + N if seed is None else seed)
-        out = torch.empty((K, N), dtype=torch.float32, device=dev)
-        step = max(1, (1 << 28) // max(N, 1))  # bounded int32 temporaries for the 64-GiB operands
-        for r0 in range(0, K, step):
-            r1 = min(K, r0 + step)
-            # reference value set: float(r % 100 - 50) / 100 (spmm_test.cu:586-594)
-            out[r0:r1] = (torch.randint(0, 100, (r1 - r0, N), generator=gB, device=dev, dtype=torch.int32) - 50).float() / 100
-        return out
-
-    def kernel_times_us(fn, n):
-        """Each launch between its own pair of HIP events on the launch stream (the torch current stream IS the stream
-        handed to the C ABI)."""
-        n = max(int(n), 1)
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-        torch.cuda.synchronize()
-        for i in range(n):
-            starts[i].record()
-            fn()
-            ends[i].record()
-        torch.cuda.synchronize()
-        return [s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends)]
-
-    def timed_region(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        sync_all()
-        wall = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([wall], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t.item())
-        return wall
-
-    def verify(rowptr, colind, val, B, C, nrows=512, tolerant=False):
-        """Sampled rows against the CPU oracle (checker only, outside every timed region): bit for bit; with `tolerant`
-        (matrices whose hub rows take the long-row pass, a re-association) rows that differ must be within
-        1e-4 * max(|ref|, sum |a*b|) and the counts are reported."""
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import numpy as np
-
-        import oracle_py
-
-        M = rowptr.numel() - 1
-        rng = np.random.RandomState(0)
-        rows = np.sort(rng.choice(M, min(nrows, M), replace=False))
-        rph = rowptr.cpu().numpy()
-        sub_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
-        sub_ptr[1:] = np.cumsum(rph[rows + 1] - rph[rows])
-        sel = torch.from_numpy(np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows]).astype(np.int64)).to(dev)
-        cih = colind[sel].cpu().numpy()
-        vh = val[sel].cpu().numpy() if val is not None else None
-        cols_u, inv = np.unique(cih, return_inverse=True)  # only the B rows these CSR rows touch travel to the host
-        Bsub = B[torch.from_numpy(cols_u.astype(np.int64)).to(dev)].cpu().numpy()
-        ref = oracle_py.spmm(sub_ptr, inv.astype(np.int32), vh, Bsub, "fma")
-        got = C[torch.from_numpy(rows).to(dev)].cpu().numpy()
-        same = (got.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
-        if not tolerant:
-            return bool(same.all())
-        scale = oracle_py.spmm_abs(sub_ptr, inv.astype(np.int32), vh, Bsub)
-        close = (np.abs(got - ref) <= 1e-4 * np.maximum(np.abs(ref), scale) + 1e-12).all(axis=1)
-        return {"rows": int(len(rows)), "bit_exact": int(same.sum()), "within_1e-4": int((close & ~same).sum()),
-                "failed": int((~close).sum())}
+    env = BenchEnv(torch, dist, dev, world, rank, use_dist, variant=args.variant)
+    sync_all, make_B, kernel_times_us, timed_region, verify = env.sync_all, env.make_B, env.kernel_times_us, env.timed_region, env.verify
 
     def measure_graph(g, val, N, valued=True, use_plan=True, samples=MIN_KERNEL_SAMPLES, keep=False):
         """Median kernel time of one (graph, width) through a plan (or the plain entry point)."""
@@ -348,8 +414,7 @@ def main():
 
     # =============================================================================================== several GPUs
     if strong:
-        out = run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, make_B, kernel_times_us, timed_region,
-                       sync_all, verify)
+        out = run_rmat(args, env, N)
         if rank == 0:
             emit(out)
         if use_dist:
@@ -529,8 +594,8 @@ def main():
             rscale = 26 if free_b > (170 << 30) else 24
             rargs = argparse.Namespace(**vars(args))
             rargs.rmat_scale, rargs.steps, rargs.warmup = rscale, 5, 2
-            rline = run_rmat(rargs, torch, dist, graphs, spmm, dev, 1, 0, False, 256, make_B, kernel_times_us, timed_region,
-                             sync_all, verify, with_cpu_baseline=not args.no_cpu_baseline)
+            rline = run_rmat(rargs, BenchEnv(torch, dist, dev, 1, 0, False, variant=args.variant), 256,
+                             with_cpu_baseline=not args.no_cpu_baseline)
             extra["rmat-%d_N256_valued" % rscale] = {
                 "kernel_us": rline["roofline"]["kernel_us"], "ms_per_step": rline["ms_per_step"], "gflops": rline["value"],
                 "achieved_GBs": rline["roofline"]["achieved"], "frac": rline["roofline"]["frac"],
@@ -856,21 +921,21 @@ def rmat_cpu_baseline(torch, g, N):
                       (len(rows), 100.0 * len(rows) / M, fl / 1e9, len(cols_u))}
 
 
-def run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, make_B, kernel_times_us, timed_region, sync_all,
-             verify, with_cpu_baseline=False):
-    """ONE RMAT graph, nnz-balanced contiguous row shards, B replicated by all-gather: the north_star experiment."""
+def run_rmat(args, env, N, with_cpu_baseline=False):
+    """ONE RMAT graph, nnz-balanced contiguous row shards, B replicated by all-gather: the north_star experiment.
+    `env` (BenchEnv) carries the device, the process group and the product — see its docstring."""
     from gespmm_amd import dist as gdist
+    from gespmm_amd import graphs
 
+    torch, dist, dev, world, rank, use_dist = env.torch, env.dist, env.dev, env.world, env.rank, env.use_dist
     scale = args.rmat_scale or 26
     t0 = time.perf_counter()
     g = graphs.rmat_shard(scale, args.edge_factor, rank, world, seed=42, device=dev)
-    torch.cuda.synchronize()
+    env.device_sync()
     gen_s = time.perf_counter() - t0
     M, K, nnz = g["M"], g["K"], g["nnz"]
     rowptr, colind = g["rowptr"], g["colind"]
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(7 + rank)
-    val = torch.rand(nnz, generator=gen, device=dev) - 0.5
+    val = torch.rand(nnz, generator=env.generator(7 + rank), device=dev) - 0.5
     if use_dist:
         tn = torch.tensor([nnz], dtype=torch.int64, device=dev)
         dist.all_reduce(tn)
@@ -880,28 +945,30 @@ def run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, mak
 
     # ---- every rank owns K/world rows of B (its own seed); one all-gather replicates them
     k0, k1 = (K * rank) // world, (K * (rank + 1)) // world
-    B_shard = make_B(k1 - k0, N, seed=5000 + rank)
+    B_shard = env.make_B(k1 - k0, N, seed=5000 + rank)
     counts = [(K * (r + 1)) // world - (K * r) // world for r in range(world)]
-    sync_all()
+    env.sync_all()
     t0 = time.perf_counter()
     B = gdist.exchange_dense(B_shard, counts) if use_dist else B_shard
-    sync_all()
+    env.sync_all()
     exchange_ms = (time.perf_counter() - t0) * 1e3 if use_dist else 0.0
 
     # ---- kernel only: B resident (the BENCH line's convention)
     C = torch.empty((M, N), dtype=torch.float32, device=dev)
-    plan = spmm.SpmmPlan(rowptr, colind, K, N, variant=args.variant, values=val, reorder=False)
+    plan = env.make_plan(rowptr, colind, K, N, val)
 
     def step():
-        spmm.csr_spmm(rowptr, colind, val, B, variant=args.variant, out=C, plan=plan)
+        env.product(rowptr, colind, val, B, C, plan)
 
     for _ in range(max(args.warmup, 1)):
         step()
-    us = kernel_times_us(step, max(args.steps, 5))
-    wall = timed_region(step, args.steps, 0)
+    us = env.kernel_times_us(step, max(args.steps, 5))
+    wall = env.timed_region(step, args.steps, 0)
     value = 2.0 * nnz_total * N * args.steps / wall / 1e9
     med = statistics.median(us)
-    verified = verify(rowptr, colind, val, B, C, nrows=256, tolerant=True) if rank == 0 else None
+    verified = env.verify(rowptr, colind, val, B, C, nrows=256, tolerant=True) if rank == 0 else None
+    if env.on_local_product is not None:  # (the CPU suite gathers the shards' rows and compares them with the unsharded product)
+        env.on_local_product(g, val, B, C)
     abytes = algorithmic_bytes(M, K, N, nnz, True)
     srows = torch.randperm(M, device=dev)[:4096]
     C_sample = C[srows].clone()
@@ -911,26 +978,25 @@ def run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, mak
     e2e = None
     pc = max(4, min(args.panel_cols, N))
     need = 4.0 * ((k1 - k0) * N + 2 * K * pc + M * N) * 1.02  # panel copies of the shard, two panel buffers, C panels
-    if use_dist and need > torch.cuda.mem_get_info(dev)[0] + 4.0 * K * N:
+    if use_dist and need > env.free_bytes() + 4.0 * K * N:
         e2e = {"skipped": "panel buffers exceed free HBM at this scale on %d GPU(s)" % world}
     elif use_dist:
         def end_to_end():
             nonlocal B, plan
             del B, plan
-            torch.cuda.empty_cache()
+            env.empty_cache()
             panels = [(c0, min(c0 + pc, N)) for c0 in range(0, N, pc)]
-            pipe = gdist.PanelPipeline(rowptr, colind, val, K, counts, [c1 - c0 for c0, c1 in panels], dev, variant=args.variant)
+            pipe = gdist.PanelPipeline(rowptr, colind, val, K, counts, [c1 - c0 for c0, c1 in panels], dev, variant=env.variant,
+                                       product=env.injected_product)
             shard_panels = [B_shard[:, c0:c1].contiguous() for c0, c1 in panels]
             pipe.run(shard_panels)  # warm
-            sync_all()
+            env.sync_all()
             reps = max(1, min(args.steps, 3))
             t0 = time.perf_counter()
             for _ in range(reps):
                 Cp = pipe.run(shard_panels)
-            sync_all()
-            t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2e_s = float(t.item())
+            env.sync_all()
+            e2e_s = env.max_over_ranks((time.perf_counter() - t0) / reps)
             # panel results against the resident-B product on sampled rows (hub rows take the long-row pass, whose chunk sums
             # are grouped by the lane geometry of the width: those rows agree to rounding, all others bit for bit)
             same, worst = 0, 0.0
@@ -943,12 +1009,11 @@ def run_rmat(args, torch, dist, graphs, spmm, dev, world, rank, use_dist, N, mak
                    "max_rel_diff_vs_resident_product": worst,
                    "note": "all-gather of panel p+1 on a second stream while panel p is multiplied; exchange inside the timed region"}
 
-
         try:
             e2e = end_to_end()
         except Exception as ex:  # noqa: BLE001 - the kernel-only line above must still be reported
             e2e = {"failed": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-            torch.cuda.empty_cache()
+            env.empty_cache()
 
     L = 64
     kernel_s = wall / args.steps

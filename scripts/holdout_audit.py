@@ -21,7 +21,7 @@ import gespmm_amd  # noqa: F401,E402
 from gespmm_amd import graphs, spmm  # noqa: E402
 
 dev = torch.device("cuda")
-HOLD = os.path.join(ROOT, "profiles", "r04", "holdout")
+HOLD = os.environ.get("GESPMM_HOLDOUT_DIR", os.path.join(ROOT, "profiles", "r05", "holdout"))
 
 
 def timeit(fn, iters):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Hold-out graphs for the plan heuristics (missing 3): generators this repository did NOT write and whose
 parameters were not fitted against the plan's clustering — networkx 3.4 (LFR benchmark, Holme-Kim, Newman-Watts-Strogatz,
-Barabasi-Albert, random geometric). Runs on the CPU (minutes), writes profiles/r04/holdout/<name>.npz (edge list u < v,
+Barabasi-Albert, random geometric). Runs on the CPU (minutes), writes $GESPMM_HOLDOUT_DIR/<name>.npz (default profiles/r05/holdout) (edge list u < v,
 vertex ids SHUFFLED by a seeded permutation so no locality is inherited from the generator's construction order).
     python scripts/holdout_graphs.py [name ...]
 """
@@ -13,7 +13,7 @@ import networkx as nx
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "profiles", "r04", "holdout")
+OUT = os.environ.get("GESPMM_HOLDOUT_DIR", os.path.join(ROOT, "profiles", "r05", "holdout"))
 
 CASES = {
     # LFR: power-law degrees (tau1) AND community sizes (tau2), mixing mu = share of a vertex's edges that leave its community

@@ -165,3 +165,70 @@ def test_rmat_shards_tile_the_global_graph(pkg):
             assert list(cut) == parts[0]["cuts"]
     deg = (full["rowptr"][1:] - full["rowptr"][:-1])
     assert int(deg.max()) > 20 * float(deg.float().mean()), "RMAT is heavy-tailed"
+
+
+def _bench_rmat_worker(rank, world, port, tmpdir):
+    """bench.py's several-GPU mode (run_rmat: rank-local RMAT shards, B exchange, kernel-only loop, panel pipeline, the record)
+    under gloo on the host: the checker is INJECTED as the product (tests only — bench.py never supplies a host product)."""
+    import argparse
+    import json
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bench
+    import oracle_py
+
+    from gespmm_amd import graphs
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def host_product(rowptr_, colind_, val_, B_, out):
+        out.copy_(torch.from_numpy(oracle_py.spmm(rowptr_.numpy(), colind_.numpy(), val_.numpy(), B_.contiguous().numpy(), "fma")))
+        return out
+
+    scale, ef, N = 12, 16, 20
+    whole_ok = []
+
+    def on_local_product(g, val, B, C):
+        pieces = [None] * world
+        dist.all_gather_object(pieces, (g["row_begin"], g["row_end"], val.numpy(), C.numpy().copy()))
+        if rank != 0:
+            return
+        pieces.sort(key=lambda t: t[0])
+        assert pieces[0][0] == 0 and pieces[-1][1] == 1 << scale
+        assert all(pieces[i][1] == pieces[i + 1][0] for i in range(world - 1)), "contiguous row shards"
+        full = graphs.rmat_shard(scale, ef, 0, 1, seed=42)
+        vals = np.concatenate([p[2] for p in pieces])
+        assert vals.shape[0] == full["nnz"] == ef << scale
+        ref = oracle_py.spmm(full["rowptr"].numpy(), full["colind"].numpy(), vals, B.numpy(), "fma")
+        got = np.concatenate([p[3] for p in pieces])
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "shard rows concatenate to the unsharded product"
+        whole_ok.append(True)
+
+    env = bench.BenchEnv(torch, dist, "cpu", world, rank, True, product=host_product, on_local_product=on_local_product)
+    args = argparse.Namespace(rmat_scale=scale, edge_factor=ef, steps=2, warmup=1, panel_cols=8, variant=-1)
+    out = bench.run_rmat(args, env, N)
+    if rank == 0:
+        assert whole_ok == [True]
+        line = json.loads(bench.compact_line(out))
+        assert line["n_gpus"] == world and line["scaling"] == "strong" and line["value"] > 0
+        assert line["config"]["nnz_per_gpu"] > 0 and "RMAT scale 12" in line["config"]["workload"]
+        e2e = line["exchange"]["end_to_end"]
+        assert e2e["panels"] == 3 and e2e["panel_cols"] == 8, e2e
+        assert e2e["sampled_rows_bit_equal_resident_product"] == "%d of %d" % (3 * out["config"]["rows_per_gpu"], 3 * out["config"]["rows_per_gpu"])
+        assert line["exchange"]["bytes_received_per_gpu"] > 0 and line["exchange"]["amortised_over_L"]["L"] == 64
+        assert "one_gpu_reference" in line and "rmat-12_N256" in line["one_gpu_reference"]
+        assert line["verified_vs_oracle"]["failed"] == 0
+        assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
+        open(os.path.join(tmpdir, "ok%d" % world), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])  # 2: equal B shards (all-gather); 3: ragged shards (one broadcast per owner)
+def test_bench_rmat_mode_under_gloo(tmp_path, world, pkg):
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_bench_rmat_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / ("ok%d" % world)).exists()
