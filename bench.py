@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3
 MIN_KERNEL_SAMPLES = 200  # the reference times 200 launches (ITER, spmm_test.cu:714)
 
-COPY_RATE_GBS = 5600.0  # read + write copy on this chip: profiles/r02/write_bandwidth.log (fill 6.7, read 5.1-6.6, copy 5.6 TB/s)
+COPY_RATE_GUIDE_GBS = 6290.0  # MI355X_MICROARCH.md:35 — measured copy rate of the chip; the sanity bound for the rate measured in the run
 LINE_LIMIT = 4096  # the final stdout line stays below this; everything else goes to EXTRA_FILE (and to stderr)
 EXTRA_FILE = os.path.join("profiles", "bench_extra_last.json")
 
@@ -374,23 +374,60 @@ def main():
             return out, step, B, C, plan
         return out
 
+    def measure_copy_rate():
+        """Read + write rate of THIS box: the library's streaming-copy yardstick (gespmm_baseline_copy_f32) on 200 MB, 20 launches
+        between one pair of events after 3 warm ones — outside every timed region. Bounded by the guide's figure."""
+        n = 50 * 1000 * 1000
+        src = torch.empty(n, dtype=torch.float32, device=dev).uniform_(-1, 1)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            spmm.baseline_copy(src, out=dst)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            spmm.baseline_copy(src, out=dst)
+        e1.record()
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(src, dst))
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        gbs = 8.0 * n / us / 1e3
+        del src, dst
+        how = "200 MB read + 200 MB written per launch, %.1f us, 20 launches%s" % (us, "" if ok else ", COPY WRONG")
+        if gbs > 1.15 * COPY_RATE_GUIDE_GBS or gbs < 0.5 * COPY_RATE_GUIDE_GBS:  # a broken measurement must not price the ceiling
+            return {"GBs": COPY_RATE_GUIDE_GBS, "how": "guide's figure (the run measured %.0f GB/s: out of the sanity range)" % gbs,
+                    "measured_GBs": gbs}
+        return {"GBs": gbs, "how": how, "measured_GBs": gbs}
+
+    copy_rate = None if strong else measure_copy_rate()  # (the several-GPU mode prices no ceiling)
+
     def ceiling_for(gx, n, frac):
-        """Where the planted structure of a stand-in caps `frac`: every B row fetched ONCE per planted group that refers to it
-        (perfect reuse inside a group, none across: the edges that leave a group go to uniformly drawn rows, and a group's rows
-        are ~170 KB of a 4 MB L2), C written once, the CSR arrays read once — moved at the rate a plain copy reaches."""
-        if "truth_group" not in gx:
+        """Where the planted structure of a stand-in caps `frac`: every B row fetched ONCE per planted unit that refers to it
+        (perfect reuse inside a unit, none across: the edges that leave it go to uniformly drawn rows), C written once, the CSR
+        arrays read once — moved at the copy rate measured in this run. The unit is the coarsest planted level whose rows of B
+        fit an XCD's L2 at this width (3 MiB of the 4): the GROUP (com-Amazon-shaped: ~330 rows, products-shaped: ~1200), or the
+        COMMUNITY where a group is larger than that (reddit-shaped: groups of 14 500 rows, communities of ~800)."""
+        if "truth_group" not in gx or copy_rate is None:
             return {}
         Mx, nz = gx["M"], gx["nnz"]
-        rp = gx["rowptr"].long()
-        rows = torch.repeat_interleave(torch.arange(Mx, device=rp.device), rp[1:] - rp[:-1])
-        pairs = int(torch.unique(gx["truth_group"][rows] * gx["K"] + gx["colind"].long()).numel())
         lines_per_row = (4 * n + 127) // 128
+        cache = gx.setdefault("_pairs", {})
+        ngroups = int(gx["truth_group"].max()) + 1
+        level = "group" if (Mx / max(ngroups, 1)) * 128 * lines_per_row <= (3 << 20) else "community"
+        if level not in cache:
+            rp = gx["rowptr"].long()
+            unit = gx["truth_group"] if level == "group" else gx["truth_community"] + gx["truth_group"] * (int(gx["truth_community"].max()) + 1)
+            keys = torch.repeat_interleave(unit.long(), rp[1:] - rp[:-1]) * gx["K"] + gx["colind"].long()
+            cache[level] = int(torch.unique(keys).numel())
+            del keys
+        pairs = cache[level]
         floor = 128 * lines_per_row * pairs + 4 * Mx * n + 4 * (Mx + 1) + 8 * nz
         ab = algorithmic_bytes(Mx, gx["K"], n, nz, True)
-        ceil = ab / (floor / COPY_RATE_GBS) / HBM_PEAK_GBS
+        ceil = ab / (floor / copy_rate["GBs"]) / HBM_PEAK_GBS
         return {"traffic_floor": floor, "ceiling_frac": ceil, "achieved_over_ceiling": frac / ceil,
-                "ceiling_note": "alg bytes / (traffic_floor / %.1f TB/s copy rate) / 8 TB/s; floor = every B row once per planted "
-                                "group that refers to it (%d pairs) + C + CSR" % (COPY_RATE_GBS / 1e3, pairs)}
+                "ceiling_note": "alg bytes / (traffic_floor / copy rate) / 8 TB/s; copy rate %.2f TB/s measured in this run (%s; the "
+                                "guide's figure is %.2f); floor = every B row once per planted %s that refers to it (%d pairs) "
+                                "+ C + CSR" % (copy_rate["GBs"] / 1e3, copy_rate["how"], COPY_RATE_GUIDE_GBS / 1e3, level, pairs)}
 
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -408,7 +445,7 @@ def main():
             return None, None, None
         if e.get("csrc_sha16") != csrc_now:
             sys.stderr.write("bench.py: profiles/hbm_traffic.json[%s] was captured at csrc %s, the tree is at %s: "
-                             "traffic not reported (re-run scripts/gpu_pmc_bench.sh)\n" % (key, e.get("csrc_sha16"), csrc_now))
+                             "traffic not reported (re-capture: scripts/gpu_pmc.sh + scripts/update_traffic_json.py)\n" % (key, e.get("csrc_sha16"), csrc_now))
             return None, "stale: captured at csrc %s, tree at %s" % (e.get("csrc_sha16"), csrc_now), None
         return e.get("bytes_per_launch"), e.get("source"), e.get("l2_hit_rate")
 
@@ -475,6 +512,8 @@ def main():
                     tw_, _, hw_ = traffic_for("%s/N%d/valued/plan" % (graph, n2))
                     widths["N%d" % n2] = {"kernel_us": rw["kernel_us"], "gflops": rw["gflops"], "frac": rw["frac"], "traffic": tw_,
                                           "l2_hit_rate": hw_}
+                    widths["N%d" % n2].update({k: v for k, v in ceiling_for(g, n2, rw["frac"]).items()
+                                               if k in ("ceiling_frac", "achieved_over_ceiling")})
         extra["N%d_unweighted" % N] = measure_graph(g, val, N, False, samples=50)
 
         if graph in ("com-amazon-sbm", "com-amazon-like") and args.locality == 0.0:
@@ -523,6 +562,7 @@ def main():
             r2s["plain_call_kernel_us"] = measure_graph(g2s, val2s, N, True, use_plan=False, samples=10)["kernel_us"]
             r2s["note"] = ("232 965 rows, 114.6 M entries, 290 planted communities (~800 rows, ~330 of a row's 492 entries inside), ids "
                           "shuffled: graphs.synthetic_graph('reddit-sbm')")
+            r2s.update(ceiling_for(g2s, N, r2s["frac"]))
             extra["reddit-sbm_N%d_valued" % N] = r2s
             del g2s, val2s, B2s, C2s, plan2s, step2s, rpr, cir
 
@@ -571,6 +611,7 @@ def main():
                         row["plan"].update({"traffic": tb, "traffic_source": tsrc, "l2_hit_rate": thit,
                                             "traffic_GBs": (tb / row["plan"]["kernel_us"] / 1e3) if tb else None,
                                             "algorithmic_bytes_per_launch": ab3})
+                    row["plan"].update({k: v for k, v in ceiling_for(g3, n3, row["plan"]["frac"]).items() if k != "ceiling_note"})
                     sweep["N%d" % n3] = row
                     del B3, C3
                 extra["%s_sweep_valued" % pname] = sweep
@@ -736,6 +777,7 @@ def main():
             "extra": extra,
         }
         out["roofline"].update(ceiling_for(g, N, head["frac"]))
+        out["roofline"]["copy_rate_GBs"] = copy_rate
         out["config"]["kernel"] = (head.get("plan") or "").split("|")[-1].strip()[:120] if head.get("plan") else "plain call"
         emit(out)
     if use_dist:
@@ -751,13 +793,20 @@ def other_configs(extra):
     def put(name, e):
         if isinstance(e, dict) and "kernel_us" in e:
             out[name] = {"ms": _r(e["kernel_us"] / 1e3, 2), "frac": _r(e.get("frac"), 2)}
+            if e.get("ceiling_frac") is not None:  # stand-ins with planted structure: where that structure caps frac, and how close
+                out[name]["ceil"] = _r(e["ceiling_frac"], 2)
+                out[name]["of_ceil"] = _r(e["achieved_over_ceiling"], 2)
 
     for k, e in extra.items():
         if k.startswith(("reddit-", "cit-hepth", "pubmed", "rmat-")):
             put(k.replace("_valued", "").replace("_unweighted", ""), e)
         if k.endswith("_sweep_valued"):
-            out[k.replace("_sweep_valued", "_plan_ms")] = {w: _r(r["plan"]["kernel_us"] / 1e3, 2) for w, r in e.items()
-                                                          if isinstance(r, dict) and "plan" in r and isinstance(r["plan"], dict)}
+            rows_ = {w: r for w, r in e.items() if isinstance(r, dict) and "plan" in r and isinstance(r["plan"], dict)}
+            out[k.replace("_sweep_valued", "_plan_ms")] = {w: _r(r["plan"]["kernel_us"] / 1e3, 2) for w, r in rows_.items()}
+            if any("ceiling_frac" in r["plan"] for r in rows_.values()):  # frac / ceiling_frac / achieved_over_ceiling per width
+                out[k.replace("_sweep_valued", "_frac_ceil_ofceil")] = {
+                    w: [_r(r["plan"]["frac"], 2), _r(r["plan"]["ceiling_frac"], 2), _r(r["plan"]["achieved_over_ceiling"], 2)]
+                    for w, r in rows_.items() if "ceiling_frac" in r["plan"]}
     return out
 
 

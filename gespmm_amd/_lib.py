@@ -58,6 +58,7 @@ EXPORTS = [
     "gespmm_coo_to_csr",
     "gespmm_row_partition",
     "gespmm_baseline_atomic_scatter_f32",
+    "gespmm_baseline_copy_f32",
     "gespmm_plan_create",
     "gespmm_plan_spmm_f32",
     "gespmm_plan_spmm_max_f32",
@@ -173,6 +174,8 @@ def _load():
     lib.gespmm_coo_to_csr.argtypes = [c_int32, c_int32, c_int64, p, p, p, p, p, p]
     lib.gespmm_baseline_atomic_scatter_f32.restype = c_int
     lib.gespmm_baseline_atomic_scatter_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, p]
+    lib.gespmm_baseline_copy_f32.restype = c_int
+    lib.gespmm_baseline_copy_f32.argtypes = [p, p, c_int64, p]
     lib.gespmm_plan_create.restype = c_int
     lib.gespmm_plan_create.argtypes = [POINTER(c_void_p), p, p, p, c_int64, c_int64, c_int64, c_int64, c_int,
                                        POINTER(PlanOptions), p]

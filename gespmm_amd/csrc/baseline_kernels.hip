@@ -47,7 +47,39 @@ __global__ __launch_bounds__(kThreads) void atomic_scatter_kernel(const int32_t*
     }
 }
 
+// Yardstick, not a product path: a plain streaming copy (one dwordx4 load + one dwordx4 store per lane and step, grid-stride,
+// 16 workgroups per CU). bench.py times it in the same process as the product to price `roofline.ceiling_frac` with the rate
+// THIS box reaches for read + write traffic (MI355X_MICROARCH.md quotes 6.29 TB/s for a copy; boxes differ by a few percent).
+__global__ __launch_bounds__(kThreads) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ void copy_tail_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t begin, int64_t n) {
+    const int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 }  // namespace
+
+hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    if (n4 > 0) {
+        int64_t blocks = (n4 + kThreads - 1) / kThreads;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(src),
+                           reinterpret_cast<float4*>(dst), n4);
+    }
+    const int64_t done = n4 * 4;
+    if (done < n) {
+        const int64_t rest = n - done;
+        if (rest > (int64_t)0x7fffffff * 256) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(copy_tail_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, st, src, dst, done, n);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_atomic_scatter(const int32_t* rowptr, const int32_t* colind, const float* in, float* out, int64_t M,
                                  int64_t K, int64_t N, int64_t nnz, hipStream_t st) {

@@ -357,6 +357,14 @@ int gespmm_baseline_atomic_scatter_f32(const int32_t* rowptr, const int32_t* col
                                               reinterpret_cast<hipStream_t>(stream));
 }
 
+int gespmm_baseline_copy_f32(const float* src, float* dst, int64_t n, void* stream) {
+    if (n < 0) return GESPMM_EINVAL;
+    if (n == 0) return 0;
+    if (!src || !dst) return GESPMM_EINVAL;
+    if (!aligned_to(src, 4) || !aligned_to(dst, 4)) return GESPMM_EALIGN;
+    return (int)gespmm::launch_copy(src, dst, n, reinterpret_cast<hipStream_t>(stream));
+}
+
 int64_t gespmm_csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
     if (M < 0 || K < 0 || nnz < 0) return GESPMM_EINVAL;
     return gespmm::csr2csc_workspace_bytes(M, K, nnz);

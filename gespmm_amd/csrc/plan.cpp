@@ -78,9 +78,13 @@ struct gespmm_plan {
     gespmm::StagingTables stg;
     double staging_seconds = 0.0;
     // gespmm_plan_tune: measured kernel times on the caller's operands (us; < 0: candidate not available)
+    // The measurement is valid for the plan's own width only: launches at p->N take tuned_kernel / tuned_vec, every other width keeps
+    // the per-launch rules of plan_policy.cpp (kernel_choice stays what the creator asked for).
     bool tuned = false;
+    int tuned_kernel = 0;  // GESPMM_PLAN_KERNEL_* that won (valid while `tuned`)
+    int tuned_vec = 0;     // 1: the winner is the batch-stream kernel with 4 floats per lane (N <= 64)
+    bool staging_kept_by_policy = false;  // keep_staged_tables() said yes at creation (else the tables exist only while tune measures them / if they won)
     double tune_us[4] = {-1.0, -1.0, -1.0, -1.0};  // batch-stream, segmented-stream, staged-rows, batch-stream with 4 floats per lane (N <= 64)
-    int narrow_vec = -1;  // -1: plan_policy decides per launch; 0 / 1: fixed by gespmm_plan_tune
 };
 
 namespace {
@@ -475,6 +479,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
                 e = build_staging_tables(p, st);
                 if (e == hipSuccess && p->stg.ev && !gespmm::keep_staged_tables(f, p->stg.staged_fraction))
                     gespmm::free_staging(&p->stg);  // not enough reuse inside the blocks: the streaming kernels stay
+                p->staging_kept_by_policy = p->stg.ev != nullptr;
                 lap("staging tables");
             }
             if (e != hipSuccess) {
@@ -594,11 +599,12 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
     return 0;
 }
 
-// The 0.1 entry point: its callers were compiled against a gespmm_plan_options of SIX int32 fields (reorder .. kernel); anything
-// a newer header appended is not read through this symbol.
+// The un-versioned entry point: every header that shipped with it alone had a gespmm_plan_options of SEVEN int32 fields
+// (reorder .. analysis — round 3's 0.1 header already carried `analysis`, and this symbol honoured it), so that is what it reads;
+// anything appended later is reachable through gespmm_plan_create_v2 only.
 int gespmm_plan_create(gespmm_plan** out, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
                        int64_t K, int64_t nnz, int64_t N, int variant, const gespmm_plan_options* opt, void* stream) {
-    return gespmm_plan_create_v2(out, rowptr, colind, val, M, K, nnz, N, variant, opt, opt ? 6 * (int64_t)sizeof(int32_t) : 0, stream);
+    return gespmm_plan_create_v2(out, rowptr, colind, val, M, K, nnz, N, variant, opt, opt ? 7 * (int64_t)sizeof(int32_t) : 0, stream);
 }
 
 int gespmm_plan_create_v2(gespmm_plan** out, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
@@ -627,9 +633,16 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     int rc;
     const bool variant_v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 ||
                             p->variant == GESPMM_VARIANT_CRC_CWM8;
+    // which kernel: the creator's choice (AUTO = the rules of plan_policy.cpp, per launch width) — or, at the plan's own width,
+    // what gespmm_plan_tune measured
+    const bool use_tuned = p->tuned && N == p->N;
+    const int kchoice = use_tuned ? p->tuned_kernel : p->kernel_choice;
+    gespmm::PlanFacts facts = p->facts;
+    facts.kernel_choice = kchoice;
     // staged-rows kernel: its tables exist (the plan decided at creation), same width, sum reducer, 16-byte operands
     const bool staged = p->reordered && p->stg.ev && N == p->N && reduce == gespmm::kReduceSum && variant_v4 &&
-                        (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO || p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED) &&
+                        (use_tuned ? kchoice == GESPMM_PLAN_KERNEL_STAGED
+                                   : ((kchoice == GESPMM_PLAN_KERNEL_AUTO && p->staging_kept_by_policy) || kchoice == GESPMM_PLAN_KERNEL_STAGED)) &&
                         (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     if (staged) {
@@ -651,8 +664,8 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     }
     if (p->reordered) {
         // (which streaming kernel: prefer_segmented; which lane geometry at narrow widths: narrow_vec4 — plan_policy.cpp)
-        const bool seg = gespmm::prefer_segmented(p->facts, p->hits_after, N);
-        const bool vec4 = p->narrow_vec >= 0 ? (p->narrow_vec == 1 && N == p->N) : gespmm::narrow_vec4(p->facts, p->hits_after, N);
+        const bool seg = gespmm::prefer_segmented(facts, p->hits_after, N);
+        const bool vec4 = use_tuned ? p->tuned_vec == 1 : gespmm::narrow_vec4(facts, p->hits_after, N);
         gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg && !vec4};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
                               vec4 ? GESPMM_VARIANT_CRC_CWM4 : p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
@@ -684,7 +697,7 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     if (!p || N <= 0 || !B || !C) return GESPMM_EINVAL;
     if (N != p->N) return GESPMM_EINVAL;  // the tables are made for one width
     // a storage-order plan has one launch path, and the caller's explicit choice stands: nothing to measure, but C = A * B as promised
-    if (!p->reordered || (p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO && !p->tuned))
+    if (!p->reordered || p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO)
         return plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -695,25 +708,32 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     hipError_t e = hipSuccess;
     const bool v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 || p->variant == GESPMM_VARIANT_CRC_CWM8;
     if (!p->stg.ev && p->analysis == GESPMM_PLAN_ANALYSIS_DEVICE && v4 && p->nnz > 0 && gespmm::staged_serves(p->K, p->N)) {
-        e = build_staging_tables(p, st);
-        if (e != hipSuccess) return (int)e;
+        e = build_staging_tables(p, st);  // (built for the occasion: kept only if the staged-rows kernel wins)
+        if (e != hipSuccess) {
+            gespmm::free_staging(&p->stg);
+            return (int)e;
+        }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e != hipSuccess) {
         if (e0) (void)hipEventDestroy(e0);
+        if (!p->staging_kept_by_policy) gespmm::free_staging(&p->stg);
         return (int)e;
     }
     const int cand[4] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STREAM};
+    const bool was_tuned = p->tuned;
+    const int was_kernel = p->tuned_kernel, was_vec = p->tuned_vec;
     int best = -1, rc = 0;
+    p->tuned = true;  // (plan_run below launches the candidate through the tuned path)
     for (int c = 0; c < 4 && rc == 0; ++c) {
         p->tune_us[c] = -1.0;
         if (c == 1 && !p->d_gtasks) continue;
         if (c == 2 && !(p->stg.ev && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && v4)) continue;
         if (c == 3 && !(p->variant == GESPMM_VARIANT_AUTO && N <= 64 && N % 4 == 0)) continue;
-        p->kernel_choice = p->facts.kernel_choice = cand[c];
-        p->narrow_vec = c == 3 ? 1 : 0;
+        p->tuned_kernel = cand[c];
+        p->tuned_vec = c == 3 ? 1 : 0;
         rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // warm: code objects, split points, L2 state
         if (rc == 0) rc = (int)hipEventRecord(e0, st);
         for (int r = 0; r < reps && rc == 0; ++r) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
@@ -728,14 +748,17 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != 0 || best < 0) {
-        p->kernel_choice = p->facts.kernel_choice = GESPMM_PLAN_KERNEL_AUTO;
-        p->narrow_vec = -1;
+        // a candidate failed: the plan is what it was before the call — and tables the policy had not kept do not stay behind
+        // (~16 bytes per entry, and an AUTO launch would otherwise take the staged-rows kernel against the policy)
+        p->tuned = was_tuned;
+        p->tuned_kernel = was_kernel;
+        p->tuned_vec = was_vec;
+        if (!p->staging_kept_by_policy && !(was_tuned && was_kernel == GESPMM_PLAN_KERNEL_STAGED)) gespmm::free_staging(&p->stg);
         return rc;
     }
-    p->kernel_choice = p->facts.kernel_choice = cand[best];
-    p->narrow_vec = best == 3 ? 1 : 0;
-    p->tuned = true;
-    if (best != 2 && p->stg.ev) gespmm::free_staging(&p->stg);  // the tables are ~16 bytes per entry: not kept for a kernel that lost
+    p->tuned_kernel = cand[best];
+    p->tuned_vec = best == 3 ? 1 : 0;
+    if (best != 2 && p->stg.ev && !p->staging_kept_by_policy) gespmm::free_staging(&p->stg);  // not kept for a kernel that lost
     if (best != 2) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // (C is the winner's product either way: same bits)
     return rc;
 }
@@ -843,8 +866,13 @@ int gespmm_plan_get_order(const gespmm_plan* p, int32_t* perm_host) {
 int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
     if (!p || !out || capacity <= 0) return GESPMM_EINVAL;
     char what[256] = "";
-    const bool vec4d = p->reordered && (p->narrow_vec >= 0 ? p->narrow_vec == 1 : gespmm::narrow_vec4(p->facts, p->hits_after, p->N));
-    const bool seg = p->reordered && p->d_gtasks && !vec4d && gespmm::prefer_segmented(p->facts, p->hits_after, p->N);
+    gespmm::PlanFacts facts = p->facts;  // (what a launch at the plan's own width does: the tuned choice, if there is one)
+    if (p->tuned) facts.kernel_choice = p->tuned_kernel;
+    const bool vec4d = p->reordered && (p->tuned ? p->tuned_vec == 1 : gespmm::narrow_vec4(facts, p->hits_after, p->N));
+    const bool seg = p->reordered && p->d_gtasks && !vec4d && gespmm::prefer_segmented(facts, p->hits_after, p->N);
+    const bool staged_d = p->stg.ev && (p->tuned ? p->tuned_kernel == GESPMM_PLAN_KERNEL_STAGED
+                                                 : (p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
+                                                    (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO && p->staging_kept_by_policy)));
     gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags | (p->reordered ? ((seg ? GESPMM_FLAG_SEG_STREAM : GESPMM_FLAG_BATCH_STREAM) | GESPMM_FLAG_NO_SLAB_BLOCKED) : 0)};
     gespmm_describe_launch(p->M, p->K, p->N, p->nnz, vec4d ? GESPMM_VARIANT_CRC_CWM4 : p->variant, &cfg, what, sizeof what);
     int n;
@@ -854,7 +882,7 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         for (int i = 0; i < p->stats.levels && i < 16 && off < 100; ++i)
             off += snprintf(lv + off, sizeof lv - (size_t)off, "%s%d", i ? ">" : "", p->stats.clusters[i]);
         char kern[420];
-        if (p->stg.ev && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
+        if (staged_d && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
             snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
                      p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);

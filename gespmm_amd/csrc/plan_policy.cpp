@@ -189,6 +189,11 @@ int sddmm_route(const PlanFacts& f, bool reordered, double hits_after, int64_t N
 extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a) {
     if (!q || !a || q->M < 0 || q->K < 0 || q->nnz < 0 || q->N < 0) return GESPMM_EINVAL;
     if (q->variant < GESPMM_VARIANT_AUTO || q->variant >= GESPMM_NUM_VARIANTS || q->reorder < 0 || q->reorder > 2) return GESPMM_EINVAL;
+    // the kernel values gespmm_plan_create accepts (2 and 4 belonged to the removed opt-in kernels)
+    if (q->kernel != GESPMM_PLAN_KERNEL_AUTO && q->kernel != GESPMM_PLAN_KERNEL_STREAM && q->kernel != GESPMM_PLAN_KERNEL_SEG_STREAM &&
+        q->kernel != GESPMM_PLAN_KERNEL_STAGED)
+        return GESPMM_EINVAL;
+    if (q->analysis != GESPMM_PLAN_ANALYSIS_DEVICE && q->analysis != GESPMM_PLAN_ANALYSIS_HOST) return GESPMM_EINVAL;
     gespmm::PlanFacts f;
     f.M = q->M;
     f.K = q->K;
@@ -225,8 +230,22 @@ extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan
     a->build_staged = keep && kd.build_staged;
     a->keep_staged = a->build_staged && gespmm::keep_staged_tables(f, q->staged_fraction);
     a->shallow_unroll = keep && kd.shallow_unroll;
-    a->segmented = keep && !a->keep_staged && gespmm::prefer_segmented(f, q->hits_after, Nl);
-    a->narrow_vec4 = keep && gespmm::narrow_vec4(f, q->hits_after, Nl);
+    // what gespmm_plan_spmm_f32 launches at N_launch: the staged-rows kernel only at the plan's own width (its tables are made
+    // for one width); at every other width the streaming rules apply — and the segmented-stream kernel is dropped wherever the
+    // launch splits long rows (capi.cpp: run_spmm; the long-row pass belongs to the batch-stream kernel)
+    const bool staged_here = a->keep_staged && Nl == q->N;
+    bool seg = keep && !staged_here && gespmm::prefer_segmented(f, q->hits_after, Nl);
+    if (seg) {
+        gespmm::Selection sl;
+        int mv = 4;
+        while (mv > 1 && (Nl % mv) != 0) mv >>= 1;
+        if (gespmm::resolve_geometry(q->M, q->K, Nl > 0 ? Nl : 1, q->nnz, q->variant, mv, 0, 0, 0, 0, 0,
+                                     ad.launch_flags | GESPMM_FLAG_SEG_STREAM | GESPMM_FLAG_NO_SLAB_BLOCKED, &sl) == 0 &&
+            sl.geo.split_long_rows)
+            seg = false;
+    }
+    a->segmented = seg;
+    a->narrow_vec4 = keep && !staged_here && gespmm::narrow_vec4(f, q->hits_after, Nl);
     a->sddmm_route = gespmm::sddmm_route(f, keep, q->hits_after, Nl);
     a->model_window = ad.model_window;
     a->model_sample = ad.model_sample;

@@ -149,6 +149,9 @@ hipError_t launch_slabplan(const int32_t* rowptr, const int32_t* colind, int32_t
 hipError_t launch_atomic_scatter(const int32_t* rowptr, const int32_t* colind, const float* in, float* out, int64_t M,
                                  int64_t K, int64_t N, int64_t nnz, hipStream_t st);
 
+// ... and a plain streaming copy dst[i] = src[i] (the read + write rate of the box: bench.py's yardstick for ceiling_frac)
+hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st);
+
 // csr2csc.hip
 int64_t csr2csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
 hipError_t launch_csr2csc(const int32_t* rowptr, const int32_t* colind, const float* csr_val,

@@ -310,6 +310,22 @@ def csr2csc(rowptr, colind, colptr, rowind, csr_data):
     return out
 
 
+def baseline_copy(src, out=None):
+    """dst[i] = src[i] through the library's streaming-copy yardstick (gespmm_baseline_copy_f32) — NOT a product path:
+    bench.py times it beside the product to price `ceiling_frac` with the read + write rate of the box."""
+    _need(src, "src", torch.float32, src.dim())
+    if out is None:
+        out = torch.empty_like(src)
+    _need(out, "out", torch.float32, src.dim())
+    if out.numel() != src.numel():
+        raise ValueError("out must have as many elements as src")
+    dev = _same_device(src, out)
+    with _on_device(dev):
+        rc = lib.gespmm_baseline_copy_f32(_ptr(src), _ptr(out), src.numel(), _stream(dev))
+    check(rc, "gespmm_baseline_copy_f32")
+    return out
+
+
 def select_variant(M, nnz, N):
     """The variant VARIANT_AUTO resolves to for this shape (host-only)."""
     return lib.gespmm_select_variant(int(M), int(nnz), int(N))

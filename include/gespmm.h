@@ -25,6 +25,7 @@
  *   gespmm_plan_*            <- (new) analysis stage in front of repeated launches; no reference counterpart
  *   gespmm_cluster_rows / gespmm_simulate_l2_hits <- (new) the plan's host-side row clustering and its L2 model
  *   gespmm_baseline_atomic_scatter_f32 <- Gunrock app's edge map  gunrock-test/app/spmm/spmm_enactor.cuh:92-105
+ *   gespmm_baseline_copy_f32 <- (new) streaming-copy yardstick for the roofline record; no reference counterpart
  *
  * Conventions (all device entry points):
  *   - every pointer is a DEVICE pointer owned by the caller, except where a
@@ -286,9 +287,9 @@ typedef struct gespmm_plan_options {
     int32_t analysis;      /* GESPMM_PLAN_ANALYSIS_*: where the clustering / L2 model / task cutting run (since 0.2) */
 } gespmm_plan_options;
 /*
- * Plan options and versions. Every field's default is 0 and fields are only ever APPENDED. gespmm_plan_create is the 0.1
- * symbol: it reads the six fields 0.1 had (reorder .. kernel) and nothing beyond them, whatever header the caller was built
- * with. gespmm_plan_create_v2 takes sizeof(gespmm_plan_options) as the caller's compiler saw it (`opt_bytes`): fields the
+ * Plan options and versions. Every field's default is 0 and fields are only ever APPENDED. gespmm_plan_create is the
+ * un-versioned symbol: it reads the SEVEN fields every header that shipped with it alone had (reorder .. analysis) and nothing
+ * beyond them, whatever header the caller was built with. gespmm_plan_create_v2 takes sizeof(gespmm_plan_options) as the caller's compiler saw it (`opt_bytes`): fields the
  * caller does not have take their defaults, bytes this library does not know are ignored.
  */
 
@@ -409,6 +410,14 @@ int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_ans
  */
 int gespmm_baseline_atomic_scatter_f32(const int32_t* rowptr, const int32_t* colind, const float* in, float* out,
                                        int64_t M, int64_t K, int64_t N, int64_t nnz, void* stream);
+
+/*
+ * Yardstick, not a product path: dst[i] = src[i] for n floats as one streaming kernel (dwordx4 per lane where both
+ * pointers are 16-byte aligned). bench.py times it in the same process as the product, so that `roofline.ceiling_frac`
+ * is priced with the read + write rate of the box the product ran on (no reference counterpart: the reference reports
+ * GFLOP/s only, spmm_test.cu:728-738).
+ */
+int gespmm_baseline_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ host side */
 

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--ncols", default="128")
     ap.add_argument("--entries", default="0,16,24,32,48,64,96,128")
     ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--kernel", default="auto", choices=("auto", "stream", "seg-stream", "staged"))
     ap.add_argument("--only-plan", action="store_true", help="one clustered plan per graph at the default task size (for rocprofv3)")
     ap.add_argument("--task-entries", type=int, default=0, help="with --only-plan: task size (0 = default)")
     args = ap.parse_args()
@@ -62,13 +62,7 @@ def main():
             us = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan))
             print("%s N=%d storage-order plan    %8.1f us  frac %.3f" % (name, N, us, abytes / us / 8e6), flush=True)
             for kernel in ("stream", "seg-stream"):
-                if kernel == "lds-rows" and N % 4:
-                    continue
                 for te in [int(x) for x in args.entries.split(",")]:
-                    if kernel == "lds-rows" and te > 32:
-                        continue
-                    if kernel == "task-outer" and (te > 64 or N < 64):
-                        continue
                     t0 = time.time()
                     plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, task_entries=te, kernel=kernel)
                     dt = time.time() - t0

@@ -22,3 +22,24 @@ def edge_case_csr(seed=0):
     rowptr[1:] = np.cumsum(degs)
     colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)  # unsorted, with repeats
     return {"M": len(degs), "K": K, "nnz": int(rowptr[-1]), "rowptr": rowptr, "colind": colind}
+
+
+def sampled_rows_equal_oracle(oracle, rowptr, colind, val, B, C, nrows=512, seed=0):
+    """`nrows` sampled rows of C = A @ B (device tensors) against the oracle's device-arithmetic chain on the extracted
+    sub-matrix, bit for bit. Only the B rows those CSR rows touch travel to the host."""
+    import torch
+
+    M = rowptr.numel() - 1
+    rng = np.random.RandomState(seed)
+    rows = np.sort(rng.choice(M, min(nrows, M), replace=False))
+    rph = rowptr.cpu().numpy()
+    sub_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
+    sub_ptr[1:] = np.cumsum(rph[rows + 1] - rph[rows])
+    sel = torch.from_numpy(np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows]).astype(np.int64)).to(colind.device)
+    cih = colind[sel].cpu().numpy()
+    vh = val[sel].cpu().numpy() if val is not None else None
+    cols_u, inv = np.unique(cih, return_inverse=True)
+    Bsub = B[torch.from_numpy(cols_u.astype(np.int64)).to(B.device)].cpu().numpy()
+    ref = oracle.spmm(sub_ptr, inv.astype(np.int32), vh, Bsub, "fma" if vh is not None else "golden")
+    got = C[torch.from_numpy(rows).to(C.device)].cpu().numpy()
+    return bool(np.array_equal(bits(got), bits(ref)))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import bits, edge_case_csr
+from helpers import bits, edge_case_csr, sampled_rows_equal_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -126,12 +126,14 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
     ref = spmm.csr_spmm(rp, ci, val, B)
     assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    assert sampled_rows_equal_oracle(oracle, rp, ci, val, B, got, nrows=1024), "planned headline product differs from the oracle"
     # structureless stand-in: whatever AUTO decides, the bits stay
     g2 = graphs.synthetic_graph("com-amazon-like", seed=42, device="cuda")
     plan2 = spmm.SpmmPlan(g2["rowptr"], g2["colind"], M, 128, values=val)
     assert "kernel=batch-stream" in plan2.describe(), plan2.describe()
     got2 = spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B, plan=plan2)
     assert torch.equal(got2.view(torch.int32), spmm.csr_spmm(g2["rowptr"], g2["colind"], val, B).view(torch.int32))
+    assert sampled_rows_equal_oracle(oracle, g2["rowptr"], g2["colind"], val, B, got2, nrows=512, seed=1)
     # N = 32 and 512 through plans of their own
     for N in (32, 512):
         Bn = (torch.randint(0, 100, (M, N), device="cuda", dtype=torch.int32) - 50).float() / 100
@@ -303,8 +305,8 @@ def test_cached_memory_limit_and_release(pkg):
 
 
 def test_plan_options_by_size(pkg, bundled):
-    """gespmm_plan_create is the 0.1 symbol: it reads the six fields 0.1 had and nothing beyond them (a caller built against the old
-    header passes a 24-byte struct); gespmm_plan_create_v2 reads what the caller's sizeof says, rejects sizes that are not a multiple of
+    """gespmm_plan_create is the un-versioned symbol: it reads the seven fields every header that shipped with it alone had (reorder ..
+    analysis) and nothing beyond them; gespmm_plan_create_v2 reads what the caller's sizeof says, rejects sizes that are not a multiple of
     4, takes defaults for fields the caller does not have and ignores bytes it does not know."""
     import ctypes
 
@@ -330,8 +332,11 @@ def test_plan_options_by_size(pkg, bundled):
         return rc, ""
 
     garbage = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, 12345, -7, 99)
-    rc, d = create(lib.gespmm_plan_create, garbage)  # 0.1 symbol: `analysis` = 12345 is never looked at
-    assert rc == 0 and "order=clustered" in d and "on the device" in d, (rc, d)
+    rc, d = create(lib.gespmm_plan_create, garbage)  # un-versioned symbol: `analysis` = 12345 IS read (seven fields) -> invalid; x1 / x2 are not
+    assert rc == -1, (rc, d)
+    host7 = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, -7, 99)
+    rc, d = create(lib.gespmm_plan_create, host7)  # a round-3 caller asking for the host analysis gets it
+    assert rc == 0 and "order=clustered" in d and "on the host" in d, (rc, d)
     rc, _ = create(lib.gespmm_plan_create_v2, garbage, ctypes.sizeof(_lib.PlanOptions))  # 28 bytes: `analysis` IS read -> invalid
     assert rc == -1, rc  # GESPMM_EINVAL
     ok = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, -7, 99)

@@ -287,3 +287,19 @@ def test_b_beyond_4gb_takes_the_two_halves_base(pkg, oracle):
         assert np.array_equal(bits(got[r:r + 1].cpu().numpy()), bits(ref)), r
     # beyond 8 GB the staged kernel is not offered: the plan falls back to the streaming kernels
     assert pkg._lib.plan_policy(M, 4_300_000, colind.size, 512, 40, 0.0, 0.9, 0.9, kernel=pkg._lib.PLAN_KERNEL_STAGED)["build_staged"] == 0
+
+
+def test_reduced_soak_of_the_staged_kernel(pkg):
+    """scripts/staged_soak.py at a reduced count in the GPU suite (round-4 review: the inline-assembly kernel is soak-tested, not proven —
+    keep the soak running with every round, not only as a log): 200 seeded random matrices x N = 128 / 256 / 512 (/ 1024), valued and
+    unweighted, forced staged plans against the plain call's strict-order bits, gespmm_plan_tune on every fifth seed."""
+    import os
+    import sys
+
+    from helpers import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import staged_soak
+
+    checked, staged = staged_soak.soak(91000, 200, verbose=False)
+    assert checked >= 1200 and staged >= 300, (checked, staged)
