@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3
 MIN_KERNEL_SAMPLES = 200  # the reference times 200 launches (ITER, spmm_test.cu:714)
+STEADY_STATE = 1000000    # expected_launches of a plan whose analysis always pays (kernel-quality figures: widths, sweeps)
 
 COPY_RATE_GUIDE_GBS = 6290.0  # MI355X_MICROARCH.md:35 — measured copy rate of the chip; the sanity bound for the rate measured in the run
 LINE_LIMIT = 4096  # the final stdout line stays below this; everything else goes to EXTRA_FILE (and to stderr)
@@ -327,8 +328,10 @@ def main():
     env = BenchEnv(torch, dist, dev, world, rank, use_dist, variant=args.variant)
     sync_all, make_B, kernel_times_us, timed_region, verify = env.sync_all, env.make_B, env.kernel_times_us, env.timed_region, env.verify
 
-    def measure_graph(g, val, N, valued=True, use_plan=True, samples=MIN_KERNEL_SAMPLES, keep=False):
-        """Median kernel time of one (graph, width) through a plan (or the plain entry point)."""
+    def measure_graph(g, val, N, valued=True, use_plan=True, samples=MIN_KERNEL_SAMPLES, keep=False, expected_launches=0):
+        """Median kernel time of one (graph, width) through a plan (or the plain entry point). `expected_launches` goes to the plan:
+        0 = the library's default, 200 (the reference's protocol) — an AUTO plan then skips an analysis that 200 launches would
+        not pay for; STEADY_STATE = the kernel a long-running caller gets (what `widths` reports)."""
         M, K, nnz = g["M"], g["K"], g["nnz"]
         B = make_B(K, N)
         C = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -343,7 +346,7 @@ def main():
                 plan = None
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                plan = spmm.SpmmPlan(g["rowptr"], g["colind"], K, N, variant=args.variant, values=v)
+                plan = spmm.SpmmPlan(g["rowptr"], g["colind"], K, N, variant=args.variant, values=v, expected_launches=expected_launches)
                 torch.cuda.synchronize()
                 times.append((time.perf_counter() - t0) * 1e3)
             plan_first_ms, plan_ms = times[0], min(times[1:])
@@ -506,7 +509,7 @@ def main():
         for n2 in (32, 512):
             for valued in (True, False):
                 torch.cuda.empty_cache()
-                rw = measure_graph(g, val, n2, valued, samples=MIN_KERNEL_SAMPLES if valued else 50)
+                rw = measure_graph(g, val, n2, valued, samples=MIN_KERNEL_SAMPLES if valued else 50, expected_launches=STEADY_STATE)
                 extra["N%d_%s" % (n2, "valued" if valued else "unweighted")] = rw
                 if valued:
                     tw_, _, hw_ = traffic_for("%s/N%d/valued/plan" % (graph, n2))
@@ -525,7 +528,9 @@ def main():
             other = "com-amazon-like" if graph == "com-amazon-sbm" else "com-amazon-sbm"
             torch.cuda.empty_cache()
             gs = graphs.synthetic_graph(other, seed=42, device=dev)
-            r = measure_graph(gs, val, N, True)
+            r = measure_graph(gs, val, N, True, expected_launches=STEADY_STATE)  # the clustered plan (the series of rounds 1-4)
+            rdef = measure_graph(gs, val, N, True)  # ... and what a plan made with the defaults does: 200 expected launches
+            r["default_policy_200_launches"] = {k: rdef.get(k) for k in ("kernel_us", "frac", "plan_ms", "gflops_incl_plan_over_200_launches", "plan")}
             r["traffic"], r["traffic_source"], r["l2_hit_rate"] = traffic_for("%s/N%d/valued/plan" % (other, N))
             rp_ = measure_graph(gs, val, N, True, use_plan=False, samples=MIN_KERNEL_SAMPLES)
             r["plain_call_kernel_us"] = rp_["kernel_us"]
@@ -535,7 +540,10 @@ def main():
             series[other] = {"kernel_us": r["kernel_us"], "gflops": r["gflops"], "frac": r["frac"], "traffic": r["traffic"],
                              "l2_hit_rate": r["l2_hit_rate"], "plan_ms": r.get("plan_ms"),
                              "plain_call_kernel_us": rp_["kernel_us"], "plain_call_frac": rp_["frac"],
-                             "gflops_incl_plan_over_200_launches": r.get("gflops_incl_plan_over_200_launches")}
+                             "gflops_incl_plan_over_200_launches": r.get("gflops_incl_plan_over_200_launches"),
+                             "default_plan_200_launches": {"kernel_us": rdef["kernel_us"], "plan_ms": rdef.get("plan_ms"),
+                                                           "gflops_incl_plan": rdef.get("gflops_incl_plan_over_200_launches"),
+                                                           "order": (rdef.get("plan") or "")[:13]}}
             series[other].update({k: v for k, v in ceiling_for(gs, N, r["frac"]).items() if k != "ceiling_note"})
             del gs
 

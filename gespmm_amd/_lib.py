@@ -71,6 +71,7 @@ EXPORTS = [
     "gespmm_simulate_l2_hits",
     "gespmm_plan_create_v2",
     "gespmm_plan_policy",
+    "gespmm_plan_policy_v2",
     "gespmm_plan_tune",
     "gespmm_set_cached_memory_limit",
     "gespmm_device_cluster_rows",
@@ -97,20 +98,24 @@ class LaunchCfg(Structure):
 
 class PlanOptions(Structure):
     _fields_ = [("reorder", c_int32), ("task_entries", c_int32), ("row_floor", c_int32), ("threads", c_int32),
-                ("flags", c_int32), ("kernel", c_int32), ("analysis", c_int32)]
+                ("flags", c_int32), ("kernel", c_int32), ("analysis", c_int32), ("expected_launches", c_int32)]
 
 
 class PlanPolicyQuery(Structure):
     _fields_ = [("M", c_int64), ("K", c_int64), ("nnz", c_int64), ("N", c_int64), ("N_launch", c_int64), ("variant", c_int32),
                 ("max_degree", c_int32), ("reorder", c_int32), ("kernel", c_int32), ("analysis", c_int32), ("flags", c_int32),
                 ("task_entries", c_int32), ("row_floor", c_int32), ("hits_before", ctypes.c_double),
-                ("hits_after", ctypes.c_double), ("staged_fraction", ctypes.c_double)]
+                ("hits_after", ctypes.c_double), ("staged_fraction", ctypes.c_double), ("expected_launches", c_int32),
+                ("reserved0", c_int32), ("wedge_probe", ctypes.c_double)]
 
 
 class PlanPolicyAnswer(Structure):
     _fields_ = [(n, c_int32) for n in ("launch_flags", "analyse", "dense_try", "keep_clustered", "task_entries",
                                        "group_task_entries", "row_floor", "build_staged", "keep_staged", "shallow_unroll",
-                                       "segmented", "sddmm_route", "narrow_vec4")] + [("model_window", c_int64), ("model_sample", c_int64)]
+                                       "segmented", "sddmm_route", "narrow_vec4")] + [("model_window", c_int64), ("model_sample", c_int64),
+                                                                                       ("cost_skipped", c_int32), ("reserved1", c_int32),
+                                                                                       ("est_gain_us", ctypes.c_double),
+                                                                                       ("est_cost_us", ctypes.c_double)]
 
 
 class Coo(Structure):
@@ -174,6 +179,8 @@ def _load():
     lib.gespmm_coo_to_csr.argtypes = [c_int32, c_int32, c_int64, p, p, p, p, p, p]
     lib.gespmm_baseline_atomic_scatter_f32.restype = c_int
     lib.gespmm_baseline_atomic_scatter_f32.argtypes = [p, p, p, p, c_int64, c_int64, c_int64, c_int64, p]
+    lib.gespmm_plan_policy_v2.restype = c_int
+    lib.gespmm_plan_policy_v2.argtypes = [POINTER(PlanPolicyQuery), c_int64, POINTER(PlanPolicyAnswer), c_int64]
     lib.gespmm_baseline_copy_f32.restype = c_int
     lib.gespmm_baseline_copy_f32.argtypes = [p, p, c_int64, p]
     lib.gespmm_plan_create.restype = c_int
@@ -230,14 +237,16 @@ class GespmmError(RuntimeError):
 
 def plan_policy(M, K, nnz, N, max_degree, hits_before=0.0, hits_after=0.0, staged_fraction=0.0, N_launch=0, variant=VARIANT_AUTO,
                 reorder=PLAN_REORDER_AUTO, kernel=PLAN_KERNEL_AUTO, analysis=PLAN_ANALYSIS_DEVICE, flags=0, task_entries=0,
-                row_floor=0):
-    """What a plan would decide for a matrix of this shape (gespmm_plan_policy: host only, no device) — a dict."""
+                row_floor=0, expected_launches=0, wedge_probe=-1.0):
+    """What a plan would decide for a matrix of this shape (gespmm_plan_policy_v2: host only, no device) — a dict.
+    `wedge_probe` is the plan's structure probe (share of sampled wedges that close; negative = unknown), `expected_launches` the
+    number of products the analysis has to pay for itself in (0 = 200)."""
     q = PlanPolicyQuery(int(M), int(K), int(nnz), int(N), int(N_launch), int(variant), int(max_degree), int(reorder), int(kernel),
                         int(analysis), int(flags), int(task_entries), int(row_floor), float(hits_before), float(hits_after),
-                        float(staged_fraction))
+                        float(staged_fraction), int(expected_launches), 0, float(wedge_probe))
     a = PlanPolicyAnswer()
-    check(lib.gespmm_plan_policy(ctypes.byref(q), ctypes.byref(a)), "gespmm_plan_policy")
-    return {n: getattr(a, n) for n, _ in PlanPolicyAnswer._fields_}
+    check(lib.gespmm_plan_policy_v2(ctypes.byref(q), ctypes.sizeof(q), ctypes.byref(a), ctypes.sizeof(a)), "gespmm_plan_policy_v2")
+    return {n: getattr(a, n) for n, _ in PlanPolicyAnswer._fields_ if not n.startswith("reserved")}
 
 
 def release_cached_memory():

@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "spmm_kernels.h"
 
@@ -50,9 +51,31 @@ __global__ __launch_bounds__(kThreads) void atomic_scatter_kernel(const int32_t*
 // Yardstick, not a product path: a plain streaming copy (one dwordx4 load + one dwordx4 store per lane and step, grid-stride,
 // 16 workgroups per CU). bench.py times it in the same process as the product to price `roofline.ceiling_frac` with the rate
 // THIS box reaches for read + write traffic (MI355X_MICROARCH.md quotes 6.29 TB/s for a copy; boxes differ by a few percent).
-__global__ __launch_bounds__(kThreads) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+using cf4 = float __attribute__((ext_vector_type(4)));
+// (shapes measured on the MI355X, profiles/r05/copy_yardstick.log; GESPMM_COPY_MODE picks one for that experiment)
+__global__ __launch_bounds__(kThreads) void copy_kernel(const cf4* __restrict__ src, cf4* __restrict__ dst, int64_t n4) {
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+template <int U, bool NT>
+__global__ __launch_bounds__(kThreads) void copy_unrolled_kernel(const cf4* __restrict__ src, cf4* __restrict__ dst, int64_t n4) {
+    // a workgroup moves U consecutive 4 KB pieces: U loads in flight per lane, then U stores
+    const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+    cf4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * kThreads;
+        if (i < n4) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * kThreads;
+        if (i < n4) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i);
+            else dst[i] = v[u];
+        }
+    }
 }
 
 __global__ void copy_tail_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t begin, int64_t n) {
@@ -67,10 +90,20 @@ hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st) 
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const int64_t n4 = vec ? n / 4 : 0;
     if (n4 > 0) {
-        int64_t blocks = (n4 + kThreads - 1) / kThreads;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(src),
-                           reinterpret_cast<float4*>(dst), n4);
+        static const int mode = getenv("GESPMM_COPY_MODE") ? atoi(getenv("GESPMM_COPY_MODE")) : 0;
+        const cf4* s4 = reinterpret_cast<const cf4*>(src);
+        cf4* d4 = reinterpret_cast<cf4*>(dst);
+        auto grid_u = [&](int U) { return dim3((unsigned)((n4 + (int64_t)kThreads * U - 1) / ((int64_t)kThreads * U))); };
+        if (mode == 1) hipLaunchKernelGGL((copy_unrolled_kernel<1, false>), grid_u(1), dim3(kThreads), 0, st, s4, d4, n4);
+        else if (mode == 2) hipLaunchKernelGGL((copy_unrolled_kernel<4, false>), grid_u(4), dim3(kThreads), 0, st, s4, d4, n4);
+        else if (mode == 3) hipLaunchKernelGGL((copy_unrolled_kernel<4, true>), grid_u(4), dim3(kThreads), 0, st, s4, d4, n4);
+        else if (mode == 4) hipLaunchKernelGGL((copy_unrolled_kernel<8, false>), grid_u(8), dim3(kThreads), 0, st, s4, d4, n4);
+        else if (mode == 5) hipLaunchKernelGGL((copy_unrolled_kernel<1, true>), grid_u(1), dim3(kThreads), 0, st, s4, d4, n4);
+        else {
+            int64_t blocks = (n4 + kThreads - 1) / kThreads;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, s4, d4, n4);
+        }
     }
     const int64_t done = n4 * 4;
     if (done < n) {

@@ -65,6 +65,8 @@ struct gespmm_plan {
     int kernel_choice = 0;         // GESPMM_PLAN_KERNEL_*
     gespmm::PlanFacts facts;       // what the policy functions (plan_policy.h) are asked with
     std::vector<int32_t> perm_host;  // filled by the host analysis, or on demand (gespmm_plan_get_order)
+    bool cost_skipped = false;       // AUTO skipped the analysis: expected launches x estimated gain < estimated cost (plan_policy.cpp)
+    double est_gain_us = 0.0, est_cost_us = 0.0;
     int analysis = 0;                // GESPMM_PLAN_ANALYSIS_*
     double model_seconds = 0.0;
     void* ws = nullptr;
@@ -206,7 +208,7 @@ int gespmm_device_cluster_rows(const int32_t* rowptr, const int32_t* colind, int
     if (M == 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int32_t max_deg = 0, bad = 0;
-    hipError_t e = gespmm::device_validate_csr(rowptr, colind, M, K, nnz, &max_deg, &bad, st);
+    hipError_t e = gespmm::device_validate_csr(rowptr, colind, M, K, nnz, &max_deg, &bad, nullptr, st);
     if (e != hipSuccess) return (int)e;
     if (bad) return GESPMM_EINVAL;
     int32_t* d_perm = nullptr;
@@ -311,6 +313,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
     if (kernel_mode != GESPMM_PLAN_KERNEL_AUTO && kernel_mode != GESPMM_PLAN_KERNEL_STREAM && kernel_mode != GESPMM_PLAN_KERNEL_SEG_STREAM &&
         kernel_mode != GESPMM_PLAN_KERNEL_STAGED)
         return GESPMM_EINVAL;
+    if (opt && opt->expected_launches < 0) return GESPMM_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const auto t_start = std::chrono::steady_clock::now();
 
@@ -344,7 +347,9 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         // ---- one pass over the matrix on the device: rowptr monotone and consistent with nnz, every column index
         //      inside [0, K) (the kernels trust them), the longest row
         int32_t max_deg = 0, bad = 0;
-        e = gespmm::device_validate_csr(rowptr, colind, M, K, nnz, &max_deg, &bad, st);
+        double wedge_probe = -1.0;
+        const int reorder_auto = reorder_mode == GESPMM_PLAN_REORDER_AUTO;
+        e = gespmm::device_validate_csr(rowptr, colind, M, K, nnz, &max_deg, &bad, (reorder_auto && !on_host) ? &wedge_probe : nullptr, st);
         if (e != hipSuccess) {
             delete p;
             return (int)e;
@@ -381,6 +386,8 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         f.user_flags = user_flags;
         f.opt_task_entries = opt ? opt->task_entries : 0;
         f.opt_row_floor = opt ? opt->row_floor : 0;
+        f.expected_launches = opt ? opt->expected_launches : 0;
+        f.wedge_probe = wedge_probe;
         {
             gespmm::Selection sel;
             int max_vec = 4;
@@ -397,6 +404,9 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         const gespmm::AnalysisDecision ad = gespmm::decide_analysis(f);
         p->launch_flags = ad.launch_flags;
         bool reorder = ad.analyse;
+        p->cost_skipped = ad.cost_skipped;
+        p->est_gain_us = ad.cost.gain_us;
+        p->est_cost_us = ad.cost.cost_us;
         const bool dense_try = ad.dense_try;
         const int64_t model_window = ad.model_window, model_sample = ad.model_sample;
 
@@ -649,7 +659,7 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
                                  p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, 0, nullptr};
-        rc = (int)gespmm::launch_spmm_staged(sa, p->K, N, reinterpret_cast<hipStream_t>(stream));
+        rc = (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0 && p->stg.nlong > 0) {
             // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits
             // them — under GESPMM_FLAG_STRICT_ORDER each is one lane group's chain instead, as everywhere else
@@ -707,7 +717,7 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     if (reps > 50) reps = 50;
     hipError_t e = hipSuccess;
     const bool v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 || p->variant == GESPMM_VARIANT_CRC_CWM8;
-    if (!p->stg.ev && p->analysis == GESPMM_PLAN_ANALYSIS_DEVICE && v4 && p->nnz > 0 && gespmm::staged_serves(p->K, p->N)) {
+    if (!p->stg.ev && p->analysis == GESPMM_PLAN_ANALYSIS_DEVICE && v4 && p->nnz > 0 && gespmm::staged_serves(p->M, p->K, p->N) && gespmm::staged_stream_fits(p->M, p->nnz)) {
         e = build_staging_tables(p, st);  // (built for the occasion: kept only if the staged-rows kernel wins)
         if (e != hipSuccess) {
             gespmm::free_staging(&p->stg);
@@ -891,13 +901,18 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f batch-stream-V4=%.1f]", p->tune_us[0],
                      p->tune_us[1], p->tune_us[2], p->tune_us[3]);
         n = snprintf(out, (size_t)capacity,
-                     "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d l2_model=%.3f->%.3f "
+                     "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d probe=%.3f l2_model=%.3f->%.3f "
                      "analysis=%.4fs on the %s (clustering %.4fs)%s | %s",
-                     p->stats.levels, lv, p->ntasks, p->task_entries, p->ngtasks, p->max_degree, p->hits_before, p->hits_after,
-                     p->analysis_seconds, p->analysis == GESPMM_PLAN_ANALYSIS_HOST ? "host" : "device", p->cluster_seconds, tuned, kern);
+                     p->stats.levels, lv, p->ntasks, p->task_entries, p->ngtasks, p->max_degree, p->facts.wedge_probe, p->hits_before,
+                     p->hits_after, p->analysis_seconds, p->analysis == GESPMM_PLAN_ANALYSIS_HOST ? "host" : "device", p->cluster_seconds, tuned, kern);
     } else {
-        n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.3fs | %s",
-                     p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, what);
+        char why[200] = "";
+        if (p->cost_skipped)
+            snprintf(why, sizeof why, " (analysis skipped: est. gain %.1f us x %d launches < est. cost %.0f us; wedge probe %.4f)", p->est_gain_us,
+                     p->facts.expected_launches > 0 ? p->facts.expected_launches : gespmm::kDefaultExpectedLaunches, p->est_cost_us,
+                     p->facts.wedge_probe);
+        n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.4fs%s | %s",
+                     p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, why, what);
     }
     if (n < 0) return GESPMM_EINVAL;
     return n < capacity ? n : (int)capacity - 1;

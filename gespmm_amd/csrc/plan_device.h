@@ -11,9 +11,11 @@
 namespace gespmm {
 
 // rowptr[0] == 0, rowptr non-decreasing, rowptr[M] == nnz, every colind in [0, K). *bad_host: 0 = fine,
-// 1 = rowptr malformed, 2 = a column index out of range. *max_degree_host: longest row.
+// 1 = rowptr malformed, 2 = a column index out of range. *max_degree_host: longest row. *wedge_probe_host (may be NULL): the structure
+// probe of plan_policy.cpp's cost estimate — share of 16 384 sampled wedges (two columns c1, c2 of one row) with c2 in row c1; -1 when the
+// matrix is not square or too few wedges exist. One more small kernel, the same readback.
 hipError_t device_validate_csr(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
-                               int32_t* max_degree_host, int32_t* bad_host, hipStream_t st);
+                               int32_t* max_degree_host, int32_t* bad_host, double* wedge_probe_host, hipStream_t st);
 
 // Multi-level label propagation of reorder.cpp on the device: perm[i] = original row processed at position i.
 // Same rules (snapshot half-sweeps, size caps, hash tie-breaks, twins), hence the same order as cluster_rows().
@@ -44,7 +46,7 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
 // (>= 2 uses), `waves` tasks, and the interleaved {code, value} stream. staged_fraction = share of the entries whose B row
 // comes from LDS. Deterministic (ties in column order). The four arrays are hipMalloc blocks owned by the caller (free_staging).
 struct StagingTables {
-    int32_t* ev = nullptr;        // 2 * (nnz_s + kStagedPad) words
+    int32_t* ev = nullptr;        // 2 * (nnz_s + M + kStagedPad) words: entries + one row-end record per row (spmm_kernels.h)
     int32_t* hot_cols = nullptr;  // nblocks * H
     int32_t* nhot = nullptr;      // nblocks
     int32_t* tasks = nullptr;     // nblocks * waves int4
@@ -64,7 +66,7 @@ struct StagingTables {
 // tables are built; val_s NULL when val_p is) and the one-row tasks of the rows taken out.
 hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
                                   int limit, StagingTables* t, int32_t** colind_s, float** val_s, hipStream_t st);
-// perm (clustered position -> original row; may be NULL) is unused since round 5 (the `nt` marks of round 3 are gone).
+// perm (clustered position -> C row; NULL = identity) goes into the row-end records of the stream.
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
                                 const float* val_p, const int32_t* perm, int R, int H, int waves, StagingTables* out, hipStream_t st);
 // val_p: values in the clustered matrix's entry order (NULL: 1.0f); rowptr_p: its row pointers (used when hub rows were split off)

@@ -288,6 +288,62 @@ __global__ void k_validate(const int32_t* __restrict__ rowptr, const int32_t* __
     }
 }
 
+// The wedge probe (round 5, plan_policy.cpp: estimate_analysis_cost): for kProbeRows hash-chosen rows r of a SQUARE matrix and kProbePairs
+// hash-chosen pairs (c1, c2) of r's columns each: is c2 a column of row c1? out[2] += hits, out[3] += wedges tried. Rides on the validation
+// pass (same readback), so it may meet a matrix that pass is about to reject: every index is clamped before use. Row c1 is scanned
+// linearly (columns may be unsorted), at most kProbeScan entries — longer rows count what the scan saw.
+constexpr int kProbeRows = 4096, kProbePairs = 4, kProbeScan = 512;
+
+__device__ __forceinline__ uint32_t probe_hash(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ void k_wedge_probe(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t M, int64_t nnz,
+                              int32_t* __restrict__ out) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int hit = 0, tried = 0;
+    if (t < kProbeRows * kProbePairs) {
+        const int s = t / kProbePairs;
+        const int64_t r = (int64_t)(probe_hash(0x9e3779b9u * (uint32_t)(s + 1)) % (uint64_t)M);
+        int64_t a = rowptr[r], b = rowptr[r + 1];
+        a = a < 0 ? 0 : (a > nnz ? nnz : a);
+        b = b < a ? a : (b > nnz ? nnz : b);
+        const int64_t d = b - a;
+        if (d >= 2) {
+            const uint32_t h = probe_hash((uint32_t)t * 0x85ebca6bu + 1u);
+            const int64_t i = h % (uint64_t)d;
+            int64_t j = (h >> 16 ^ h * 31u) % (uint64_t)(d - 1);
+            if (j >= i) ++j;
+            const int64_t c1 = colind[a + i], c2 = colind[a + j];
+            if (c1 >= 0 && c1 < M) {
+                tried = 1;
+                int64_t a1 = rowptr[c1], b1 = rowptr[c1 + 1];
+                a1 = a1 < 0 ? 0 : (a1 > nnz ? nnz : a1);
+                b1 = b1 < a1 ? a1 : (b1 > nnz ? nnz : b1);
+                if (b1 - a1 > kProbeScan) b1 = a1 + kProbeScan;
+                for (int64_t q = a1; q < b1; ++q)
+                    if (colind[q] == c2) {
+                        hit = 1;
+                        break;
+                    }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        hit += __shfl_xor(hit, o);
+        tried += __shfl_xor(tried, o);
+    }
+    if (lane_id() == 0 && tried) {
+        atomicAdd(&out[2], hit);
+        atomicAdd(&out[3], tried);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ small helpers
 
 __global__ void k_iota(int32_t* __restrict__ a, int64_t n) {
@@ -1100,19 +1156,24 @@ hipError_t launch_half_sweep(const LpArgs& base, const int32_t* lists, const int
 // ====================================================================================================================
 
 hipError_t device_validate_csr(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int64_t nnz,
-                               int32_t* max_degree_host, int32_t* bad_host, hipStream_t st) {
+                               int32_t* max_degree_host, int32_t* bad_host, double* wedge_probe_host, hipStream_t st) {
     Scratch sc(st);
     GESPMM_TRY(sc.init(0, 0, 1024));
     int32_t* out = nullptr;
-    GESPMM_TRY(sc.get(&out, 2));
-    GESPMM_TRY(hipMemsetAsync(out, 0, 8, st));
+    GESPMM_TRY(sc.get(&out, 4));
+    GESPMM_TRY(hipMemsetAsync(out, 0, 16, st));
     const int64_t n = std::max<int64_t>(M, nnz);
     if (n > 0) hipLaunchKernelGGL(k_validate, dim3(grid_for(n)), dim3(256), 0, st, rowptr, colind, M, K, nnz, out);
+    // the structure probe: square matrices only (column c1 must also be a row), same readback as the validation
+    const bool probe = wedge_probe_host && M == K && M > 1 && nnz > 0;
+    if (probe)
+        hipLaunchKernelGGL(k_wedge_probe, dim3(grid_for((int64_t)kProbeRows * kProbePairs)), dim3(256), 0, st, rowptr, colind, M, nnz, out);
     GESPMM_TRY(hipGetLastError());
-    int32_t h[2] = {0, 0};
-    GESPMM_TRY(fetch(h, out, 2, st));
+    int32_t h[4] = {0, 0, 0, 0};
+    GESPMM_TRY(fetch(h, out, 4, st));
     *bad_host = h[0];
     *max_degree_host = h[1];
+    if (wedge_probe_host) *wedge_probe_host = (probe && h[3] >= 256) ? (double)h[2] / (double)h[3] : -1.0;
     return hipSuccess;
 }
 
@@ -1643,24 +1704,44 @@ __global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, i
         return lo;
     };
     const int r0 = bound(w), r1 = bound(w + 1);
-    reinterpret_cast<int4*>(tasks)[i] = make_int4(r0, r1 - r0, rowptr_p[r0], rowptr_p[r1]);
+    // stream positions: entry p of row r is record p + r (one row-end record behind every row)
+    reinterpret_cast<int4*>(tasks)[i] = make_int4(r0, r1 - r0, rowptr_p[r0] + r0, rowptr_p[r1] + r1);
 }
 
-__global__ void k_stage_interleave(const int32_t* __restrict__ code, const float* __restrict__ val_p, int64_t nnz, int64_t total,
-                                   int32_t* __restrict__ ev) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int2 w = make_int2(0, 0);  // padding: column 0, value +0
-    if (i < nnz) {
-        w.x = code[i];
-        w.y = val_p ? __float_as_int(val_p[i]) : 0x3f800000;
+__device__ __forceinline__ int row_of_entry(const int32_t* __restrict__ rowptr, int M, int q) {
+    int lo = 0, hi = M;  // rowptr[lo] <= q < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= q) lo = mid;
+        else hi = mid;
     }
-    reinterpret_cast<int2*>(ev)[i] = w;
+    return lo;
 }
 
-__global__ void k_stage_values(const float* __restrict__ val_p, int64_t nnz, int32_t* __restrict__ ev) {
+// The record stream: entry p of row r -> record p + r = {code, value bits}
+__global__ void k_stage_interleave(const int32_t* __restrict__ code, const float* __restrict__ val_p,
+                                   const int32_t* __restrict__ rowptr_p, int M, int64_t nnz, int32_t* __restrict__ ev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnz) ev[2 * i + 1] = val_p ? __float_as_int(val_p[i]) : 0x3f800000;
+    if (i >= nnz) return;
+    const int r = row_of_entry(rowptr_p, M, (int)i);
+    reinterpret_cast<int2*>(ev)[i + r] = make_int2(code[i], val_p ? __float_as_int(val_p[i]) : 0x3f800000);
+}
+
+// ... row r's end record {kStagedRowEnd, C row of r} at rowptr_p[r + 1] + r, and the padding behind the last row: staged slot 0,
+// value +0 (an LDS read, no memory gather; never summed)
+__global__ void k_stage_rowends(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ perm, int64_t M, int64_t nnz,
+                                int32_t* __restrict__ ev) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) reinterpret_cast<int2*>(ev)[(int64_t)rowptr_p[t + 1] + t] = make_int2(kStagedRowEnd, perm ? perm[t] : (int)t);
+    else if (t < M + kStagedPad) reinterpret_cast<int2*>(ev)[nnz + t] = make_int2((int)0x80000000u, 0);
+}
+
+__global__ void k_stage_values(const float* __restrict__ val_p, const int32_t* __restrict__ rowptr_p, int M, int64_t nnz,
+                               int32_t* __restrict__ ev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    const int r = row_of_entry(rowptr_p, M, (int)i);
+    ev[2 * (i + r) + 1] = val_p ? __float_as_int(val_p[i]) : 0x3f800000;
 }
 
 }  // namespace
@@ -1681,16 +1762,6 @@ __global__ void k_split_degrees(const int32_t* __restrict__ rowptr_p, int64_t M,
     }
     deg_s[i] = d;
     is_long[i] = l;
-}
-
-__device__ __forceinline__ int row_of_entry(const int32_t* __restrict__ rowptr, int M, int q) {
-    int lo = 0, hi = M;  // rowptr[lo] <= q < rowptr[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (rowptr[mid] <= q) lo = mid;
-        else hi = mid;
-    }
-    return lo;
 }
 
 __global__ void k_split_compact(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ rowptr_s,
@@ -1716,11 +1787,9 @@ __global__ void k_stage_values_split(const float* __restrict__ val_p, const int3
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nnz_s) return;
     int bits = 0x3f800000;
-    if (val_p) {
-        const int r = row_of_entry(rowptr_s, M, (int)q);
-        bits = __float_as_int(val_p[rowptr_p[r] + ((int)q - rowptr_s[r])]);
-    }
-    ev[2 * q + 1] = bits;
+    const int r = row_of_entry(rowptr_s, M, (int)q);
+    if (val_p) bits = __float_as_int(val_p[rowptr_p[r] + ((int)q - rowptr_s[r])]);
+    ev[2 * (q + r) + 1] = bits;  // (record position of entry q of row r in the staged kernel's stream)
 }
 
 }  // namespace
@@ -1776,7 +1845,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     const int64_t nblk = (M + R - 1) / R;
     // (Round 3 marked columns whose own row sits far away in the clustered order and gathered them `nt`; level or harmful once the block
     // heights and the clustering depth had settled — profiles/r04/far_marks_by_graph.log — and removed in round 5.)
-    (void)perm;
+    if (!staged_stream_fits(M, nnz)) return hipErrorInvalidValue;
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < K) ++bits;
     size_t sort_bytes = 0;
@@ -1810,13 +1879,14 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.hot_cols), (size_t)nblk * H * 4));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.nhot), (size_t)nblk * 4));
         GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.tasks), (size_t)nblk * kStagedWaves * 16));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + kStagedPad) * 8));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + M + kStagedPad) * 8));
         GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0xFF, (size_t)nblk * H * 4, st));  // unused slots: -1 (the kernel copies nothing for them)
         hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
                            (const int32_t*)idx_out, H, code, t.hot_cols, t.nhot, staged);
         hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, R, kStagedWaves, t.tasks);
-        hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz + kStagedPad)), dim3(256), 0, st, (const int32_t*)code, val_p, nnz,
-                           nnz + kStagedPad, t.ev);
+        hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz)), dim3(256), 0, st, (const int32_t*)code, val_p, rowptr_p, (int)M, nnz,
+                           t.ev);
+        hipLaunchKernelGGL(k_stage_rowends, dim3(grid_for(M + kStagedPad)), dim3(256), 0, st, rowptr_p, perm, M, nnz, t.ev);
         GESPMM_TRY(hipGetLastError());
         unsigned long long h = 0;
         GESPMM_TRY(fetch(&h, (const unsigned long long*)staged, 1, st));  // (synchronises: the temporaries may go)
@@ -1849,7 +1919,7 @@ hipError_t device_staging_set_values(const StagingTables& t, const float* val_p,
             hipLaunchKernelGGL(k_stage_values_split, dim3(grid_for(t.nnz_s)), dim3(256), 0, st, val_p, rowptr_p,
                                (const int32_t*)t.rowptr_s, (int)M, t.nnz_s, t.ev);
     } else if (nnz > 0) {
-        hipLaunchKernelGGL(k_stage_values, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, nnz, t.ev);
+        hipLaunchKernelGGL(k_stage_values, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, rowptr_p, (int)M, nnz, t.ev);
     }
     return hipGetLastError();
 }

@@ -6,6 +6,9 @@
 
 #include "plan_policy.h"
 
+#include <cstddef>
+#include <cstring>
+
 #include "../../include/gespmm.h"
 #include "select.h"
 #include "spmm_kernels.h"
@@ -26,6 +29,40 @@ int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags) {
 }
 
 static bool crc_family(int v) { return v >= GESPMM_VARIANT_CRC && v <= GESPMM_VARIANT_CRC_CWM8; }
+
+// Cost awareness (round 5). Until round 4 AUTO clustered every matrix with >= 16 384 rows and a B beyond 8 MB, whatever the analysis
+// cost and however few launches would use it: the reference's own GCN configuration (pubmed, hidden 128, cached=True) got 52 % SLOWER
+// per epoch, the structureless com-Amazon stand-in lost 16 % inside the reference's 200-launch protocol (profiles/r04/gcn_epochs.log,
+// bench_round4.log). Two estimates, both from numbers known BEFORE the clustering:
+//   gain per launch = gathered bytes (4 nnz N) x expected gain in L2 hit rate x 0.085 us per MB — measured savings per MB of gathers that
+//     turn from misses into hits: 0.071 (com-Amazon-shaped communities: 150 -> 107 us), 0.097 (structureless), 0.10 (LFR, geometric),
+//     0.12 (products-shaped): profiles/r05/probe_calibration.log;
+//   expected gain in hit rate from the WEDGE PROBE (plan_device.hip: k_wedge_probe, one small kernel riding on the validation pass):
+//     the share of sampled (row r; two of its columns c1, c2) wedges with c2 in row c1. Structureless graphs close none (1e-4: gains
+//     0.02-0.15), every graph with communities, triangles or geometry closes 6-58 % (gains 0.29-0.90): 0.1 + 0.9 sqrt(probe), capped
+//     at 0.85; unknown (rectangular matrix, host analysis): 0.6 — the benefit of the doubt;
+//   cost of the analysis = 3.4 ms of launch and synchronisation latency at any size + 1.6 ns per entry up to 2 M + 0.6 ns per entry
+//     (7.4 ms at 1.85 M entries, 75 ms at 124 M: profiles/r04/small_graph_plans.log, bench_round4.log) — device analysis; the host
+//     form is ~30x that.
+CostEstimate estimate_analysis_cost(const PlanFacts& f) {
+    CostEstimate c;
+    if (f.wedge_probe < 0.0) c.hits_gain = 0.60;  // unknown: the benefit of the doubt — only matrices too small to ever pay are skipped
+    else {
+        double r = 0.0, x = f.wedge_probe;  // sqrt by Newton (no <cmath> dependency on the device toolchain's host pass)
+        if (x > 0.0) {
+            r = x < 1.0 ? 1.0 : x;
+            for (int i = 0; i < 40; ++i) r = 0.5 * (r + x / r);
+        }
+        c.hits_gain = 0.10 + 0.90 * r;
+        if (c.hits_gain > 0.85) c.hits_gain = 0.85;
+    }
+    const double gathered_mb = 4.0 * (double)f.nnz * (double)f.N / 1e6;
+    c.gain_us = gathered_mb * c.hits_gain * 0.085;
+    const double e = (double)f.nnz;
+    c.cost_us = 3400.0 + 1.6e-3 * (e < 2e6 ? e : 2e6) + 0.6e-3 * e;
+    if (f.host_analysis) c.cost_us *= 30.0;
+    return c;
+}
 
 AnalysisDecision decide_analysis(const PlanFacts& f) {
     AnalysisDecision a;
@@ -50,6 +87,15 @@ AnalysisDecision decide_analysis(const PlanFacts& f) {
         if (!a.analyse && !f.host_analysis && (f.slab_blocked || mean > 96) && crc_family(f.sel_variant) && big_enough) {
             a.analyse = true;
             a.dense_try = f.slab_blocked;
+        }
+    }
+    a.cost = estimate_analysis_cost(f);
+    if (a.analyse && f.reorder_mode == GESPMM_PLAN_REORDER_AUTO) {
+        const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+        if (a.cost.gain_us * (double)launches < a.cost.cost_us) {
+            a.analyse = false;  // the storage order serves these launches faster than an analysis they would have to pay for
+            a.dense_try = false;
+            a.cost_skipped = true;
         }
     }
     // the model of the XCD L2s: window = B rows that 3 MiB hold; matrices beyond 2^25 non-zeros: the first 2^22
@@ -105,11 +151,12 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
     d.group_task_entries = gb;
     // Staged-rows kernel: worth its tables where a block of clustered rows uses the same B rows again and again
     // (profiles/r03/staged_rows.log, staged_degree_sweep.log; products-shaped communities: 3.0 vs 3.9 ms at N = 128, 5.8 vs
-    // 7.8 ms at N = 256). At N = 128 a row is half of what a load instruction could carry and short rows are level at best
-    // (com-Amazon-shaped communities: 108 vs 106 us; mean degree 8: 239 vs 236 us; from 12 on: 9-15 % ahead); at N = 256 short
-    // rows win as well (com-Amazon-shaped: 196 vs 208 us; mean degree 8: 416 vs 450 us). Device analysis only.
+    // 7.8 ms at N = 256). Until round 4 short rows were level at best at N = 128 (com-Amazon-shaped communities: 108 vs 106 us; mean
+    // degree 8: 239 vs 236 us) and a mean degree of 12 was asked there; with round 5's walk (row ends in the stream, packed
+    // multiply-adds) they win at both widths: com-Amazon-shaped 92.7 vs 107 us (N = 128), 175 vs 216 us (N = 256); mean degree 6 / 8:
+    // x1.06 / x1.14 at N = 128 (profiles/r05/staged_degree_sweep.log, kernel_ab_record_stream.log). Device analysis only.
     const bool v4 = f.variant == GESPMM_VARIANT_AUTO || f.variant == GESPMM_VARIANT_CRC_CWM4 || f.variant == GESPMM_VARIANT_CRC_CWM8;
-    const bool fits = f.nnz > 0 && staged_serves(f.K, f.N);
+    const bool fits = f.nnz > 0 && staged_serves(f.M, f.K, f.N) && staged_stream_fits(f.M, f.nnz);
     const bool want = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
                       (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
                        f.nnz >= (1 << 20) && v4);
@@ -186,8 +233,28 @@ int sddmm_route(const PlanFacts& f, bool reordered, double hits_after, int64_t N
 
 }  // namespace gespmm
 
+namespace {
+constexpr int64_t kQueryBytesV1 = (int64_t)offsetof(gespmm_plan_policy_query, expected_launches);
+constexpr int64_t kAnswerBytesV1 = (int64_t)offsetof(gespmm_plan_policy_answer, cost_skipped);
+}  // namespace
+
 extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a) {
-    if (!q || !a || q->M < 0 || q->K < 0 || q->nnz < 0 || q->N < 0) return GESPMM_EINVAL;
+    return gespmm_plan_policy_v2(q, kQueryBytesV1, a, kAnswerBytesV1);
+}
+
+extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64_t q_bytes, gespmm_plan_policy_answer* a_out, int64_t a_bytes) {
+    if (!q_in || !a_out || q_bytes < kQueryBytesV1 || a_bytes < kAnswerBytesV1 || q_bytes % 4 != 0 || a_bytes % 4 != 0) return GESPMM_EINVAL;
+    gespmm_plan_policy_query qq;
+    std::memset(&qq, 0, sizeof qq);
+    qq.wedge_probe = -1.0;  // (a 0.2 caller: unknown)
+    std::memcpy(&qq, q_in, (size_t)(q_bytes < (int64_t)sizeof qq ? q_bytes : (int64_t)sizeof qq));
+    if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, wedge_probe) + 8) qq.wedge_probe = -1.0;
+    gespmm_plan_policy_answer aa;
+    std::memset(&aa, 0, sizeof aa);
+    const gespmm_plan_policy_query* q = &qq;
+    gespmm_plan_policy_answer* a = &aa;
+
+    if (q->M < 0 || q->K < 0 || q->nnz < 0 || q->N < 0 || q->expected_launches < 0) return GESPMM_EINVAL;
     if (q->variant < GESPMM_VARIANT_AUTO || q->variant >= GESPMM_NUM_VARIANTS || q->reorder < 0 || q->reorder > 2) return GESPMM_EINVAL;
     // the kernel values gespmm_plan_create accepts (2 and 4 belonged to the removed opt-in kernels)
     if (q->kernel != GESPMM_PLAN_KERNEL_AUTO && q->kernel != GESPMM_PLAN_KERNEL_STREAM && q->kernel != GESPMM_PLAN_KERNEL_SEG_STREAM &&
@@ -207,6 +274,8 @@ extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan
     f.user_flags = q->flags;
     f.opt_task_entries = q->task_entries;
     f.opt_row_floor = q->row_floor;
+    f.expected_launches = q->expected_launches;
+    f.wedge_probe = q->wedge_probe;
     gespmm::Selection sel;
     int max_vec = 4;
     while (max_vec > 1 && (q->N % max_vec) != 0) max_vec >>= 1;
@@ -249,5 +318,9 @@ extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan
     a->sddmm_route = gespmm::sddmm_route(f, keep, q->hits_after, Nl);
     a->model_window = ad.model_window;
     a->model_sample = ad.model_sample;
+    a->cost_skipped = ad.cost_skipped;
+    a->est_gain_us = ad.cost.gain_us;
+    a->est_cost_us = ad.cost.cost_us;
+    std::memcpy(a_out, &aa, (size_t)(a_bytes < (int64_t)sizeof aa ? a_bytes : (int64_t)sizeof aa));
     return 0;
 }

@@ -21,6 +21,8 @@ struct PlanFacts {
     bool host_analysis = false;            // GESPMM_PLAN_ANALYSIS_HOST
     int user_flags = 0;                    // gespmm_plan_options.flags
     int opt_task_entries = 0, opt_row_floor = 0;
+    int expected_launches = 0;             // gespmm_plan_options.expected_launches (0 = kDefaultExpectedLaunches)
+    double wedge_probe = -1.0;             // share of sampled wedges (c1, c2 in one row) that close (c2 in row c1); < 0: unknown
 
     int64_t mean_ceil() const { return M > 0 ? (nnz + M - 1) / M : 0; }
     int64_t mean_floor() const { return M > 0 ? nnz / M : 0; }
@@ -29,12 +31,27 @@ struct PlanFacts {
 
 // user flags + the long-row decision from the longest row (SPLIT_LONG_ROWS or STRICT_ORDER is always set on return)
 int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags);
-// mean degree from which AUTO considers the staged-rows kernel at width N
-inline int staged_min_mean_degree(int64_t N) { return N >= 256 ? 5 : 12; }
+// mean degree from which AUTO considers the staged-rows kernel at width N (round 5: 5 at every width — with the record-stream walk the
+// kernel is ahead on short rows at 128 columns too: com-Amazon-shaped communities 92.7 vs 107 us, planted communities of mean degree
+// 6 / 8 / 12: x1.06 / x1.14 / x1.19, profiles/r05/staged_degree_sweep.log; until round 4 short rows were level at best and 12 was asked)
+inline int staged_min_mean_degree(int64_t N) { (void)N; return 5; }
 
 // ---- before the analysis: launch flags, whether to cluster at all, how to model the L2s
+constexpr int kDefaultExpectedLaunches = 200;  // the reference's protocols: ITER = 200 (spmm_test.cu:714), 200 epochs (gcn_custom.py:134)
+
+// What clustering is expected to buy per launch and what the analysis is expected to cost (both in us): the numbers decide_analysis
+// weighs under reorder = AUTO. Pure functions of the facts (shape, width, probe).
+struct CostEstimate {
+    double hits_gain = 0.0;  // expected gain in modelled L2 hit rate
+    double gain_us = 0.0;    // per launch
+    double cost_us = 0.0;    // once
+};
+CostEstimate estimate_analysis_cost(const PlanFacts& f);
+
 struct AnalysisDecision {
     int launch_flags = 0;      // user flags + the long-row decision (exact: the plan has seen the longest row)
+    bool cost_skipped = false; // AUTO would analyse, but the expected launches do not amortise the analysis
+    CostEstimate cost;
     bool analyse = false;      // run clustering + L2 model
     bool dense_try = false;    // a dense graph: the clustered order is kept only on strong community structure
     int64_t model_window = 0;  // B rows one XCD's L2 is modelled to hold

@@ -104,16 +104,21 @@ hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStre
 // spmm_staged.hip — scalar-stream kernel with a block's most used B rows staged in LDS (clustered plans, N = 128 / 256 and, as
 // 256-column tiles bound to XCDs, 512 / 1024; sum).
 // plan_device.hip (device_build_staging) writes the tables: blocks of staged_block_rows(N) consecutive rows of the clustered matrix,
-// `waves` tasks per block (int4 {first row, #rows, CSR begin, CSR end}), per block the staged columns, and the entry stream
-// `ev` = {code, value bits} per entry (code >= 0: column; code < 0: staged slot in its low bits), padded by kStagedPad entries.
+// `waves` tasks per block (int4 {first row, #rows, stream begin, stream end}), per block the staged columns, and the record stream
+// `ev`: per row its entries {code, value bits} (bit 31 of the code clear: column; set: staged slot in its low bits) followed by ONE
+// row-end record {kStagedRowEnd, C row of that row} — also for rows without entries — so a wavefront needs nothing but its stream
+// range: no row pointers, no row ids, no position compares on the walk (round 5). Record position of entry p of row r: p + r; the
+// stream is padded by kStagedPad records.
 constexpr int kStagedMaxWaves = 16;      // wavefronts per block: 4, 8 or 16 (StagedShape)
 constexpr int kStagedLdsPerWave = 4096;  // bytes of staged B rows per wavefront of the block (16 wavefronts: 64 KB)
 constexpr int kStagedPad = 64;
+constexpr int kStagedRowEnd = 0x40000000;  // code of a row-end record (both address shifts of the kernel drop the bit: slot 0 / column 0)
 constexpr int kStagedMaxRow = 2048;  // longer rows are walked by the streaming kernel's long-row pass, not by one wavefront
+inline bool staged_stream_fits(int64_t M, int64_t nnz) { return nnz + M + kStagedPad < (1ll << 31) - 64; }  // 32-bit stream positions
 struct StagedArgs {
-    const int32_t* rowptr;    // clustered matrix
-    const int32_t* ev;        // 2 * (nnz + kStagedPad) words
-    const int32_t* perm;      // C row of clustered row i
+    const int32_t* rowptr;    // clustered matrix (not read by the kernel since round 5: the stream carries the row ends)
+    const int32_t* ev;        // 2 * (nnz + M + kStagedPad) words
+    const int32_t* perm;      // C row of clustered row i (not read by the kernel since round 5: the row-end records carry it)
     const int32_t* tasks;     // nblocks * waves int4
     const int32_t* hot_cols;  // nblocks * H (H = staged_shape(N).slots)
     const int32_t* nhot;      // nblocks
@@ -133,8 +138,8 @@ struct StagedShape {
 StagedShape staged_shape(int64_t N);
 inline int staged_rows_per_block_lds(int64_t N) { return staged_shape(N).slots; }  // H for this width; 0 = width not served
 inline int staged_block_rows(int64_t N) { return staged_shape(N).rows; }
-bool staged_serves(int64_t K, int64_t N);  // width served and B addressable (32-bit offsets; two 4 GB halves for the tiled widths)
-hipError_t launch_spmm_staged(const StagedArgs& a, int64_t K, int64_t N, hipStream_t st);
+bool staged_serves(int64_t M, int64_t K, int64_t N);  // width served, B and C addressable (32-bit offsets; two 4 GB halves for the tiled widths)
+hipError_t launch_spmm_staged(const StagedArgs& a, int64_t M, int64_t K, int64_t N, hipStream_t st);
 
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form
@@ -148,6 +153,9 @@ hipError_t launch_slabplan(const int32_t* rowptr, const int32_t* colind, int32_t
 // baseline_kernels.hip — Gunrock-style edge-parallel atomicAdd scatter (comparison column only)
 hipError_t launch_atomic_scatter(const int32_t* rowptr, const int32_t* colind, const float* in, float* out, int64_t M,
                                  int64_t K, int64_t N, int64_t nnz, hipStream_t st);
+
+// ... and a plain streaming copy dst[i] = src[i] (the read + write rate of the box: bench.py's yardstick for ceiling_frac)
+hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st);
 
 // ... and a plain streaming copy dst[i] = src[i] (the read + write rate of the box: bench.py's yardstick for ceiling_frac)
 hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st);

@@ -1,5 +1,5 @@
 // spmm_staged.hip — the plan's kernel for clustered matrices with rows long enough to share neighbours inside a block:
-// scalar-stream walk + the block's most used B rows staged in LDS (round 3).
+// scalar-branch walk over a record stream + the block's most used B rows staged in LDS (round 3; the record stream: round 5).
 //
 // What bounds the streaming kernels on such a matrix (products-shaped communities, N = 128: 75 % of the gathers hit the L2
 // and the product still takes 3.9 ms = 16 TB/s of gathers) is the vector memory path: every wave-level load instruction costs
@@ -8,32 +8,42 @@
 // is free for the address unit is one that is never issued. Hence:
 //
 //   * ONE ROW PER WAVEFRONT AT A TIME: a B row of N = 64 * VEC floats is one load of VEC dwords per lane. Everything that is the
-//     same for the 64 lanes — the CSR stream (code, value), row ends, C row ids — lives in SGPRs and arrives through the scalar
-//     cache; "is this entry's B row staged?" is a SCALAR branch around one of {ds_read, global_load}: a staged entry issues no
+//     same for the 64 lanes — a record's code and value — is read out of the wavefront's window of the stream into SGPR pairs;
+//     "is this entry's B row staged?" is a SCALAR branch around one of {ds_read, global_load}: a staged entry issues no
 //     vector memory instruction at all;
 //   * a workgroup of 16 wavefronts owns a BLOCK of 96 (N = 128) / 64 (N = 256) consecutive rows of the plan's clustered matrix; the analysis
 //     (plan_device.hip: device_build_staging) lists per block the <= H columns used most often inside it (>= 2 uses; H rows =
-//     64 KB) and rewrites the block's entries: code >= 0 = column, code < 0 = slot of the staged row. The workgroup copies the
-//     listed rows into LDS once, coalesced, then each wavefront walks its share of the block's rows as one stream;
-//   * the scalar unit issues one instruction per clock per CU, so the loop is written to need ~4 of them per entry: {code,
-//     value} interleaved (one s_load per chunk of 8 entries, the next chunk requested before this one's gathers — the CSR
-//     stream is read once, every scalar load goes to memory), ONE vector instruction forms the offset that serves either path
-//     (`code << log2(row bytes)` drops the flag bit: LDS address of the staged row or byte offset of the B row, + the lane's
-//     offset), compare + branch, and the multiply-adds take the value straight from its SGPR.
+//     64 KB) and rewrites the block's entries: bit 31 of the code clear = column, set = slot of the staged row. The workgroup copies
+//     the listed rows into LDS once, coalesced, then each wavefront walks its share of the block's rows as one stream;
+//   * THE RECORD STREAM (round 5): per row its entries {code, value} and then ONE row-end record {kStagedRowEnd, C row} — rows
+//     without entries have theirs too. A wavefront needs nothing but a range of that stream: no row pointers, no row ids, no
+//     position compares, no row cursor. 64 records at a time sit in a register pair (the next window is requested a window ahead,
+//     through the vector path: a scalar load would share its counter with the LDS reads); one ballot per window and kind gives
+//     the masks "B row from memory" and "row end", and a chunk of 8 records tests mask BITS: all staged -> 8 LDS reads without a
+//     branch; no row end -> 8 packed multiply-add groups and nothing else. Round 4's walk compared every entry's position with its
+//     row's end and the task's end: 6.9 scalar + 2.9 branch + 6.4 vector instructions per entry on rows of 12 entries
+//     (profiles/r05/staged_issue_counters.log), now 5.2 + 2.1 + 5.3 per record;
+//   * two multiply-adds per instruction: v_pk_fma_f32 on accumulator PAIRS with the value broadcast from the record's SGPR pair
+//     (op_sel picks its high dword for both halves) — each half is a fused multiply-add rounded like v_fma_f32.
 //
 // Every output element is still ONE fp32 chain over the row's entries in CSR order with one fused multiply-add per entry
 // (spmm_test.cu:182-203 semantics; unweighted matrices carry 1.0f: fma(1, b, acc) == acc + b exactly), so the bits are those
-// of every other variant. Sum reducer, N = 128 or 256, K * N * 4 < 4 GB (32-bit offsets); everything else stays on the
-// streaming kernels. Rows of more than kStagedMaxRow entries never reach this kernel: the plan empties them in the row pointers it
-// passes here and runs them through the streaming kernel's long-row pass afterwards (plan.cpp: plan_run).
+// of every other variant. Sum reducer; N = 128, 256 and — as 256-column tiles bound to XCDs — 512 / 1024; B and C below 4 GB
+// (32-bit lane offsets from an SGPR base; the tiled widths reach 8 GB through two bases); everything else stays on the streaming
+// kernels. Rows of more than kStagedMaxRow entries never reach this kernel: the plan empties them in the row pointers the tables are
+// built from (their row-end record stores zeros) and runs them through the streaming kernel's long-row pass afterwards
+// (plan.cpp: plan_run).
 //
-// The gathers are inline assembly: written as C++ the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read (it
-// cannot see that the two paths never write the same register in the same pass) and one memory access is in flight at a time.
+// The gathers and the row-end chunks are inline assembly: written as C++ the compiler puts `s_waitcnt vmcnt(0)` in front of every
+// LDS read (it cannot see that the two paths never write the same register in the same pass), and its structurizer turns "bit set ->
+// store and zero, else multiply-add" into ~6 scalar instructions and two register copies per record.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "spmm_device.h"
 #include "spmm_kernels.h"
@@ -57,6 +67,15 @@ namespace {
 typedef const __attribute__((address_space(4))) int32_t* cint_ptr;  // constant address space: scalar loads
 using f4v = float __attribute__((ext_vector_type(4)));
 using i2v = int __attribute__((ext_vector_type(2)));
+using v2f = float __attribute__((ext_vector_type(2)));
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 template <int VEC> struct LaneVec;
 template <> struct LaneVec<2> { using type = float __attribute__((ext_vector_type(2))); };
@@ -82,7 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     constexpr int kRowF4 = kRowBytes / 16;
     constexpr int kWin = 64;                        // entries of the stream one wavefront holds in a register pair
     static_assert(kStagedPad >= kWin, "a window is read whole: up to kWin - 1 entries past a task's end");
-    static_assert(kWin % U == 0 && (U == 8 || U == 16), "whole chunks per window");
+    static_assert(kWin % U == 0 && (U == 8 || U == 16), "whole chunks per window, whole groups of four records per chunk");
     static_assert(TSHIFT >= 0 && TSHIFT <= 3, "at most one tile per XCD");
     __shared__ f4v s_hot[H * kRowF4];
 
@@ -110,16 +129,15 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     int hcol[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) hcol[u] = (dbg & 1) ? -1 : hc[(u * kStagedWaves * 64 + tid) / kRowF4];
-    const int row_first = tk[0], nrows = tk[1], wb = tk[2], we = tk[3];
+    const int wb = tk[2], we = tk[3];  // the wavefront's range of the record stream (entries + one row-end record per row)
     const float* Bp = a.B + (size_t)tile * (64 * VEC);
     const float* BpHi = Bp + (1ull << 30);  // + 4 GB (PAGE2)
     (void)BpHi;
     const uint32_t loff = (uint32_t)lane * (4u * VEC);
 
-    // Round trip 2 — the staged rows (slots the block does not use hold -1: no load), and the wavefront's own metadata, all of it
-    // through the VECTOR path: the first window of the entry stream, and the row ends / C rows of its first 64 rows (lane i: row i).
-    // Nothing on the walk below is a scalar MEMORY load — see the header: a scalar load shares its counter with the LDS reads and
-    // is waited for with every chunk.
+    // Round trip 2 — the staged rows (slots the block does not use hold -1: no load) and the first window of the wavefront's
+    // stream, through the VECTOR path. Nothing on the walk below is a scalar MEMORY load — see the header: a scalar load shares its
+    // counter with the LDS reads and is waited for with every chunk. Row ends and C rows arrive WITH the stream (row-end records).
     const f4v* B4 = reinterpret_cast<const f4v*>(a.B);
     f4v stage[4];
 #pragma unroll
@@ -130,13 +148,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     }
     const i2v* evv = reinterpret_cast<const i2v*>(a.ev) + wb;
     i2v win = {0, 0};
-    int rpv = 0, pmv = 0;
-    if (nrows > 0) {
-        win = __builtin_nontemporal_load(evv + lane);  // (the stream is padded: a whole window is always readable)
-        const int rl = (lane < nrows) ? lane : nrows - 1;  // rows 0 .. 63 of the task (clamped to its last row)
-        rpv = __builtin_nontemporal_load(a.rowptr + row_first + 1 + rl);
-        pmv = __builtin_nontemporal_load(a.perm + row_first + rl);
-    }
+    if (we > wb) win = __builtin_nontemporal_load(evv + lane);  // (the stream is padded: a whole window is always readable)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         if (hcol[u] >= 0) s_hot[u * kStagedWaves * 64 + tid] = stage[u];
@@ -147,48 +159,33 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         t_staged = __builtin_readcyclecounter();
     }
-    if (nrows == 0) return;
+    if (we <= wb) return;  // (a task without rows)
     // one offset serves both paths (LDS address of a staged row / byte offset into B): the staging array must sit at LDS address 0
     // (it is the kernel's only LDS object; a compile-time constant — the check folds away)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) f4v*)s_hot != 0u) __builtin_trap();
-    int cur = 0;
-    int rend = __builtin_amdgcn_readlane(rpv, 0);
-    int crow = __builtin_amdgcn_readlane(pmv, 0);
-    float acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-    auto flush = [&]() {  // row `cur` is complete: store it, step to the next one
-        float* Crow = a.C + (((size_t)crow << TSHIFT) + (size_t)tile) * (size_t)(64 * VEC);
-        vec_t out;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) out[i] = acc[i];
-        if constexpr (VEC == 2) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(loff), "v"(out), "s"(Crow) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(loff), "v"(out), "s"(Crow) : "memory");
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-        ++cur;
-        if (cur < nrows) {
-            if ((cur & 63) == 0) {
-                // a task of more than 64 rows (rare: a block is 24-96 rows for 4-16 wavefronts): the next 64 row ends / C rows. Assembly, so
-                // that the wait for these two loads sits in THIS branch — as C++ loads the compiler waits for the vector memory counter
-                // at the join, i.e. after every row's store (measured: the walk then takes a store round trip per row)
-                const int rl = (cur + lane < nrows) ? cur + lane : nrows - 1;
-                const int32_t* rp_src = a.rowptr + row_first + 1 + rl;
-                const int32_t* pm_src = a.perm + row_first + rl;
-                asm volatile(
-                    "global_load_dword %0, %2, off nt\n\t"
-                    "global_load_dword %1, %3, off nt\n\t"
-                    "s_waitcnt vmcnt(0)"
-                    : "=&v"(rpv), "=&v"(pmv)
-                    : "v"(rp_src), "v"(pm_src)
-                    : "memory");
-            }
-            rend = __builtin_amdgcn_readlane(rpv, cur & 63);
-            crow = __builtin_amdgcn_readlane(pmv, cur & 63);
-        }
-    };
-    // code: bit 31 = staged (low bits: LDS slot); else the column
-    auto gather = [&](int code, vec_t& d) {
+    // Accumulators as PAIRS: one v_pk_fma_f32 per two columns, the value broadcast from the record's SGPR pair {code, value} — both
+    // halves take the pair's HIGH dword (op_sel:[1,0,0] op_sel_hi:[1,1,1]). Two fused multiply-adds per instruction, each rounded
+    // like v_fma_f32: the bits of every other variant.
+    // (256-column tiles: the four accumulators are pinned to v[60:63] — inline assembly cannot name the halves of a register
+    //  quadruple, and a row end wants ONE 16-byte store per lane: two 8-byte stores write every line of C in two halves and cost
+    //  the short-row graphs a third of their time, profiles/r05/kernel_ab_record_stream.log)
+    v2f acc[1] = {v2f{0.0f, 0.0f}};
+    f4v acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    (void)acc;
+    (void)acc4;
+    // A row-end record's value word is the C row of the row that ends there (rows without entries have one too: zeros are stored).
+    // C rows are addressed like B rows: SGPR base (+ 4 GB for the upper half, PAGE2) and a 32-bit lane offset `crow << log2(row bytes)`.
+    float* const Cp = a.C + (size_t)tile * (64 * VEC);
+    float* const CpHi = Cp + (1ull << 30);
+    (void)CpHi;
+    // code: bit 31 = staged (low bits: LDS slot), else the column; kStagedRowEnd (bit 30) = row-end record. Both address shifts drop
+    // bits 30 / 31, so a row-end record reads slot 0 in a chunk that gathers from LDS only (harmless, never summed).
+    // `mem` = this chunk's share of the window's memory mask, J = the entry's bit in it: a SCALAR bit test decides the path.
+    auto gather = [&](int code, uint32_t mem, auto J, vec_t& d) {
+        constexpr int kJ = decltype(J)::value;
+        const float* const bp = Bp;        // (named here: a generic lambda does not capture through an asm operand)
+        const float* const bp_hi = BpHi;
+        (void)bp_hi;
         // (the reference to s_hot keeps the staging stores alive: the LDS reads below are invisible to the compiler)
         // (one tile: the same offset serves both paths — LDS address of the staged row / byte offset of the B row — and the
         //  compiler keeps one register; tiled: the strides differ)
@@ -200,9 +197,9 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
             constexpr int kPageBit = 32 - kGlobalShift;  // bit of the column that selects the 4 GB half
             uint64_t base;  // scratch SGPR pair: the chosen half's base
             asm volatile(
-                "s_cmp_lt_i32 %3, 0\n\t"
+                "s_bitcmp0_b32 %3, %8\n\t"
                 "s_cbranch_scc1 1f\n\t"
-                "s_bitcmp1_b32 %3, %7\n\t"
+                "s_bitcmp1_b32 %9, %7\n\t"
                 "s_cselect_b64 %1, %6, %4\n\t"
                 "global_load_dwordx4 %0, %2, %1\n\t"
                 "s_branch 2f\n"
@@ -210,11 +207,11 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
                 "ds_read_b128 %0, %5\n"
                 "2:"
                 : "=&v"(d), "=&s"(base)
-                : "v"(voff), "s"(code), "s"(Bp), "v"(voff_l), "s"(BpHi), "n"(kPageBit)
+                : "v"(voff), "s"(mem), "s"(bp), "v"(voff_l), "s"(bp_hi), "n"(kPageBit), "n"(kJ), "s"(code)
                 : "memory", "scc");
         } else if constexpr (VEC == 2)
             asm volatile(
-                "s_cmp_lt_i32 %2, 0\n\t"
+                "s_bitcmp0_b32 %2, %5\n\t"
                 "s_cbranch_scc1 1f\n\t"
                 "global_load_dwordx2 %0, %1, %3\n\t"
                 "s_branch 2f\n"
@@ -222,11 +219,11 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
                 "ds_read_b64 %0, %4\n"
                 "2:"
                 : "=&v"(d)
-                : "v"(voff), "s"(code), "s"(Bp), "v"(voff_l)
+                : "v"(voff), "s"(mem), "s"(bp), "v"(voff_l), "n"(kJ)
                 : "memory", "scc");
         else
             asm volatile(
-                "s_cmp_lt_i32 %2, 0\n\t"
+                "s_bitcmp0_b32 %2, %5\n\t"
                 "s_cbranch_scc1 1f\n\t"
                 "global_load_dwordx4 %0, %1, %3\n\t"
                 "s_branch 2f\n"
@@ -234,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
                 "ds_read_b128 %0, %4\n"
                 "2:"
                 : "=&v"(d)
-                : "v"(voff), "s"(code), "s"(Bp), "v"(voff_l)
+                : "v"(voff), "s"(mem), "s"(bp), "v"(voff_l), "n"(kJ)
                 : "memory", "scc");
     };
     auto gather_lds = [&](int code, vec_t& d) {  // a chunk whose entries are all staged: no branch, no vector memory
@@ -243,27 +240,112 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
         if constexpr (VEC == 2) asm volatile("ds_read_b64 %0, %1" : "=&v"(d) : "v"(voff_l) : "memory");
         else asm volatile("ds_read_b128 %0, %1" : "=&v"(d) : "v"(voff_l) : "memory");
     };
-    auto fma_row = [&](int vbits, const vec_t& b) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "s"(vbits), "v"(b[i]));
+    auto fma_row = [&](uint64_t cv, const vec_t& b) {
+        if constexpr (VEC == 2) {
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[0]) : "s"(cv), "v"(b));
+        } else {
+            const v2f blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
+            asm("v_pk_fma_f32 v[60:61], %1, %2, v[60:61] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                "v_pk_fma_f32 v[62:63], %1, %3, v[62:63] op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+                : "+{v[60:63]}"(acc4)
+                : "s"(cv), "v"(blo), "v"(bhi));
+        }
     };
-    // (Window slots past `we` belong to the next task or the padding: harmless gathers — staged slots are < H, columns are
-    // valid — that are not summed.)
+    // Four records of a chunk that holds a row end, as ONE block of assembly: per record a scalar bit test of the chunk's row-end
+    // mask and a branch that is not taken for an entry (-> its multiply-adds, fall through to the next record); the row-end code sits
+    // behind the four (store the accumulators to C row `value word`, zero them, jump back). Written out because the compiler's
+    // structurizer turns the same C++ into ~6 scalar instructions and two register copies per record.
+#define GESPMM_FMA2(A, C, B) "v_pk_fma_f32 " A ", " C ", " B ", " A " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+    auto consume4 = [&](uint32_t ends, const uint64_t* cv, const vec_t* b) {
+        uint32_t t;
+        const uint32_t r0 = (uint32_t)(cv[0] >> 32), r1 = (uint32_t)(cv[1] >> 32), r2 = (uint32_t)(cv[2] >> 32), r3 = (uint32_t)(cv[3] >> 32);
+        if constexpr (VEC == 2) {
+#define GESPMM_END2(R) "v_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1\n\tv_mov_b64 %[a], 0\n\t"
+            asm volatile(
+                "s_bitcmp1_b32 %[e], 0\n\ts_cbranch_scc1 10f\n\t" GESPMM_FMA2("%[a]", "%[c0]", "%[b0]") "\n11:\n\t"
+                "s_bitcmp1_b32 %[e], 1\n\ts_cbranch_scc1 20f\n\t" GESPMM_FMA2("%[a]", "%[c1]", "%[b1]") "\n21:\n\t"
+                "s_bitcmp1_b32 %[e], 2\n\ts_cbranch_scc1 30f\n\t" GESPMM_FMA2("%[a]", "%[c2]", "%[b2]") "\n31:\n\t"
+                "s_bitcmp1_b32 %[e], 3\n\ts_cbranch_scc1 40f\n\t" GESPMM_FMA2("%[a]", "%[c3]", "%[b3]")
+                "s_branch 99f\n"
+                "10:\n\t" GESPMM_END2("%[r0]") "s_branch 11b\n"
+                "20:\n\t" GESPMM_END2("%[r1]") "s_branch 21b\n"
+                "30:\n\t" GESPMM_END2("%[r2]") "s_branch 31b\n"
+                "40:\n\t" GESPMM_END2("%[r3]") "\n99:"
+                : [a] "+v"(acc[0]), [t] "=&v"(t)
+                : [e] "s"(ends), [c0] "s"(cv[0]), [c1] "s"(cv[1]), [c2] "s"(cv[2]), [c3] "s"(cv[3]), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]),
+                  [b3] "v"(b[3]), [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [sh] "n"(kGlobalShift), [lo] "v"(loff), [C] "s"(Cp)
+                : "memory", "scc");
+#undef GESPMM_END2
+        } else {
+            v2f bl[4], bh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bl[j] = __builtin_shufflevector(b[j], b[j], 0, 1);
+                bh[j] = __builtin_shufflevector(b[j], b[j], 2, 3);
+            }
+            // (one 16-byte store per lane; TWO wait states before the stored registers are overwritten — a store wider than 8 bytes reads its data late, gfx940+: a single one let the zeros through now and then, cora at N = 1024)
+#define GESPMM_STORE4(BASE) "global_store_dwordx4 %[t], v[60:63], " BASE " sc1\n\ts_nop 1\n\tv_mov_b64 v[60:61], 0\n\tv_mov_b64 v[62:63], 0\n\t"
+#define GESPMM_ROWS4(END)                                                                                                                  \
+    "s_bitcmp1_b32 %[e], 0\n\ts_cbranch_scc1 10f\n\t" GESPMM_FMA2("v[60:61]", "%[c0]", "%[b0]") GESPMM_FMA2("v[62:63]", "%[c0]", "%[h0]") "\n11:\n\t" \
+    "s_bitcmp1_b32 %[e], 1\n\ts_cbranch_scc1 20f\n\t" GESPMM_FMA2("v[60:61]", "%[c1]", "%[b1]") GESPMM_FMA2("v[62:63]", "%[c1]", "%[h1]") "\n21:\n\t" \
+    "s_bitcmp1_b32 %[e], 2\n\ts_cbranch_scc1 30f\n\t" GESPMM_FMA2("v[60:61]", "%[c2]", "%[b2]") GESPMM_FMA2("v[62:63]", "%[c2]", "%[h2]") "\n31:\n\t" \
+    "s_bitcmp1_b32 %[e], 3\n\ts_cbranch_scc1 40f\n\t" GESPMM_FMA2("v[60:61]", "%[c3]", "%[b3]") GESPMM_FMA2("v[62:63]", "%[c3]", "%[h3]")              \
+    "s_branch 99f\n"                                                                                                                      \
+    "10:\n\t" END("%[r0]") "s_branch 11b\n"                                                                                              \
+    "20:\n\t" END("%[r1]") "s_branch 21b\n"                                                                                              \
+    "30:\n\t" END("%[r2]") "s_branch 31b\n"                                                                                              \
+    "40:\n\t" END("%[r3]") "\n99:"
+            if constexpr (!PAGE2) {
+#define GESPMM_END4(R) "v_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\t" GESPMM_STORE4("%[C]")
+                asm volatile(GESPMM_ROWS4(GESPMM_END4)
+                             : [a4] "+{v[60:63]}"(acc4), [t] "=&v"(t)
+                             : [e] "s"(ends), [c0] "s"(cv[0]), [c1] "s"(cv[1]), [c2] "s"(cv[2]), [c3] "s"(cv[3]), [b0] "v"(bl[0]), [b1] "v"(bl[1]),
+                               [b2] "v"(bl[2]), [b3] "v"(bl[3]), [h0] "v"(bh[0]), [h1] "v"(bh[1]), [h2] "v"(bh[2]), [h3] "v"(bh[3]), [r0] "s"(r0),
+                               [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [sh] "n"(kGlobalShift), [lo] "v"(loff), [C] "s"(Cp)
+                             : "memory", "scc");
+#undef GESPMM_END4
+            } else {
+                constexpr int kPageBitC = 32 - kGlobalShift;  // bit of the C row that selects the 4 GB half
+                uint64_t base;
+#define GESPMM_END4P(R) "s_bitcmp1_b32 " R ", %[pg]\n\ts_cselect_b64 %[cb], %[Chi], %[C]\n\tv_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\t" GESPMM_STORE4("%[cb]")
+                asm volatile(GESPMM_ROWS4(GESPMM_END4P)
+                             : [a4] "+{v[60:63]}"(acc4), [t] "=&v"(t), [cb] "=&s"(base)
+                             : [e] "s"(ends), [c0] "s"(cv[0]), [c1] "s"(cv[1]), [c2] "s"(cv[2]), [c3] "s"(cv[3]), [b0] "v"(bl[0]), [b1] "v"(bl[1]),
+                               [b2] "v"(bl[2]), [b3] "v"(bl[3]), [h0] "v"(bh[0]), [h1] "v"(bh[1]), [h2] "v"(bh[2]), [h3] "v"(bh[3]), [r0] "s"(r0),
+                               [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [sh] "n"(kGlobalShift), [lo] "v"(loff), [C] "s"(Cp), [Chi] "s"(CpHi),
+                               [pg] "n"(kPageBitC)
+                             : "memory", "scc");
+#undef GESPMM_END4P
+            }
+#undef GESPMM_ROWS4
+#undef GESPMM_STORE4
+        }
+    };
+#undef GESPMM_FMA2
+    // The walk (round 5). One ballot per window and kind turns the codes into two masks — records whose B row comes from memory,
+    // row-end records — and a chunk of U records tests mask BITS: a chunk without a row end is U multiply-add groups and nothing else,
+    // a chunk that gathers from LDS only has no branch on its gathers. The walk used to compare every entry's position with its row's
+    // end and the task's end and to step a row cursor (row pointers and C rows in two more registers): 6.9 scalar + 2.9 branch
+    // instructions per entry on a graph with rows of 12 entries, and the scalar unit — one instruction per clock per CU — was the
+    // busiest unit of the kernel (profiles/r05/staged_issue_counters.log). A task's last record is a row end, so records behind `we`
+    // (the next task's, or the padding: gathered, harmlessly) only ever reach an accumulator that is never stored.
     for (int kw = wb; kw < we; kw += kWin) {
         // the next window is requested a whole window (kWin / U chunks) before it is needed; only chunks that gather from memory
         // themselves wait for the vector memory counter, and those wait for their own (younger) loads anyway
         i2v nxt = win;
         if (kw + kWin < we) nxt = __builtin_nontemporal_load(evv + (kw - wb) + kWin + lane);
-        const uint64_t gmask = (dbg & 2) ? 0ull : __ballot(win.x >= 0);  // entries of this window whose B row comes from memory
+        const uint64_t gmask = (dbg & 2) ? 0ull : __ballot((uint32_t)win.x < (uint32_t)kStagedRowEnd);  // B row from memory
+        uint64_t lmask = __ballot((win.x & kStagedRowEnd) != 0 && win.x >= 0);                          // row-end records ...
+        if (we - kw < kWin) lmask &= (1ull << (we - kw)) - 1ull;                                          // ... of THIS task
 #pragma unroll 1
         for (int c = 0; c < kWin; c += U) {
-            const int k = kw + c;
-            if (k >= we) break;
-            int code[U], vb[U];
+            if (kw + c >= we) break;
+            uint64_t cv[U];  // {code, value bits} of the chunk's records: SGPR pairs
+            int code[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 code[j] = __builtin_amdgcn_readlane(win.x, c + j);
-                vb[j] = __builtin_amdgcn_readlane(win.y, c + j);
+                cv[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.y, c + j) << 32) | (uint32_t)code[j];
             }
             vec_t bv[U];
             const uint32_t anymem = (uint32_t)(gmask >> c) & ((1u << U) - 1u);
@@ -272,28 +354,22 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
                 for (int j = 0; j < U; ++j) gather_lds(code[j], bv[j]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else {
-#pragma unroll
-                for (int j = 0; j < U; ++j) gather(code[j], bv[j]);
+                static_for<U>([&](auto J) { gather(code[decltype(J)::value], anymem, J, bv[decltype(J)::value]); });
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) asm volatile("" : "+v"(bv[j]));  // (uses of bv stay behind the wait)
-            if (k + U <= rend) {
+            const uint32_t ends = (uint32_t)(lmask >> c) & ((1u << U) - 1u);
+            if (ends == 0) {
 #pragma unroll
-                for (int j = 0; j < U; ++j) fma_row(vb[j], bv[j]);
+                for (int j = 0; j < U; ++j) fma_row(cv[j], bv[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    if (k + j < we) {
-                        while (k + j >= rend) flush();  // rows ending before this entry (incl. empty ones)
-                        fma_row(vb[j], bv[j]);
-                    }
-                }
+                for (int j = 0; j < U; j += 4) consume4(ends >> j, cv + j, bv + j);
             }
         }
         win = nxt;
     }
-    while (cur < nrows) flush();  // last row and any trailing empty rows
     if (dbg & 4) {
         const uint64_t t_walk = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -337,15 +413,16 @@ StagedShape staged_shape(int64_t N) {
     return sh;
 }
 
-// B beyond 4 GB: two 4 GB halves (tiled widths only), up to 8 GB.
-bool staged_serves(int64_t K, int64_t N) {
+// B and C rows are addressed by a 32-bit lane offset from an SGPR base: the larger of the two matrices must stay below 4 GB — or, for the
+// tiled widths, below 8 GB (two 4 GB halves, the base chosen by one bit of the row index).
+bool staged_serves(int64_t M, int64_t K, int64_t N) {
     int t;
     if (!staged_tile_cols(N, &t)) return false;
-    const uint64_t bytes = (uint64_t)K * (uint64_t)N * 4ull;
+    const uint64_t bytes = (uint64_t)(M > K ? M : K) * (uint64_t)N * 4ull;
     return bytes < 0xFFFF0000ull || (t >= 1 && bytes < 0x1FFFF0000ull);
 }
 
-hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t K, int64_t N, hipStream_t st) {
+hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t M, int64_t K, int64_t N, hipStream_t st) {
     StagedArgs a = a_in;
     static const int dbg_env = (GESPMM_STAGED_INSTRUMENT && getenv("GESPMM_STAGED_DEBUG")) ? atoi(getenv("GESPMM_STAGED_DEBUG")) : 0;
     a.debug = dbg_env;
@@ -360,10 +437,10 @@ hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t K, int64_t N, hipS
     if (dbg_env & 4) (void)hipMemsetAsync(dbg_buf, 0, dbg_need * 8, st);
     a.dbg_clk = dbg_buf;
     if (a.nblocks <= 0) return hipSuccess;
-    if (!staged_serves(K, N)) return hipErrorInvalidValue;
+    if (!staged_serves(M, K, N)) return hipErrorInvalidValue;
     int t;
     const int tc = staged_tile_cols(N, &t);
-    const bool paged = (uint64_t)K * (uint64_t)N * 4ull >= 0xFFFF0000ull;
+    const bool paged = (uint64_t)(M > K ? M : K) * (uint64_t)N * 4ull >= 0xFFFF0000ull;
     const dim3 grid((unsigned)a.nblocks << (t > 0 ? t : 0)), block((unsigned)a.waves * 64);
     static const int u_env = getenv("GESPMM_STAGED_U") ? atoi(getenv("GESPMM_STAGED_U")) : 0;  // experiment knob: entries in flight per wavefront
 #define GESPMM_STAGED_LAUNCH(VEC, U, TS, PG)                                                                                   \

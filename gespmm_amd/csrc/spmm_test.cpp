@@ -40,6 +40,8 @@
 //                   loop, its time printed; same results) — with --validate the planned product is checked as well
 //   --tune          with --plan: the plan's kernel is chosen by gespmm_plan_tune (candidates timed on the driver's operands) before the
 //                   timed loop; the tuning time is printed with the plan
+//   --expected-launches n   with --plan: the launches the plan is told to expect (default: --iters, i.e. what the timed loop will run);
+//                   an AUTO plan skips its analysis where that many launches would not pay for it
 //   --describe      print what the library launches for each N (gespmm_describe_launch)
 //   --cache dir     keep the parsed matrix as a binary file in `dir` and reuse it next time
 //
@@ -213,6 +215,7 @@ int main(int argc, char** argv) {
     bool validate = false, cpu_baseline = false, use_values = false, seed_given = false, vendor = true, describe = false;
     bool atomic_baseline = false, use_plan = false, tune_plan = false;
     unsigned seed = 0;
+    int expected_launches = 0;  // 0: what the timed loop runs (--iters)
     std::vector<int> ncols_list;
     const char* out_path = "spmm_test_out.out";
     const char* mtx_path = nullptr;
@@ -240,13 +243,14 @@ int main(int argc, char** argv) {
         else if (a == "--atomic-baseline") atomic_baseline = true;
         else if (a == "--plan") use_plan = true;
         else if (a == "--tune") use_plan = tune_plan = true;
+        else if (a == "--expected-launches") expected_launches = atoi(next("--expected-launches"));
         else if (a == "--cache") cache_dir = next("--cache");
         else if (positional == 0) { mtx_path = argv[i]; positional++; }
         else if (positional == 1) { dev_id = atoi(argv[i]); positional++; }
     }
     if (!mtx_path) {
         fprintf(stderr, "usage: %s <file.mtx> [device_id] [--ncols a,b,c] [--method m] [--iters n] [--seed s] "
-                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--plan] [--tune] [--no-vendor] [--describe] [--out path]\n", argv[0]);
+                        "[--use-values] [--validate] [--cpu-baseline] [--atomic-baseline] [--plan] [--tune] [--expected-launches n] [--no-vendor] [--describe] [--out path]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (iters < 1) iters = 1;
@@ -453,9 +457,12 @@ int main(int argc, char** argv) {
         gespmm_plan* plan = nullptr;
         if (use_plan) {
             const auto t0 = std::chrono::steady_clock::now();
-            CHECK_GE(gespmm_plan_create(&plan, g.indptr_dev, g.indices_dev, g.data_dev, M, K, nnz, N,
-                                        method == GESPMM_VARIANT_NAIVE || method == GESPMM_VARIANT_PARREDUCE ? GESPMM_VARIANT_AUTO : method,
-                                        nullptr, nullptr));
+            gespmm_plan_options po;
+            memset(&po, 0, sizeof po);
+            po.expected_launches = expected_launches > 0 ? expected_launches : iters;
+            CHECK_GE(gespmm_plan_create_v2(&plan, g.indptr_dev, g.indices_dev, g.data_dev, M, K, nnz, N,
+                                           method == GESPMM_VARIANT_NAIVE || method == GESPMM_VARIANT_PARREDUCE ? GESPMM_VARIANT_AUTO : method,
+                                           &po, (int64_t)sizeof po, nullptr));
             if (tune_plan) CHECK_GE(gespmm_plan_tune(plan, g.B_dev, g.C_dev, N, 3, nullptr));
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             char what[768];

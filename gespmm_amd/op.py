@@ -109,6 +109,9 @@ class GCNConv(torch.nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.improved, self.cached, self.normalize = improved, cached, normalize
         self.tune_plans = bool(kwargs.pop("tune_plans", False))
+        # extension: products each cached plan is expected to serve (0 = 200: the reference trains 200 epochs, gcn_custom.py:134, one
+        # forward and one backward product per layer and epoch) — the plans weigh their analysis against it (SpmmPlan)
+        self.expected_launches = int(kwargs.pop("expected_launches", 0))
         self.weight = Parameter(torch.empty(in_channels, out_channels))
         self.bias = Parameter(torch.empty(out_channels)) if bias else None
         if not bias:
@@ -152,12 +155,14 @@ class GCNConv(torch.nn.Module):
             # Keyed on the addresses only. That is safe: the plans hold strong references to the index tensors they were
             # made from, so those addresses cannot be recycled for another graph while the plans are alive, and SpmmPlan
             # itself notices in-place edits of the pattern through the tensors' version counters (and raises). The analysis
-            # runs on the device: ~6 ms per direction for a com-Amazon-sized graph, ~0.1 ms for pubmed.
+            # runs on the device and is weighed against the launches it serves (round 5): a com-Amazon-sized graph with communities
+            # is clustered (~7 ms per direction), pubmed keeps its storage order (one validation pass, ~0.1 ms).
             key = (rowptr.data_ptr(), colind.data_ptr(), colptr.data_ptr(), rowind.data_ptr(), h.shape[1])
             if self.cached_plans is None or self.cached_plans[0] != key:
                 n = rowptr.numel() - 1
-                self.cached_plans = (key, (_spmm.SpmmPlan(rowptr, colind, colptr.numel() - 1, h.shape[1]),
-                                           _spmm.SpmmPlan(colptr, rowind, n, h.shape[1])))
+                self.cached_plans = (key, (_spmm.SpmmPlan(rowptr, colind, colptr.numel() - 1, h.shape[1],
+                                                          expected_launches=self.expected_launches),
+                                           _spmm.SpmmPlan(colptr, rowind, n, h.shape[1], expected_launches=self.expected_launches)))
                 if self.tune_plans and not torch.cuda.is_current_stream_capturing():
                     with torch.no_grad():  # kernel choice by measurement, once per direction (same bits whichever wins)
                         fwd, bwd = self.cached_plans[1]

@@ -98,10 +98,14 @@ class SpmmPlan:
     The plan keeps references to ``rowptr`` / ``colind`` (and the values it last saw) and notices in-place edits
     through the tensors' version counters: new VALUES are re-permuted automatically, a changed PATTERN raises —
     make a new plan. One plan serves one stream at a time.
+
+    ``expected_launches`` (0 = 200, the reference's protocols): with ``reorder="auto"`` the analysis is weighed against the
+    products that will use it — a matrix whose estimated gain x launches does not pay for the estimated analysis time keeps
+    its storage order and costs one validation pass (``describe()`` says so).
     """
 
     def __init__(self, rowptr, colind, K, N, variant=_lib.VARIANT_AUTO, values=None, reorder="auto", task_entries=0,
-                 threads=0, flags=0, row_floor=0, kernel="auto", analysis="device"):
+                 threads=0, flags=0, row_floor=0, kernel="auto", analysis="device", expected_launches=0):
         _need(rowptr, "rowptr", torch.int32, 1)
         _need(colind, "colind", torch.int32, 1)
         if values is not None:
@@ -119,7 +123,7 @@ class SpmmPlan:
         kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM,
                 "staged": _lib.PLAN_KERNEL_STAGED}[kernel]
         where = {"device": _lib.PLAN_ANALYSIS_DEVICE, "host": _lib.PLAN_ANALYSIS_HOST}[analysis]
-        opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where)
+        opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where, int(expected_launches))
         self._handle = ctypes.c_void_p()
         M, K_, N_, nnz, var = self.shape
         with _on_device(dev):

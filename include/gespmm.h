@@ -285,6 +285,9 @@ typedef struct gespmm_plan_options {
     int32_t flags;         /* GESPMM_FLAG_* applied to every launch (e.g. GESPMM_FLAG_STRICT_ORDER) */
     int32_t kernel;        /* GESPMM_PLAN_KERNEL_*: which kernel a clustered plan launches */
     int32_t analysis;      /* GESPMM_PLAN_ANALYSIS_*: where the clustering / L2 model / task cutting run (since 0.2) */
+    int32_t expected_launches; /* products this plan is expected to serve, 0 = 200 (the reference's ITER, spmm_test.cu:714; its GCN runs 200
+                              epochs, gcn_custom.py:134). reorder = AUTO weighs the analysis against them: clustering is skipped when the
+                              estimated gain per launch x launches does not pay for its estimated time (since 0.3, gespmm_plan_create_v2 only) */
 } gespmm_plan_options;
 /*
  * Plan options and versions. Every field's default is 0 and fields are only ever APPENDED. gespmm_plan_create is the
@@ -385,6 +388,11 @@ typedef struct gespmm_plan_policy_query {
     int32_t reorder, kernel, analysis, flags, task_entries, row_floor; /* as in gespmm_plan_options */
     double hits_before, hits_after; /* modelled L2 hit rates in storage / clustered order */
     double staged_fraction;  /* share of the entries whose B row a staged-rows block holds in LDS */
+    /* since 0.3 (read by gespmm_plan_policy_v2 when q_bytes covers them) */
+    int32_t expected_launches; /* as in gespmm_plan_options (0 = 200) */
+    int32_t reserved0;
+    double wedge_probe;      /* share of sampled (row r; c1, c2 in r) wedges with c2 in row c1 — the plan's cheap structure probe on square
+                                matrices; negative = unknown (rectangular matrix, host analysis) */
 } gespmm_plan_policy_query;
 typedef struct gespmm_plan_policy_answer {
     int32_t launch_flags;      /* user flags + GESPMM_FLAG_SPLIT_LONG_ROWS or _STRICT_ORDER */
@@ -398,8 +406,14 @@ typedef struct gespmm_plan_policy_answer {
     int32_t sddmm_route;       /* 0 CSR call, 1 COO on expanded row ids, 2 clustered edge order + scatter */
     int32_t narrow_vec4;       /* the launch at N_launch <= 64 takes 4 floats per lane (variant 3) instead of 1 */
     int64_t model_window, model_sample;
+    /* since 0.3 (written by gespmm_plan_policy_v2 when a_bytes covers them) */
+    int32_t cost_skipped;      /* reorder = AUTO would have analysed, but gain x launches < cost: storage order, no analysis */
+    int32_t reserved1;
+    double est_gain_us;        /* estimated saving per launch if the clustered order is kept */
+    double est_cost_us;        /* estimated time of the analysis */
 } gespmm_plan_policy_answer;
-int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);
+int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);  /* the 0.2 layouts (up to staged_fraction / model_sample) */
+int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q, int64_t q_bytes, gespmm_plan_policy_answer* a, int64_t a_bytes);
 
 /*
  * Comparison column, not a product path: the Gunrock app's edge map

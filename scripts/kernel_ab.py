@@ -81,7 +81,7 @@ def main():
                 out.append("plain %.1f" % t)
             for kern in (["auto"] if args.auto else []) + args.kernels:
                 try:
-                    p = spmm.SpmmPlan(rp, ci, K, N, values=val, **({} if kern == "auto" else {"reorder": True, "kernel": kern}))
+                    p = spmm.SpmmPlan(rp, ci, K, N, values=val, **({"expected_launches": 1000000} if kern == "auto" else {"reorder": True, "kernel": kern}))
                 except Exception as ex:  # noqa: BLE001
                     out.append("%s n/a (%s)" % (kern, str(ex)[:40]))
                     continue

@@ -3,7 +3,7 @@ intra-community degree = 2/3 of the mean), N = 128 and 256: staged-rows against 
     python scripts/staged_degree_sweep.py"""
 import statistics, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 import gespmm_amd
 from gespmm_amd import graphs, spmm
 
@@ -18,7 +18,7 @@ def timed(fn, reps=20):
 
 
 M = 600_000
-for mean in (8, 12, 16, 24, 32, 48):
+for mean in [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else '8,12,16,24,32,48'.split(','))]:
     nnz = M * mean
     rp, ci, _ = graphs.community_csr(M, nnz, M // 48, 512, mean * 2.0 / 3.0, 0.6, 1.5, 1.55, 42, "cuda")
     val = torch.rand(nnz, device="cuda") - 0.5

@@ -72,9 +72,10 @@ def test_plan_flag_validates_and_times_through_the_analysis_stage(tmp_path):
     assert "validate done (8 variants, N=64)" in r.stdout and "validate done (8 variants, N=128)" in r.stdout  # 0..5, AUTO, plan
     assert re.search(r"N=128 plan \([0-9.]+ s\): order=", r.stdout), r.stdout
     assert re.search(r"N=128 method=-1 plan: [0-9.]+ ms/iter", r.stdout)
-    # --tune: the plan's kernel by measurement before the timed loop (pubmed clusters at N = 128; the product still validates)
+    # --tune: the plan's kernel by measurement before the timed loop (pubmed clusters at N = 128 once enough launches are expected to
+    # pay for the analysis — 20 would not, round 5; the product still validates)
     r = subprocess.run([DRIVER, os.path.join(GOLDEN, "pubmed.mtx"), "--tune", "--validate", "--ncols", "128", "--method", "-1",
-                        "--iters", "20", "--seed", "5", "--no-vendor", "--out", str(tmp_path / "o2.csv")], cwd=tmp_path,
+                        "--iters", "20", "--expected-launches", "100000", "--seed", "5", "--no-vendor", "--out", str(tmp_path / "o2.csv")], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "WA" not in r.stdout, r.stdout

@@ -121,7 +121,7 @@ def test_full_size_community_graph_auto_plan(pkg, oracle):
     plan = spmm.SpmmPlan(rp, ci, M, 128, values=val)
     d = plan.describe()
     assert d.startswith("order=clustered"), d
-    assert "kernel=batch-stream" in d and "group_tasks=" in d, d  # short rows: batch kernel (plan_prefers_segmented)
+    assert "kernel=staged-rows" in d and "group_tasks=" in d, d  # round 5: the staged-rows kernel on short rows too (92.7 vs 107 us)
     B = (torch.randint(0, 100, (M, 128), device="cuda", dtype=torch.int32) - 50).float() / 100
     got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
     ref = spmm.csr_spmm(rp, ci, val, B)
@@ -298,7 +298,7 @@ def test_cached_memory_limit_and_release(pkg):
     for limit in (0, 1 << 30, -1):  # 0: nothing is kept between plans
         _lib.set_cached_memory_limit(limit)
         for _ in range(2):
-            plan = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 128)
+            plan = spmm.SpmmPlan(g["rowptr"], g["colind"], g["K"], 128, expected_launches=100000)  # (a quarter-size graph: 200 would not pay)
             assert plan.clustered
             del plan
         _lib.release_cached_memory()

@@ -10,9 +10,11 @@ SPLIT, STRICT, SHALLOW = _lib.FLAG_SPLIT_LONG_ROWS, _lib.FLAG_STRICT_ORDER, _lib
 # name, (M, nnz, N, max_degree, hits_before, hits_after, staged_fraction), expected subset of the answer
 TABLE = [
     # ---- BASELINE configs (the stand-ins' measured analysis numbers)
-    ("C2a com-amazon-sbm N=128", (334863, 1851744, 128, 120, 0.018, 0.651, 0.0),
-     dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=40, group_task_entries=16, build_staged=0, shallow_unroll=1,
+    ("C2a com-amazon-sbm N=128", (334863, 1851744, 128, 120, 0.018, 0.651, 0.750),  # round 5: staged-rows on short rows too (92.7 vs 107 us)
+     dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=40, group_task_entries=16, build_staged=1, keep_staged=1, shallow_unroll=1,
           segmented=0, launch_flags=STRICT, sddmm_route=2, narrow_vec4=0)),
+    ("planted communities, mean degree 6, N=128: share 0.515 stays with the streaming kernels", (600000, 3600000, 128, 40, 0.01, 0.60, 0.515),
+     dict(keep_clustered=1, build_staged=1, keep_staged=0)),
     ("C2a com-amazon-like N=128", (334863, 1851744, 128, 499, 0.025, 0.176, 0.0),
      dict(analyse=1, keep_clustered=1, task_entries=40, build_staged=0, shallow_unroll=0, segmented=0, sddmm_route=1)),
     ("C2a com-amazon-sbm N=32", (334863, 1851744, 32, 120, 0.09, 0.70, 0.0),
@@ -66,12 +68,54 @@ TABLE = [
 @pytest.mark.parametrize("name,shape,expect", TABLE, ids=[t[0] for t in TABLE])
 def test_policy_table(name, shape, expect):
     M, nnz, N, maxdeg, hb, ha, sf = shape
-    got = _lib.plan_policy(M, M, nnz, N, maxdeg, hb, ha, sf)
+    # (steady state — enough launches for any analysis to pay: this table pins the structure and kernel rules; the cost rule has its own)
+    got = _lib.plan_policy(M, M, nnz, N, maxdeg, hb, ha, sf, expected_launches=1000000)
     for k, v in expect.items():
         if k == "launch_flags":
             assert got[k] & (SPLIT | STRICT) == v, (name, k, got)
         else:
             assert got[k] == v, (name, k, got)
+
+
+# The cost rule (round 5, plan_policy.cpp: estimate_analysis_cost): name, (M, nnz, N, wedge probe, expected launches) -> analysed or skipped.
+# Probes as measured by scripts/probe_calibration.py (profiles/r05/probe_calibration.log).
+COST_TABLE = [
+    ("com-amazon-sbm N=128, 200 launches: 55 us x 200 > 7.5 ms", (334863, 1851744, 128, 0.416, 0), dict(analyse=1, cost_skipped=0)),
+    ("com-amazon-like N=128, 200 launches: a structureless graph does not pay (was -16 % in round 4)", (334863, 1851744, 128, 0.0001, 0),
+     dict(analyse=0, cost_skipped=1)),
+    ("com-amazon-like N=128, 2000 launches: it does", (334863, 1851744, 128, 0.0001, 2000), dict(analyse=1, cost_skipped=0)),
+    ("com-amazon-sbm N=32, 200 launches: 14 us x 200 < 7.5 ms", (334863, 1851744, 32, 0.416, 0), dict(analyse=0, cost_skipped=1)),
+    ("com-amazon-sbm N=32, 1000 launches", (334863, 1851744, 32, 0.416, 1000), dict(analyse=1, cost_skipped=0)),
+    ("pubmed N=128, 200 launches: the reference's GCN (was +52 % per epoch in round 4)", (19717, 108365, 128, 0.114, 0), dict(analyse=0, cost_skipped=1)),
+    ("pubmed N=128, rectangular / unknown probe", (19717, 108365, 128, -1.0, 0), dict(analyse=0, cost_skipped=1)),
+    ("pubmed N=128, 10 000 launches", (19717, 108365, 128, 0.114, 10000), dict(analyse=1, cost_skipped=0)),
+    ("products-sbm N=128, 200 launches", (2449029, 123718280, 128, 0.320, 0), dict(analyse=1, cost_skipped=0)),
+    ("products-like N=128, 200 launches: 640 us x 200 > 80 ms — the analysis runs (and finds nothing)", (2449029, 123718280, 128, 0.0004, 0),
+     dict(analyse=1, cost_skipped=0)),
+    ("geometric N=128", (600000, 7175884, 128, 0.583, 0), dict(analyse=1, cost_skipped=0)),
+    ("LFR mu=0.3 N=128", (300000, 4759166, 128, 0.0615, 0), dict(analyse=1, cost_skipped=0)),
+    ("Barabasi-Albert N=128, 200 launches: 30 us x 200 < 10 ms (measured gain of its plan: 16 us)", (500000, 5999928, 128, 0.0004, 0),
+     dict(analyse=0, cost_skipped=1)),
+    ("unknown probe (rectangular), com-Amazon-sized, N=128: the benefit of the doubt", (334863, 1851744, 128, -1.0, 0), dict(analyse=1, cost_skipped=0)),
+]
+
+
+@pytest.mark.parametrize("name,shape,expect", COST_TABLE, ids=[t[0] for t in COST_TABLE])
+def test_cost_rule(name, shape, expect):
+    M, nnz, N, probe, launches = shape
+    got = _lib.plan_policy(M, M, nnz, N, 100, wedge_probe=probe, expected_launches=launches)
+    for k, v in expect.items():
+        assert got[k] == v, (name, k, got)
+    assert got["est_cost_us"] > 3000 and got["est_gain_us"] > 0
+    # an explicit order is never second-guessed, and the 0.2 entry point (no probe, default launches) still answers
+    assert _lib.plan_policy(M, M, nnz, N, 100, wedge_probe=probe, expected_launches=launches, reorder=_lib.PLAN_REORDER)["analyse"] == 1
+    import ctypes
+
+    q = _lib.PlanPolicyQuery(M, M, nnz, N, 0, -1, 100, 0, 0, 0, 0, 0, 0, 0.0, 0.5, 0.0, 12345, 0, 0.9)  # (the 0.2 symbol must not read the tail)
+    a = _lib.PlanPolicyAnswer()
+    a.cost_skipped = 77
+    assert _lib.lib.gespmm_plan_policy(ctypes.byref(q), ctypes.byref(a)) == 0
+    assert a.cost_skipped == 77, "the 0.2 symbol writes the 0.2 answer only"
 
 
 def test_policy_respects_the_callers_choices():
