@@ -48,8 +48,9 @@ __global__ __launch_bounds__(kThreads) void atomic_scatter_kernel(const int32_t*
     }
 }
 
-// Yardstick, not a product path: a plain streaming copy (one dwordx4 load + one dwordx4 store per lane and step, grid-stride,
-// 16 workgroups per CU). bench.py times it in the same process as the product to price `roofline.ceiling_frac` with the rate
+// Yardstick, not a product path: a plain streaming copy — one non-temporal dwordx4 load + store per lane, one workgroup per 4 KB
+// (6.5 TB/s read + write on the MI355X; the grid-stride form of the same copy and torch's own copy_ reach 5.3, four loads in flight
+// per lane 5.5-6.2: profiles/r05/copy_yardstick.log — the yardstick is the fastest copy we can write, not a convenient one). bench.py times it in the same process as the product to price `roofline.ceiling_frac` with the rate
 // THIS box reaches for read + write traffic (MI355X_MICROARCH.md quotes 6.29 TB/s for a copy; boxes differ by a few percent).
 using cf4 = float __attribute__((ext_vector_type(4)));
 // (shapes measured on the MI355X, profiles/r05/copy_yardstick.log; GESPMM_COPY_MODE picks one for that experiment)
@@ -90,7 +91,7 @@ hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st) 
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const int64_t n4 = vec ? n / 4 : 0;
     if (n4 > 0) {
-        static const int mode = getenv("GESPMM_COPY_MODE") ? atoi(getenv("GESPMM_COPY_MODE")) : 0;
+        static const int mode = getenv("GESPMM_COPY_MODE") ? atoi(getenv("GESPMM_COPY_MODE")) : 5;  // 5: the fastest shape measured
         const cf4* s4 = reinterpret_cast<const cf4*>(src);
         cf4* d4 = reinterpret_cast<cf4*>(dst);
         auto grid_u = [&](int U) { return dim3((unsigned)((n4 + (int64_t)kThreads * U - 1) / ((int64_t)kThreads * U))); };

@@ -106,6 +106,13 @@ AnalysisDecision decide_analysis(const PlanFacts& f) {
     return a;
 }
 
+int cluster_levels_for(const PlanFacts& f) {
+    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+    // 2 ms buy 4.5 % of ~140 us = 6 us per launch on the one graph family they help: ~330 launches to break even there, nothing
+    // to gain elsewhere; with a margin for graphs between the two families
+    return launches < 2000 ? 3 : 0;
+}
+
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after) {
     if (f.reorder_mode != GESPMM_PLAN_REORDER_AUTO) return true;
     // the storage order is as good (already local, or nothing to find): keep it and pay nothing per launch. (0.05 until round 4: a

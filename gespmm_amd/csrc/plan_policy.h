@@ -59,6 +59,11 @@ struct AnalysisDecision {
 };
 AnalysisDecision decide_analysis(const PlanFacts& f);
 
+// Clustering depth (0 = the library's default of 6 levels). Levels 4-6 merge little and cost ~2 ms of launch latency on a
+// com-Amazon-sized graph; they are worth 4.5 % per launch on the structureless stand-in and nothing on graphs with communities
+// (profiles/r04/like_regression.log, cluster_levels.log) — a plan that expects fewer than 2000 launches stops at three.
+int cluster_levels_for(const PlanFacts& f);
+
 // ---- after the model: is the clustered order worth its per-launch indirection?
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after);
 

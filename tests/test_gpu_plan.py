@@ -318,7 +318,8 @@ def test_plan_options_by_size(pkg, bundled):
     M, K, nnz = g["M"], g["K"], g["nnz"]
 
     class Big(ctypes.Structure):  # a FUTURE header: the known fields + two more
-        _fields_ = [(n, ctypes.c_int32) for n in ("reorder", "task_entries", "row_floor", "threads", "flags", "kernel", "analysis", "x1", "x2")]
+        _fields_ = [(n, ctypes.c_int32) for n in ("reorder", "task_entries", "row_floor", "threads", "flags", "kernel", "analysis",
+                                                  "expected_launches", "x1", "x2")]
 
     def create(fn, opt, *size):
         h = ctypes.c_void_p()
@@ -331,21 +332,24 @@ def test_plan_options_by_size(pkg, bundled):
             return rc, buf.value.decode()
         return rc, ""
 
-    garbage = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, 12345, -7, 99)
+    garbage = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, 12345, 0, -7, 99)
     rc, d = create(lib.gespmm_plan_create, garbage)  # un-versioned symbol: `analysis` = 12345 IS read (seven fields) -> invalid; x1 / x2 are not
     assert rc == -1, (rc, d)
-    host7 = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, -7, 99)
+    host7 = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, -5, -7, 99)  # (-5: beyond what this symbol reads)
     rc, d = create(lib.gespmm_plan_create, host7)  # a round-3 caller asking for the host analysis gets it
     assert rc == 0 and "order=clustered" in d and "on the host" in d, (rc, d)
     rc, _ = create(lib.gespmm_plan_create_v2, garbage, ctypes.sizeof(_lib.PlanOptions))  # 28 bytes: `analysis` IS read -> invalid
     assert rc == -1, rc  # GESPMM_EINVAL
-    ok = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, -7, 99)
+    ok = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, _lib.PLAN_KERNEL_STREAM, _lib.PLAN_ANALYSIS_HOST, 300, -7, 99)
     rc, d = create(lib.gespmm_plan_create_v2, ok, ctypes.sizeof(Big))  # a bigger struct than this library knows: the tail is ignored
     assert rc == 0 and "on the host" in d, (rc, d)
     rc, d = create(lib.gespmm_plan_create_v2, ok, 24)  # an old caller through the new symbol: analysis takes its default
     assert rc == 0 and "on the device" in d, (rc, d)
     rc, _ = create(lib.gespmm_plan_create_v2, ok, 26)
     assert rc != 0
-    removed = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, 2, 0, 0, 0)  # GESPMM_PLAN_KERNEL_LDS_ROWS of rounds 2-3: gone
+    neg = Big(_lib.PLAN_REORDER_AUTO, 0, 0, 0, 0, 0, 0, -3, 0, 0)  # expected_launches < 0 through the symbol that reads it: invalid
+    rc, _ = create(lib.gespmm_plan_create_v2, neg, ctypes.sizeof(_lib.PlanOptions))
+    assert rc == -1, rc
+    removed = Big(_lib.PLAN_REORDER, 0, 0, 0, 0, 2, 0, 0, 0, 0)  # GESPMM_PLAN_KERNEL_LDS_ROWS of rounds 2-3: gone
     rc, _ = create(lib.gespmm_plan_create, removed)
     assert rc != 0
