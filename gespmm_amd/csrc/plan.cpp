@@ -45,6 +45,8 @@ struct gespmm_plan {
     bool valued = false;
     int32_t max_degree = 0;
     bool reordered = false;
+    void* d_block = nullptr;  // device analysis: perm / rowptr / colind / src_begin (/ val) are parts of this ONE allocation
+    bool val_in_block = false;
     int32_t* d_rowptr = nullptr;
     int32_t* d_colind = nullptr;
     float* d_val = nullptr;
@@ -140,6 +142,13 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 void free_device(gespmm_plan* p) {
     gespmm::free_staging(&p->stg);
     if (p->gtasks_shared) p->d_gtasks = nullptr;
+    if (p->d_block) {  // the permuted copy is one block
+        (void)hipFree(p->d_block);
+        p->d_block = nullptr;
+        p->d_rowptr = p->d_colind = p->d_perm = p->d_src_begin = nullptr;
+        if (p->val_in_block) p->d_val = nullptr;
+        p->val_in_block = false;
+    }
     void* ptrs[] = {p->d_rowptr, p->d_colind, p->d_val, p->d_perm, p->d_src_begin, p->d_tasks, p->ws, p->d_gtasks, p->d_coo_row, p->d_edge_dst, p->d_sddmm_tmp, p->d_coo_row_storage};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -423,21 +432,39 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
             // ==================================================================== analysis on the device
             lap(nullptr);
             const auto tc = std::chrono::steady_clock::now();
-            e = hipMalloc(reinterpret_cast<void**>(&p->d_perm), (size_t)M * 4);
+            {   // one allocation for the plan's permuted copy of the matrix (a hipMalloc costs ~0.1 ms: five of them were 7 % of the analysis)
+                auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+                const size_t b_perm = up((size_t)M * 4), b_rp = up(((size_t)M + 1) * 4), b_ci = up((size_t)(nnz > 0 ? nnz : 1) * 4),
+                             b_src = up((size_t)M * 4), b_val = p->valued ? up((size_t)(nnz > 0 ? nnz : 1) * 4) : 0;
+                e = hipMalloc(&p->d_block, b_perm + b_rp + b_ci + b_src + b_val);
+                if (e == hipSuccess) {
+                    char* base = reinterpret_cast<char*>(p->d_block);
+                    p->d_perm = reinterpret_cast<int32_t*>(base);
+                    p->d_rowptr = reinterpret_cast<int32_t*>(base + b_perm);
+                    p->d_colind = reinterpret_cast<int32_t*>(base + b_perm + b_rp);
+                    p->d_src_begin = reinterpret_cast<int32_t*>(base + b_perm + b_rp + b_ci);
+                    if (p->valued) {
+                        p->d_val = reinterpret_cast<float*>(base + b_perm + b_rp + b_ci + b_src);
+                        p->val_in_block = true;
+                    }
+                }
+            }
             gespmm::ClusterOptions copt = cluster_options_from_env();
             if (copt.max_levels <= 0) copt.max_levels = gespmm::cluster_levels_for(f);
             if (e == hipSuccess) e = gespmm::device_cluster_rows(M, K, nnz, rowptr, colind, copt, p->d_perm, &p->stats, st);
             p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
             lap("cluster");
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_rowptr), ((size_t)M + 1) * 4);
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_colind), (size_t)(nnz > 0 ? nnz : 1) * 4);
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_src_begin), (size_t)M * 4);
             if (e == hipSuccess)
                 e = gespmm::device_permute_csr(M, nnz, rowptr, colind, p->d_perm, p->d_rowptr, p->d_colind, p->d_src_begin, st);
             lap("permute");
             const auto tm = std::chrono::steady_clock::now();
+            // (the storage order is only judged against the clustered one — "already local, or hit by hubs: keep it" shows anywhere in a
+            //  slice — so on matrices of >= 2^20 entries the first QUARTER of every slice is modelled: a quarter of the sort)
+            const int64_t before_sample = nnz >= (1 << 20) ? std::max<int64_t>(nnz / 32, 1 << 15) : model_sample;
             if (e == hipSuccess)
-                e = gespmm::device_l2_model(M, K, nnz, rowptr, colind, 8, model_window, model_sample, 4096, &p->hits_before, st);
+                e = gespmm::device_l2_model(M, K, nnz, rowptr, colind, 8, model_window,
+                                            model_sample > 0 ? std::min<int64_t>(model_sample, before_sample) : before_sample, 4096,
+                                            &p->hits_before, st);
             if (e == hipSuccess)
                 e = gespmm::device_l2_model(M, K, nnz, p->d_rowptr, p->d_colind, 8, model_window, model_sample, 4096,
                                             &p->hits_after, st);
@@ -450,11 +477,11 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
             }
             if (!gespmm::keep_clustered_order(f, ad, p->hits_before, p->hits_after)) {
                 reorder = false;  // the storage order (or the cache-blocked path) is as good: keep it and pay nothing per launch
-                (void)hipFree(p->d_perm);
-                (void)hipFree(p->d_rowptr);
-                (void)hipFree(p->d_colind);
-                (void)hipFree(p->d_src_begin);
+                (void)hipFree(p->d_block);
+                p->d_block = nullptr;
                 p->d_perm = p->d_rowptr = p->d_colind = p->d_src_begin = nullptr;
+                p->d_val = nullptr;
+                p->val_in_block = false;
             }
         }
         if (reorder && !on_host) {
@@ -476,13 +503,12 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
                 p->gtasks_shared = true;  // one block holds both tables: free d_tasks only
             }
             lap("tasks x2");
-            if (e == hipSuccess && p->valued) e = hipMalloc(reinterpret_cast<void**>(&p->d_val), (size_t)(nnz > 0 ? nnz : 1) * 4);
-            if (e == hipSuccess && p->valued && nnz > 0) {
+            if (e == hipSuccess && p->valued && nnz > 0) {  // (d_val is part of the plan's block)
                 hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p->d_rowptr,
                                    p->d_src_begin, val, p->d_val, (int)M, (int)nnz);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the caller's `val` is not read after the call returns)
             lap("values");
             // ---- staged-rows kernel (choose_plan_kernel says when): the tables are built, and kept when enough entries find
             //      their B row staged
@@ -660,7 +686,7 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
-                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, 0, nullptr};
+                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, p->stg.slots, 0, nullptr};
         rc = (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0 && p->stg.nlong > 0) {
             // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits

@@ -46,12 +46,14 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
 // (>= 2 uses), `waves` tasks, and the interleaved {code, value} stream. staged_fraction = share of the entries whose B row
 // comes from LDS. Deterministic (ties in column order). The four arrays are hipMalloc blocks owned by the caller (free_staging).
 struct StagingTables {
+    void* block = nullptr;        // the one allocation ev / tasks / hot_cols / nhot are parts of
     int32_t* ev = nullptr;        // 2 * (nnz_s + M + kStagedPad) words: entries + one row-end record per row (spmm_kernels.h)
     int32_t* hot_cols = nullptr;  // nblocks * H
     int32_t* nhot = nullptr;      // nblocks
     int32_t* tasks = nullptr;     // nblocks * waves int4
     int32_t nblocks = 0;
     int32_t waves = 0;            // wavefronts (tasks) per block
+    int32_t slots = 0;            // staged rows per block (H)
     double staged_fraction = 0.0;
     // hub rows (device_split_long_rows): the staged kernel walks a copy of the row pointers in which they are EMPTY, and they
     // are handed to the streaming kernel's long-row pass as one-row tasks. NULL / 0: no such rows, the plan's own row pointers.

@@ -1830,7 +1830,9 @@ hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_
 
 void free_staging(StagingTables* t) {
     if (!t) return;
-    void* ptrs[] = {t->ev, t->hot_cols, t->nhot, t->tasks, t->rowptr_s, t->ltasks};
+    // (ev / hot_cols / nhot / tasks are parts of ONE block since round 5: a hipMalloc costs the analysis ~0.1 ms)
+    void* ptrs[] = {t->block ? t->block : (void*)t->ev, t->block ? nullptr : (void*)t->hot_cols, t->block ? nullptr : (void*)t->nhot,
+                    t->block ? nullptr : (void*)t->tasks, t->rowptr_s, t->ltasks};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     *t = StagingTables();
@@ -1876,10 +1878,17 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
                                                        (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
                                                        (unsigned)bits, st));
         // the tables themselves belong to the plan: blocks of their own
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.hot_cols), (size_t)nblk * H * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.nhot), (size_t)nblk * 4));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.tasks), (size_t)nblk * kStagedWaves * 16));
-        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&t.ev), (size_t)(nnz + M + kStagedPad) * 8));
+        {
+            auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t b_hot = up((size_t)nblk * H * 4), b_nhot = up((size_t)nblk * 4), b_tasks = up((size_t)nblk * kStagedWaves * 16),
+                         b_ev = up((size_t)(nnz + M + kStagedPad) * 8);
+            GESPMM_TRY(hipMalloc(&t.block, b_ev + b_tasks + b_hot + b_nhot));
+            char* base = reinterpret_cast<char*>(t.block);
+            t.ev = reinterpret_cast<int32_t*>(base);
+            t.tasks = reinterpret_cast<int32_t*>(base + b_ev);
+            t.hot_cols = reinterpret_cast<int32_t*>(base + b_ev + b_tasks);
+            t.nhot = reinterpret_cast<int32_t*>(base + b_ev + b_tasks + b_hot);
+        }
         GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0xFF, (size_t)nblk * H * 4, st));  // unused slots: -1 (the kernel copies nothing for them)
         hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
                            (const int32_t*)idx_out, H, code, t.hot_cols, t.nhot, staged);
@@ -1900,12 +1909,14 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         free_staging(&t);
         return e;
     }
+    out->block = t.block;
     out->ev = t.ev;
     out->hot_cols = t.hot_cols;
     out->nhot = t.nhot;
     out->tasks = t.tasks;
     out->nblocks = t.nblocks;
     out->waves = waves;
+    out->slots = H;
     out->staged_fraction = t.staged_fraction;
     if (!out->rowptr_s) out->nnz_s = nnz;
     return hipSuccess;

@@ -110,7 +110,7 @@ hipError_t launch_spmm_parreduce(const SpmmArgs& a, const Geometry& geo, hipStre
 // range: no row pointers, no row ids, no position compares on the walk (round 5). Record position of entry p of row r: p + r; the
 // stream is padded by kStagedPad records.
 constexpr int kStagedMaxWaves = 16;      // wavefronts per block: 4, 8 or 16 (StagedShape)
-constexpr int kStagedLdsPerWave = 4096;  // bytes of staged B rows per wavefront of the block (16 wavefronts: 64 KB)
+constexpr int kStagedLdsPerWave = 4096;  // bytes of staged B rows per wavefront of the block (16 wavefronts: 64 KB); GESPMM_STAGED_LDS_KB=8: 8192
 constexpr int kStagedPad = 64;
 constexpr int kStagedRowEnd = 0x40000000;  // code of a row-end record (both address shifts of the kernel drop the bit: slot 0 / column 0)
 constexpr int kStagedMaxRow = 2048;  // longer rows are walked by the streaming kernel's long-row pass, not by one wavefront
@@ -126,6 +126,7 @@ struct StagedArgs {
     float* C;
     int32_t nblocks;
     int32_t waves;            // wavefronts (= tasks) per block the tables were built for
+    int32_t slots;            // staged rows per block the tables were built for (H: decides the LDS per wavefront, 4 or 8 KB)
     int32_t debug;            // experiments only (GESPMM_STAGED_DEBUG): 1 = skip the staging copy, 2 = every gather from LDS — WRONG results;
                               // 4 = phase clocks summed into dbg_clk
     unsigned long long* dbg_clk;

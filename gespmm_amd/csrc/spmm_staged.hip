@@ -89,10 +89,11 @@ template <> struct LaneVec<4> { using type = float __attribute__((ext_vector_typ
 // PAGE2: B between 4 and 8 GB (products-shaped x 512 columns: 5.0 GB). The lane's 32-bit offset wraps modulo 4 GB by itself —
 // `code << log2(row bytes)` drops the bit that says which half — and the base pointer is chosen between B and B + 4 GB by
 // that bit of the (scalar) code: two scalar instructions on the memory path, none on the LDS path.
-template <int VEC, int U, int TSHIFT, bool PAGE2, int WAVES>
+template <int VEC, int U, int TSHIFT, bool PAGE2, int WAVES, int LK>
 __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     constexpr int kStagedWaves = WAVES;
-    constexpr int kStagedLdsBytes = WAVES * kStagedLdsPerWave;
+    constexpr int kStagedLdsBytes = WAVES * LK * 1024;  // LK KB of staged B rows per wavefront of the block (4: two blocks per CU; 8: one)
+    constexpr int P = LK;                                // 16-byte pieces of the staging copy per thread
     using vec_t = typename LaneVec<VEC>::type;
     constexpr int kRowBytes = 256 * VEC;          // bytes of a row inside one tile
     constexpr int kRowShift = (VEC == 2) ? 9 : 10;
@@ -122,13 +123,13 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     const uint64_t t_start = (dbg & 4) ? __builtin_readcyclecounter() : 0;
     const int task = blk * kStagedWaves + wave;
     // Round trip 1 — everything whose address follows from the block id alone: the wavefront's task (scalar) and the block's staged
-    // columns (vector; thread t copies the 16-byte pieces t, t + T, t + 2T, t + 3T of the H x row-bytes array, T = threads per block).
+    // columns (vector; thread t copies the 16-byte pieces t, t + T, ... (P of them) of the H x row-bytes array, T = threads per block).
     cint_ptr tk = (cint_ptr)(uintptr_t)a.tasks + (size_t)task * 4;
     const int32_t* hc = a.hot_cols + (size_t)blk * H;
-    static_assert(H * kRowF4 == 4 * kStagedWaves * 64, "four pieces per thread");
-    int hcol[4];
+    static_assert(H * kRowF4 == P * kStagedWaves * 64, "P pieces per thread");
+    int hcol[P];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) hcol[u] = (dbg & 1) ? -1 : hc[(u * kStagedWaves * 64 + tid) / kRowF4];
+    for (int u = 0; u < P; ++u) hcol[u] = (dbg & 1) ? -1 : hc[(u * kStagedWaves * 64 + tid) / kRowF4];
     const int wb = tk[2], we = tk[3];  // the wavefront's range of the record stream (entries + one row-end record per row)
     const float* Bp = a.B + (size_t)tile * (64 * VEC);
     const float* BpHi = Bp + (1ull << 30);  // + 4 GB (PAGE2)
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     // stream, through the VECTOR path. Nothing on the walk below is a scalar MEMORY load — see the header: a scalar load shares its
     // counter with the LDS reads and is waited for with every chunk. Row ends and C rows arrive WITH the stream (row-end records).
     const f4v* B4 = reinterpret_cast<const f4v*>(a.B);
-    f4v stage[4];
+    f4v stage[P];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < P; ++u) {
         const int i = u * kStagedWaves * 64 + tid;
         stage[u] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
         if (hcol[u] >= 0) stage[u] = B4[(((size_t)hcol[u] << TSHIFT) + (size_t)tile) * kRowF4 + (i % kRowF4)];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     i2v win = {0, 0};
     if (we > wb) win = __builtin_nontemporal_load(evv + lane);  // (the stream is padded: a whole window is always readable)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < P; ++u)
         if (hcol[u] >= 0) s_hot[u * kStagedWaves * 64 + tid] = stage[u];
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0);  // the compiler's scoreboard is clean when the assembly gathers start
@@ -407,9 +408,10 @@ StagedShape staged_shape(int64_t N) {
     StagedShape sh = {0, 0, 0};
     if (!tc) return sh;
     sh.waves = (waves_env == 4 || waves_env == 8 || waves_env == 16) ? waves_env : kStagedMaxWaves;
+    constexpr int lds_kb = 4;  // per wavefront
     sh.rows = (tc == 128 ? 6 : 4) * sh.waves;
     if (rows_env > 0) sh.rows = rows_env;
-    sh.slots = sh.waves * kStagedLdsPerWave / (tc * 4);
+    sh.slots = sh.waves * lds_kb * 1024 / (tc * 4);
     return sh;
 }
 
@@ -443,11 +445,16 @@ hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t M, int64_t K, int6
     const bool paged = (uint64_t)(M > K ? M : K) * (uint64_t)N * 4ull >= 0xFFFF0000ull;
     const dim3 grid((unsigned)a.nblocks << (t > 0 ? t : 0)), block((unsigned)a.waves * 64);
     static const int u_env = getenv("GESPMM_STAGED_U") ? atoi(getenv("GESPMM_STAGED_U")) : 0;  // experiment knob: entries in flight per wavefront
+    const int lds_kb = a.slots > 0 ? (int)((int64_t)a.slots * tc * 4 / ((int64_t)a.waves * 1024)) : 4;  // what the tables were built for
+    // (8 KB per wavefront — one 16-wavefront block per CU with twice the staged rows — was built and measured: 20-40 % slower on every
+    //  graph, products-shaped 3.92 vs 2.79 ms, geometric 240 vs 193 us: two blocks per CU hide each other's staging round trips, one does
+    //  not. profiles/r05/staged_lds_per_wave.log; the kernel stays generic in LK, only 4 is instantiated)
+    if (lds_kb != 4) return hipErrorInvalidValue;
 #define GESPMM_STAGED_LAUNCH(VEC, U, TS, PG)                                                                                   \
     do {                                                                                                                       \
-        if (a.waves == 16) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 16>), grid, block, 0, st, a);                \
-        else if (a.waves == 8) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 8>), grid, block, 0, st, a);             \
-        else if (a.waves == 4) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 4>), grid, block, 0, st, a);             \
+        if (a.waves == 16) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 16, 4>), grid, block, 0, st, a);        \
+        else if (a.waves == 8) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 8, 4>), grid, block, 0, st, a);          \
+        else if (a.waves == 4) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 4, 4>), grid, block, 0, st, a);          \
         else return hipErrorInvalidValue;                                                                                      \
     } while (0)
     if (tc == 128 && u_env == 16) GESPMM_STAGED_LAUNCH(2, 16, 0, false);
