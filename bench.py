@@ -291,6 +291,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--panel-cols", type=int, default=128, help="column panel of the exchange/compute pipeline")
+    ap.add_argument("--expected-launches", type=int, default=0,
+                    help="expected_launches of the headline plan (0 = the library's default, 200 = the reference's protocol)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the several-GPU run (nccl = RCCL on ROCm)")
     args = ap.parse_args()
 
@@ -469,7 +471,7 @@ def main():
     gen.manual_seed(7 + rank)
     val = torch.rand(nnz, generator=gen, device=dev) - 0.5
 
-    head, step, B, C, plan = measure_graph(g, val, N, True, use_plan=not args.no_plan, keep=True)
+    head, step, B, C, plan = measure_graph(g, val, N, True, use_plan=not args.no_plan, keep=True, expected_launches=args.expected_launches)
     wall = timed_region(step, args.steps, args.warmup)
     flop_per_step = 2.0 * nnz * N * world  # weak scaling: every rank owns one graph of this size
     value = flop_per_step * args.steps / wall / 1e9
