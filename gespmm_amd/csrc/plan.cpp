@@ -281,7 +281,7 @@ int gespmm_plan_debug_tasks(const gespmm_plan* p, int32_t which, int32_t* out_ho
 static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
     const auto ts = std::chrono::steady_clock::now();
     const int64_t M = p->M, K = p->K, nnz = p->nnz, N = p->N;
-    const gespmm::StagedShape shape = gespmm::staged_shape(N);
+    const gespmm::StagedShape shape = gespmm::staged_shape_any(N);  // (the wide kernel's block shape, or the narrow kernel's at N <= 64)
     hipError_t e = hipSuccess;
     const int32_t* rp_s = p->d_rowptr;
     const int32_t* ci_s = p->d_colind;
@@ -297,7 +297,8 @@ static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
         nnz_s = p->stg.nnz_s;
     }
     if (e == hipSuccess && nnz_s > 0)
-        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, shape.rows, shape.slots, shape.waves, &p->stg, st);
+        e = gespmm::device_build_staging(M, K, nnz_s, rp_s, ci_s, val_s, p->d_perm, shape.rows, shape.slots, shape.waves,
+                                         gespmm::staged_tasks_per_block(N), &p->stg, st);
     if (ci_tmp) (void)hipFree(ci_tmp);
     if (val_tmp) (void)hipFree(val_tmp);
     if (e == hipSuccess && !p->stg.ev) gespmm::free_staging(&p->stg);  // (nothing but hub rows)
@@ -687,7 +688,8 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
                                  p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, p->stg.slots, 0, nullptr};
-        rc = (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream));
+        rc = gespmm::staged_shape(N).waves ? (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream))
+                                           : (int)gespmm::launch_spmm_staged_narrow(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream));
         if (rc == 0 && p->stg.nlong > 0) {
             // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits
             // them — under GESPMM_FLAG_STRICT_ORDER each is one lane group's chain instead, as everywhere else
@@ -745,7 +747,7 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     if (reps > 50) reps = 50;
     hipError_t e = hipSuccess;
     const bool v4 = p->variant == GESPMM_VARIANT_AUTO || p->variant == GESPMM_VARIANT_CRC_CWM4 || p->variant == GESPMM_VARIANT_CRC_CWM8;
-    if (!p->stg.ev && p->analysis == GESPMM_PLAN_ANALYSIS_DEVICE && v4 && p->nnz > 0 && gespmm::staged_serves(p->M, p->K, p->N) && gespmm::staged_stream_fits(p->M, p->nnz)) {
+    if (!p->stg.ev && p->analysis == GESPMM_PLAN_ANALYSIS_DEVICE && v4 && p->nnz > 0 && gespmm::staged_serves_any(p->M, p->K, p->N) && gespmm::staged_stream_fits(p->M, p->nnz)) {
         e = build_staging_tables(p, st);  // (built for the occasion: kept only if the staged-rows kernel wins)
         if (e != hipSuccess) {
             gespmm::free_staging(&p->stg);
@@ -922,7 +924,7 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         char kern[420];
         if (staged_d && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
             snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
-                     p->stg.nblocks, gespmm::staged_rows_per_block_lds(p->N), p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
+                     p->stg.nblocks, gespmm::staged_shape_any(p->N).slots, p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
         char tuned[200] = "";
         if (p->tuned)

@@ -69,8 +69,10 @@ struct StagingTables {
 hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
                                   int limit, StagingTables* t, int32_t** colind_s, float** val_s, hipStream_t st);
 // perm (clustered position -> C row; NULL = identity) goes into the row-end records of the stream.
+// `parts`: tasks per block (the wide kernel: one per wavefront = waves; the narrow kernel: one per lane group = waves x G)
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, const int32_t* perm, int R, int H, int waves, StagingTables* out, hipStream_t st);
+                                const float* val_p, const int32_t* perm, int R, int H, int waves, int parts, StagingTables* out,
+                                hipStream_t st);
 // val_p: values in the clustered matrix's entry order (NULL: 1.0f); rowptr_p: its row pointers (used when hub rows were split off)
 hipError_t device_staging_set_values(const StagingTables& t, const float* val_p, const int32_t* rowptr_p, int64_t M, int64_t nnz,
                                      hipStream_t st);

@@ -1839,11 +1839,13 @@ void free_staging(StagingTables* t) {
 }
 
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
-                                const float* val_p, const int32_t* perm, int R, int H, int waves, StagingTables* out, hipStream_t st) {
+                                const float* val_p, const int32_t* perm, int R, int H, int waves, int parts, StagingTables* out,
+                                hipStream_t st) {
     // (rowptr_p / colind_p / val_p / nnz describe what the staged kernel walks: the clustered matrix, or its copy without hub rows —
     // `out` then already carries rowptr_s / ltasks / nlong / nnz_s from device_split_long_rows, which stay)
-    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0 || waves <= 0 || waves > kStagedMaxWaves) return hipErrorInvalidValue;
-    const int kStagedWaves = waves;
+    if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0 || waves <= 0 || waves > kStagedMaxWaves || parts < waves || parts > 64 * waves)
+        return hipErrorInvalidValue;
+    const int kStagedWaves = parts;  // tasks per block
     const int64_t nblk = (M + R - 1) / R;
     // (Round 3 marked columns whose own row sits far away in the clustered order and gathered them `nt`; level or harmful once the block
     // heights and the clustering depth had settled — profiles/r04/far_marks_by_graph.log — and removed in round 5.)

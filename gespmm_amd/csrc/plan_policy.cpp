@@ -163,10 +163,11 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
     // multiply-adds) they win at both widths: com-Amazon-shaped 92.7 vs 107 us (N = 128), 175 vs 216 us (N = 256); mean degree 6 / 8:
     // x1.06 / x1.14 at N = 128 (profiles/r05/staged_degree_sweep.log, kernel_ab_record_stream.log). Device analysis only.
     const bool v4 = f.variant == GESPMM_VARIANT_AUTO || f.variant == GESPMM_VARIANT_CRC_CWM4 || f.variant == GESPMM_VARIANT_CRC_CWM8;
-    const bool fits = f.nnz > 0 && staged_serves(f.M, f.K, f.N) && staged_stream_fits(f.M, f.nnz);
+    const bool fits = f.nnz > 0 && staged_serves_any(f.M, f.K, f.N) && staged_stream_fits(f.M, f.nnz);
+    const bool narrow = !staged_serves(f.M, f.K, f.N);  // N = 16 / 32 / 64: the lane-group form of the kernel (spmm_staged_narrow.hip)
     const bool want = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
-                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
-                       f.nnz >= (1 << 20) && v4);
+                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && !narrow && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
+                       f.nnz >= (1 << 20) && v4);  // (narrow widths: opt-in until measured)
     d.build_staged = fits && want && !f.host_analysis;
     // Where the clustered order is modelled to hit L2 (>= 40 % of the gathers) four B rows in flight per lane group beat eight
     // at up to 128 columns (com-Amazon-shaped communities, N = 128: 105 vs 114 us, N = 64: 48 vs 60 us; at 256+ columns and on

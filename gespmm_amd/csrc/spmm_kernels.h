@@ -141,6 +141,23 @@ inline int staged_rows_per_block_lds(int64_t N) { return staged_shape(N).slots; 
 inline int staged_block_rows(int64_t N) { return staged_shape(N).rows; }
 bool staged_serves(int64_t M, int64_t K, int64_t N);  // width served, B and C addressable (32-bit offsets; two 4 GB halves for the tiled widths)
 hipError_t launch_spmm_staged(const StagedArgs& a, int64_t M, int64_t K, int64_t N, hipStream_t st);
+// spmm_staged_narrow.hip — the same tables at N = 16 / 32 / 64: a wavefront is G = 64 / (N / 4) lane groups, each walking its own range
+// of the record stream (`waves` x G tasks per block); staged rows from LDS and memory rows under complementary EXEC masks.
+StagedShape staged_narrow_shape(int64_t N);  // waves = 0: width not served
+int staged_narrow_groups(int64_t N);         // lane groups (tasks) per wavefront
+bool staged_narrow_serves(int64_t M, int64_t K, int64_t N);
+hipError_t launch_spmm_staged_narrow(const StagedArgs& a, int64_t M, int64_t K, int64_t N, hipStream_t st);
+// either kernel: the block shape of width N (waves = 0: neither serves it) and the tasks per block
+inline StagedShape staged_shape_any(int64_t N) {
+    const StagedShape w = staged_shape(N);
+    return w.waves ? w : staged_narrow_shape(N);
+}
+inline int staged_tasks_per_block(int64_t N) {
+    const StagedShape w = staged_shape(N);
+    if (w.waves) return w.waves;
+    return staged_narrow_shape(N).waves * staged_narrow_groups(N);
+}
+inline bool staged_serves_any(int64_t M, int64_t K, int64_t N) { return staged_serves(M, K, N) || staged_narrow_serves(M, K, N); }
 
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form

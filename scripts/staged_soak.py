@@ -34,7 +34,7 @@ def soak(first, count, verbose=True):
             continue
         rp, ci = torch.from_numpy(rowptr).cuda(), torch.from_numpy(colind).cuda()
         val = torch.from_numpy((rng.rand(colind.size).astype(np.float32) - 0.5)).cuda()
-        for N in (128, 256, 512) + ((1024,) if seed % 7 == 0 else ()):
+        for N in (128, 256, 512, 32) + ((1024, 16, 64) if seed % 7 == 0 else ()) + ((64,) if seed % 3 == 0 else ()):
             B = torch.from_numpy((rng.rand(K, N).astype(np.float32) - 0.5)).cuda()
             plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="staged", flags=0x100)
             staged += "kernel=staged-rows" in plan.describe()

@@ -15,7 +15,7 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("N", (128, 256, 512, 1024))
+@pytest.mark.parametrize("N", (16, 32, 64, 128, 256, 512, 1024))  # 16 / 32 / 64: the lane-group form (spmm_staged_narrow.hip)
 @pytest.mark.parametrize("graph", ("cora", "pubmed"))
 def test_bits_equal_oracle_valued_unweighted_and_new_values(pkg, oracle, bundled, graph, N):
     from gespmm_amd import spmm
