@@ -167,7 +167,11 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
     const bool narrow = !staged_serves(f.M, f.K, f.N);  // N = 16 / 32 / 64: the lane-group form of the kernel (spmm_staged_narrow.hip)
     const bool want = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
                       (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && !narrow && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
-                       f.nnz >= (1 << 20) && v4);  // (narrow widths: opt-in until measured)
+                       f.nnz >= (1 << 20) && v4) ||
+                      // the lane-group form at N = 32 / 64 (spmm_staged_narrow.hip): worth its tables where most of the entries will be
+                      // staged — rows of 10+ entries in an order modelled at >= 0.75 hits (keep_staged_tables decides on the share)
+                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && narrow && (f.N == 32 || f.N == 64) && mean >= 10 && hits_after >= 0.75 &&
+                       f.nnz >= (1 << 20) && f.variant == GESPMM_VARIANT_AUTO);
     d.build_staged = fits && want && !f.host_analysis;
     // Where the clustered order is modelled to hit L2 (>= 40 % of the gathers) four B rows in flight per lane group beat eight
     // at up to 128 columns (com-Amazon-shaped communities, N = 128: 105 vs 114 us, N = 64: 48 vs 60 us; at 256+ columns and on
@@ -188,6 +192,14 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     //                      (without the `nt` marks of round 3, which cost this tile width 4-9 %: holdout_audit.log after far_marks_by_graph.log)
     // (round 3 asked for 0.40 at both widths: fitted on the planted-community generator alone, 20-41 % behind on the LFR graphs)
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return true;
+    if (f.N <= 64) {
+        // Narrow widths (round 5, profiles/r05/kernel_ab_narrow.log; time of the best streaming kernel / lane-group staged kernel):
+        //   share 0.93-0.98 geometric x1.35 (N = 32) / x1.35 (64) · 0.85-0.90 small-world x1.23 / x1.45 · 0.65-0.75 products-shaped
+        //   communities (mean degree 50) x1.10 / x1.12 · 0.75-0.80 com-Amazon-shaped (mean degree 5.5) x0.91 / x0.84 ·
+        //   0.63-0.75 LFR mu = 0.1 (mean degree 16) x0.69 / x0.74 · 0.22 structureless x0.57
+        // — most entries staged, or long rows with two thirds staged
+        return staged_fraction >= 0.85 || (f.mean_ceil() >= 32 && staged_fraction >= 0.62);
+    }
     return staged_fraction >= (f.N == 128 ? 0.60 : 0.42);  // (128-column tiles : 256-column tiles)
 }
 

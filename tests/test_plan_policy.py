@@ -30,8 +30,13 @@ TABLE = [
      dict(analyse=1, dense_try=1, keep_clustered=1, segmented=1)),
     ("C3 products-sbm N=128", (2449029, 123718280, 128, 1446, 0.003, 0.840, 0.638),
      dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=255, build_staged=1, keep_staged=1, segmented=0, model_sample=1 << 22)),
-    ("C3 products-sbm N=32", (2449029, 123718280, 32, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=1)),
-    ("C3 products-sbm N=64", (2449029, 123718280, 64, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0, segmented=0)),
+    # round 5: the lane-group form of the staged kernel at N = 32 / 64 (1185 vs 1302 us, 1865 vs 2089 us)
+    ("C3 products-sbm N=32", (2449029, 123718280, 32, 1446, 0.01, 0.85, 0.707), dict(keep_clustered=1, build_staged=1, keep_staged=1, segmented=0)),
+    ("C3 products-sbm N=64", (2449029, 123718280, 64, 1446, 0.01, 0.85, 0.651), dict(keep_clustered=1, build_staged=1, keep_staged=1, segmented=0)),
+    ("C3 products-sbm N=16: streaming kernels", (2449029, 123718280, 16, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0)),
+    ("geometric N=32: share 0.93", (600000, 7175884, 32, 30, 0.02, 0.93, 0.931), dict(build_staged=1, keep_staged=1)),
+    ("LFR mu=0.1 N=32: share 0.71 on rows of 16 loses (105 vs 69 us)", (300000, 4717400, 32, 306, 0.144, 0.786, 0.709), dict(build_staged=1, keep_staged=0)),
+    ("com-amazon-sbm N=64: short rows stay with the streaming kernels", (334863, 1851744, 64, 120, 0.05, 0.68, 0.0), dict(build_staged=0)),
     ("C3 products-sbm N=512", (2449029, 123718280, 512, 1446, 0.001, 0.833, 0.503), dict(keep_clustered=1, build_staged=1, keep_staged=1, task_entries=102)),
     # ---- hold-out graphs (profiles/r04/holdout_audit.log): the rows that moved thresholds in round 4
     ("LFR mu=0.1 N=128: share 0.565 loses 21 % staged", (300000, 4717400, 128, 306, 0.041, 0.768, 0.565),
