@@ -588,9 +588,10 @@ def main():
                 plan3 = spmm.SpmmPlan(g3["rowptr"], g3["colind"], g3["K"], 128, values=val3)
                 torch.cuda.synchronize()
                 sweep = {"plan_ms": (time.perf_counter() - t0) * 1e3, "plan": plan3.describe()}
-                # (the staged-rows kernel's tables are made for ONE width: N = 256 and N = 512 get plans of their own)
+                # (the staged-rows kernel's tables are made for ONE width: N = 32 / 64 — the lane-group form — and N = 256 / 512 get
+                #  plans of their own)
                 wide = {}
-                for nw in (256, 512):
+                for nw in (32, 64, 256, 512):
                     tw = []
                     for _ in range(2):
                         wide[nw] = None
