@@ -51,6 +51,8 @@ def load(name, scale):
     p = os.path.join(HOLD, name + ".npz")
     if os.path.exists(p):
         return from_npz(p)
+    if name.startswith("rmat-"):  # rmat-<scale>: the Graph500 generator of config 5, one shard = the whole graph
+        return graphs.rmat_shard(int(name.split("-")[1]), device=dev)
     kw = {"scale": scale} if scale != 1.0 else {}
     return graphs.synthetic_graph(name, seed=42, device=dev, **kw)
 
