@@ -113,9 +113,10 @@ class PlanPolicyAnswer(Structure):
     _fields_ = [(n, c_int32) for n in ("launch_flags", "analyse", "dense_try", "keep_clustered", "task_entries",
                                        "group_task_entries", "row_floor", "build_staged", "keep_staged", "shallow_unroll",
                                        "segmented", "sddmm_route", "narrow_vec4")] + [("model_window", c_int64), ("model_sample", c_int64),
-                                                                                       ("cost_skipped", c_int32), ("reserved1", c_int32),
+                                                                                       ("cost_skipped", c_int32), ("cluster_levels", c_int32),
                                                                                        ("est_gain_us", ctypes.c_double),
-                                                                                       ("est_cost_us", ctypes.c_double)]
+                                                                                       ("est_cost_us", ctypes.c_double), ("cluster_sweeps", c_int32),
+                                                                                       ("reserved1", c_int32)]
 
 
 class Coo(Structure):

@@ -452,6 +452,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
             }
             gespmm::ClusterOptions copt = cluster_options_from_env();
             if (copt.max_levels <= 0) copt.max_levels = gespmm::cluster_levels_for(f);
+            if (copt.sweeps <= 0) copt.sweeps = gespmm::cluster_sweeps_for(f);
             if (e == hipSuccess) e = gespmm::device_cluster_rows(M, K, nnz, rowptr, colind, copt, p->d_perm, &p->stats, st);
             p->cluster_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
             lap("cluster");
@@ -535,6 +536,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
             p->perm_host.resize((size_t)M);
             gespmm::ClusterOptions copt = cluster_options_from_env();
             if (copt.max_levels <= 0) copt.max_levels = gespmm::cluster_levels_for(f);
+            if (copt.sweeps <= 0) copt.sweeps = gespmm::cluster_sweeps_for(f);
             copt.threads = opt ? opt->threads : 0;
             if (gespmm::cluster_rows(M, K, h_rowptr.data(), h_colind.data(), copt, p->perm_host.data(), &p->stats) != 0) {
                 delete p;

@@ -113,6 +113,15 @@ int cluster_levels_for(const PlanFacts& f) {
     return launches < 2000 ? 3 : 0;
 }
 
+int cluster_sweeps_for(const PlanFacts& f) {
+    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+    // label-propagation sweeps per level. Five (the default of cluster_rows) against three, profiles/r05/cluster_sweeps.log: the analysis
+    // of the com-Amazon-shaped graph 5.8 -> 5.0 ms, of the geometric graph 15.9 -> 12.0, of LFR 10.1 -> 8.1, while the launch is the same
+    // within the noise of a box (89.1 / 197.8 / 171.6 us against 90.6 / 196.4 / 174.0; small-world 350 against 333-345: 200 launches lose
+    // 1-3 ms and the plan saves 7). Two sweeps cost the launch 2-4 %. Plans that expect a long life keep all five.
+    return launches < 2000 ? 3 : 0;
+}
+
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after) {
     if (f.reorder_mode != GESPMM_PLAN_REORDER_AUTO) return true;
     // the storage order is as good (already local, or nothing to find): keep it and pay nothing per launch. (0.05 until round 4: a
@@ -341,6 +350,8 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     a->cost_skipped = ad.cost_skipped;
     a->est_gain_us = ad.cost.gain_us;
     a->est_cost_us = ad.cost.cost_us;
+    a->cluster_levels = ad.analyse ? gespmm::cluster_levels_for(f) : 0;
+    a->cluster_sweeps = ad.analyse ? gespmm::cluster_sweeps_for(f) : 0;
     std::memcpy(a_out, &aa, (size_t)(a_bytes < (int64_t)sizeof aa ? a_bytes : (int64_t)sizeof aa));
     return 0;
 }

@@ -408,9 +408,11 @@ typedef struct gespmm_plan_policy_answer {
     int64_t model_window, model_sample;
     /* since 0.3 (written by gespmm_plan_policy_v2 when a_bytes covers them) */
     int32_t cost_skipped;      /* reorder = AUTO would have analysed, but gain x launches < cost: storage order, no analysis */
-    int32_t reserved1;
+    int32_t cluster_levels;    /* clustering depth of this plan (0 = the clustering's own default: six levels) */
     double est_gain_us;        /* estimated saving per launch if the clustered order is kept */
     double est_cost_us;        /* estimated time of the analysis */
+    int32_t cluster_sweeps;    /* label-propagation sweeps per level (0 = the clustering's own default: five) */
+    int32_t reserved1;
 } gespmm_plan_policy_answer;
 int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);  /* the 0.2 layouts (up to staged_fraction / model_sample) */
 int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q, int64_t q_bytes, gespmm_plan_policy_answer* a, int64_t a_bytes);

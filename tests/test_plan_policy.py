@@ -123,6 +123,17 @@ def test_cost_rule(name, shape, expect):
     assert a.cost_skipped == 77, "the 0.2 symbol writes the 0.2 answer only"
 
 
+def test_clustering_effort_follows_the_expected_launches():
+    """Plans with a short life cluster three levels deep with three sweeps each (profiles/r05/cluster_sweeps.log: the launch is the same
+    within the noise of a box, the analysis 15-25 % shorter); plans with a long life take the clustering's defaults (six / five)."""
+    short = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42)
+    assert (short["analyse"], short["cluster_levels"], short["cluster_sweeps"]) == (1, 3, 3)
+    long_ = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42, expected_launches=2000)
+    assert (long_["analyse"], long_["cluster_levels"], long_["cluster_sweeps"]) == (1, 0, 0)
+    none = _lib.plan_policy(19717, 19717, 108365, 128, 100, wedge_probe=0.11)
+    assert (none["analyse"], none["cluster_levels"], none["cluster_sweeps"]) == (0, 0, 0)
+
+
 def test_policy_respects_the_callers_choices():
     base = (334863, 334863, 1851744, 128, 120, 0.018, 0.651, 0.0)
     assert _lib.plan_policy(*base, reorder=_lib.PLAN_NO_REORDER)["analyse"] == 0
