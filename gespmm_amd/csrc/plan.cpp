@@ -463,12 +463,13 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
             // (the storage order is only judged against the clustered one — "already local, or hit by hubs: keep it" shows anywhere in a
             //  slice — so on matrices of >= 2^20 entries the first QUARTER of every slice is modelled: a quarter of the sort)
             const int64_t before_sample = nnz >= (1 << 20) ? std::max<int64_t>(nnz / 32, 1 << 15) : model_sample;
+            const int model_points = gespmm::model_points_for(f);  // sampled accesses per slice
             if (e == hipSuccess)
                 e = gespmm::device_l2_model(M, K, nnz, rowptr, colind, 8, model_window,
-                                            model_sample > 0 ? std::min<int64_t>(model_sample, before_sample) : before_sample, 4096,
+                                            model_sample > 0 ? std::min<int64_t>(model_sample, before_sample) : before_sample, model_points,
                                             &p->hits_before, st);
             if (e == hipSuccess)
-                e = gespmm::device_l2_model(M, K, nnz, p->d_rowptr, p->d_colind, 8, model_window, model_sample, 4096,
+                e = gespmm::device_l2_model(M, K, nnz, p->d_rowptr, p->d_colind, 8, model_window, model_sample, model_points,
                                             &p->hits_after, st);
             p->model_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tm).count();
             lap("l2 model x2");

@@ -284,7 +284,9 @@ __global__ void k_validate(const int32_t* __restrict__ rowptr, const int32_t* __
     }
     if (lane_id() == 0) {
         if (bad) atomicOr(&out[0], bad);
-        if (deg > 0) atomicMax(&out[1], deg);
+        // (the maximum only grows: a wavefront that sees it at or above its own skips the atomic — 29 000 same-address atomics on the
+        //  headline graph were 65 us, ten times the reading of the matrix)
+        if (deg > 0 && deg > __atomic_load_n(&out[1], __ATOMIC_RELAXED)) atomicMax(&out[1], deg);
     }
 }
 
@@ -369,10 +371,24 @@ __global__ void k_lower_bound_ptr(const int32_t* __restrict__ keys, int n, int n
     out[i] = lo;
 }
 
-__global__ void k_gather_rows_of(const int32_t* __restrict__ ptr, int n, const int32_t* __restrict__ pos, int cnt,
-                                 int32_t* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) out[i] = owner_of(ptr, n, pos[i]);
+// out[e] = the row that owns CSR position e, for every position. The 256 consecutive positions of a workgroup belong to a short range
+// of rows: two full searches find it, every thread then searches inside (a few steps that hit L1) — against 19 dependent steps through
+// L2 per entry when the owners of the SORTED positions were looked up after the transposition sort (86 us on the headline graph).
+__global__ void __launch_bounds__(256) k_rows_of_entries(const int32_t* __restrict__ ptr, int n, int64_t E, int32_t* __restrict__ out) {
+    __shared__ int s_lo, s_hi;
+    const int64_t e0 = (int64_t)blockIdx.x * 256;
+    if (threadIdx.x == 0) s_lo = owner_of(ptr, n, (int)e0);
+    if (threadIdx.x == 64) s_hi = owner_of(ptr, n, (int)(e0 + 255 < E ? e0 + 255 : E - 1));
+    __syncthreads();
+    const int64_t e = e0 + threadIdx.x;
+    if (e >= E) return;
+    int lo = s_lo, hi = s_hi;  // the owner is the LAST row r in [lo, hi] with ptr[r] <= e
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ptr[mid] <= (int)e) lo = mid;
+        else hi = mid - 1;
+    }
+    out[e] = lo;
 }
 
 __global__ void k_gather2(const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b,
@@ -401,9 +417,15 @@ constexpr int kBins = 4;  // degree classes 1..8, 9..64, 65..2048, > 2048
 constexpr int kHashSlots = 4096;
 __device__ inline int bin_of(int d) { return d <= 8 ? 0 : (d <= 64 ? 1 : (d <= 2048 ? 2 : 3)); }
 
-// lists[b * n + ...] = nodes of class b (order irrelevant: every node's result depends only on the snapshot)
-__global__ void k_bin_nodes(const int32_t* __restrict__ ptr, const int32_t* __restrict__ twin, int n,
-                            int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+// lists[b * n + ...] = nodes of class b (order irrelevant: every node's result depends only on the snapshot). A workgroup counts its
+// nodes per class in LDS and claims its share of each list with ONE global atomic per class (one per wavefront and class before:
+// 5 000 same-address atomics on the headline graph, 53 us per call — profiles/r05/plan_kernel_stats_before.csv).
+constexpr int kBinThreads = 1024;
+__global__ void __launch_bounds__(kBinThreads) k_bin_nodes(const int32_t* __restrict__ ptr, const int32_t* __restrict__ twin, int n,
+                                                           int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+    __shared__ int s_cnt[kBins], s_base[kBins];
+    if (threadIdx.x < kBins) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int b = -1;
     if (i < n) {
@@ -411,15 +433,20 @@ __global__ void k_bin_nodes(const int32_t* __restrict__ ptr, const int32_t* __re
         if (d > 0 && !(twin && twin[i] >= 0)) b = bin_of(d);
     }
     const int lane = lane_id();
+    int off = 0;  // this node's place inside the workgroup's share of list b
     for (int k = 0; k < kBins; ++k) {
         const unsigned long long mask = __ballot(b == k);
         if (mask == 0) continue;
         const int leader = __ffsll((long long)mask) - 1;
         int base = 0;
-        if (lane == leader) base = atomicAdd(&counts[k], __popcll(mask));
+        if (lane == leader) base = atomicAdd(&s_cnt[k], __popcll(mask));
         base = __shfl(base, leader);
-        if (b == k) lists[(int64_t)k * n + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+        if (b == k) off = base + __popcll(mask & ((1ull << lane) - 1ull));
     }
+    __syncthreads();
+    if (threadIdx.x < kBins) s_base[threadIdx.x] = s_cnt[threadIdx.x] > 0 ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0;
+    __syncthreads();
+    if (b >= 0) lists[(int64_t)b * n + s_base[b] + off] = i;
 }
 
 struct LpArgs {
@@ -661,10 +688,15 @@ __global__ void k_commit_rows(int32_t* __restrict__ cur, const int32_t* __restri
             atomicSub(&size[old], w);
         }
     }
+    // (one global atomic per workgroup, of 1024 threads: a per-wavefront atomic on `changed` made this kernel 36 us per call)
+    __shared__ int s_changed;
+    if (threadIdx.x == 0) s_changed = 0;
+    __syncthreads();
     const unsigned long long m = __ballot(ch);
-    if (m && lane_id() == (__ffsll((long long)m) - 1)) atomicAdd(changed, __popcll(m));
+    if (m && lane_id() == (__ffsll((long long)m) - 1)) atomicAdd(&s_changed, __popcll(m));
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (s_changed) atomicAdd(changed, s_changed);
         __threadfence();
         if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
             const int c = atomicAdd(changed, 0);
@@ -907,12 +939,18 @@ __global__ void k_model_prev(const int32_t* __restrict__ cols_sorted, const int3
     prev[pos_sorted[i]] = (i > 0 && cols_sorted[i - 1] == cols_sorted[i]) ? pos_sorted[i - 1] : -1;
 }
 
-// One wavefront per sampled access p: hit iff the column was used before in this slice at position a and fewer than
-// `window` DISTINCT columns were used in (a, p) — an access q in between is a first use there iff prev[q] < a.
-__global__ void __launch_bounds__(64) k_model_sample(const int32_t* __restrict__ prev, const SliceInfo* __restrict__ info,
-                                                     int slices, int samples, long long window,
-                                                     int32_t* __restrict__ hits /* [slices] */,
-                                                     int32_t* __restrict__ taken /* [slices] */) {
+// One workgroup (four wavefronts) per sampled access p: hit iff the column was used before in this slice at position a and fewer than
+// `window` DISTINCT columns were used in (a, p) — an access q in between is a first use there iff prev[q] < a. The wavefronts take
+// alternate 512-access pieces of (a, p) and add what they count to one LDS counter; each leaves as soon as the counter has reached
+// the window (the answer is then "miss" whatever the others still add), so the count is exact whenever it matters.
+// (Round 5: one wavefront per sample walked up to a whole slice in 256-access steps — 425 us per call on the headline graph, a sixth
+//  of the analysis: profiles/r05/plan_kernel_stats_before.csv.)
+constexpr int kModelSampleThreads = 256;
+__global__ void __launch_bounds__(kModelSampleThreads) k_model_sample(const int32_t* __restrict__ prev, const SliceInfo* __restrict__ info,
+                                                                      int slices, int samples, long long window,
+                                                                      int32_t* __restrict__ hits /* [slices] */,
+                                                                      int32_t* __restrict__ taken /* [slices] */) {
+    __shared__ int s_distinct;
     const int s = blockIdx.y;
     const int k = blockIdx.x;
     const int b = info->begin[s], e = info->end[s];
@@ -921,33 +959,34 @@ __global__ void __launch_bounds__(64) k_model_sample(const int32_t* __restrict__
     const long long n = len < samples ? len : samples;
     if (k >= n) return;
     const int p = b + (int)(((2 * (long long)k + 1) * len) / (2 * n));
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kWaves = kModelSampleThreads / 64, kPiece = 512;
     const int a = prev[p];
     int hit = 0;
-    if (a >= b) {
+    if (a >= b) {  // (uniform over the workgroup: every thread read the same prev[p])
         if ((long long)p - a - 1 < window) hit = 1;  // fewer accesses than the window holds
         else {
-            long long distinct = 0;
-            hit = 1;
-            // 256 accesses per step: four independent coalesced loads per lane in flight
-            for (int q0 = a + 1; q0 < p; q0 += 256) {
+            if (threadIdx.x == 0) s_distinct = 0;
+            __syncthreads();
+            for (long long q0 = (long long)a + 1 + (long long)wave * kPiece; q0 < p; q0 += (long long)kWaves * kPiece) {
                 int first = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = q0 + j * 64 + lane;
+                for (int j = 0; j < kPiece / 64; ++j) {  // eight independent coalesced loads per lane in flight
+                    const long long q = q0 + j * 64 + lane;
                     first += (q < p && prev[q] < a) ? 1 : 0;
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) first += __shfl_xor(first, o);
-                distinct += first;
-                if (distinct >= window) {
-                    hit = 0;
-                    break;
-                }
+                int seen = 0;
+                if (lane == 0) seen = atomicAdd(&s_distinct, first) + first;
+                seen = __shfl(seen, 0);
+                if (seen >= window) break;
             }
+            __syncthreads();
+            hit = s_distinct < window ? 1 : 0;
         }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         atomicAdd(&taken[s], 1);
         if (hit) atomicAdd(&hits[s], 1);
     }
@@ -1119,10 +1158,15 @@ hipError_t build_cols(Scratch& sc, DLevel& lv, const int32_t* n_of /* nullptr: r
     GESPMM_TRY(sc.get(&iota, E));
     GESPMM_TRY(sc.get(&keys_out, E));
     GESPMM_TRY(sc.get(&order, E));
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(E)), dim3(256), 0, st, iota, E);
-    GESPMM_TRY(sort_pairs<int32_t>(sc, lv.rows.idx, keys_out, iota, order, E, bits_for(lv.C), st));
-    if (n_of) hipLaunchKernelGGL(k_gather2, dim3(grid_for(E)), dim3(256), 0, st, n_of, lv.rows.w, order, (int)E, cidx, cw);
-    else hipLaunchKernelGGL(k_gather_rows_of, dim3(grid_for(E)), dim3(256), 0, st, lv.rows.ptr, lv.R, order, (int)E, cidx);
+    if (n_of) {
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(E)), dim3(256), 0, st, iota, E);
+        GESPMM_TRY(sort_pairs<int32_t>(sc, lv.rows.idx, keys_out, iota, order, E, bits_for(lv.C), st));
+        hipLaunchKernelGGL(k_gather2, dim3(grid_for(E)), dim3(256), 0, st, n_of, lv.rows.w, order, (int)E, cidx, cw);
+    } else {
+        // level 0: the sort carries every entry's ROW along (stable: rows ascend inside a column) — no lookup afterwards
+        hipLaunchKernelGGL(k_rows_of_entries, dim3(grid_for(E)), dim3(256), 0, st, lv.rows.ptr, lv.R, E, iota);
+        GESPMM_TRY(sort_pairs<int32_t>(sc, lv.rows.idx, keys_out, iota, cidx, E, bits_for(lv.C), st));
+    }
     hipLaunchKernelGGL(k_lower_bound_ptr, dim3(grid_for((int64_t)lv.C + 1)), dim3(256), 0, st, keys_out, (int)E, lv.C,
                        cptr);
     GESPMM_TRY(hipGetLastError());
@@ -1263,9 +1307,10 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         int32_t* ticket = flags_dev + 2;
         int32_t* rcounts = flags_dev + 4;
         int32_t* ccounts = flags_dev + 8;
-        hipLaunchKernelGGL(k_bin_nodes, dim3(grid_for(R)), dim3(256), 0, st, lv.rows.ptr, (const int32_t*)nullptr, R, rlists,
-                           rcounts);
-        hipLaunchKernelGGL(k_bin_nodes, dim3(grid_for(C)), dim3(256), 0, st, lv.cols.ptr, lv.twin, C, clists, ccounts);
+        hipLaunchKernelGGL(k_bin_nodes, dim3((unsigned)((R + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0, st, lv.rows.ptr,
+                           (const int32_t*)nullptr, R, rlists, rcounts);
+        hipLaunchKernelGGL(k_bin_nodes, dim3((unsigned)((C + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0, st, lv.cols.ptr,
+                           lv.twin, C, clists, ccounts);
         GESPMM_TRY(hipGetLastError());
         int32_t h_counts[8];
         GESPMM_TRY(fetch(h_counts, (const int32_t*)(flags_dev + 4), 8, st));
@@ -1308,8 +1353,8 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             a.rweight = lv.rweight;
             a.skip_half = (twins && sweep + 1 < sweeps) ? 1 : 0;
             GESPMM_TRY(launch_half_sweep<true>(a, rlists, rcounts, h_counts, R, acc, acc_wgs, R, st));
-            hipLaunchKernelGGL(k_commit_rows, dim3(grid_for(R)), dim3(256), 0, st, rlab, (const int32_t*)rnext, lv.rweight, size,
-                               R, changed, ticket, done);
+            hipLaunchKernelGGL(k_commit_rows, dim3((unsigned)((R + 1023) / 1024)), dim3(1024), 0, st, rlab, (const int32_t*)rnext,
+                               lv.rweight, size, R, changed, ticket, done);
             GESPMM_TRY(hipGetLastError());
         }
         lap("sweeps", level);
@@ -1510,7 +1555,7 @@ hipError_t device_l2_model(int64_t M, int64_t K, int64_t nnz, const int32_t* row
     GESPMM_TRY(sort_pairs<int32_t>(sc, cols, cols_sorted, poss, pos_sorted, total, bits_for(K), st));
     hipLaunchKernelGGL(k_model_prev, dim3(grid_for(total)), dim3(256), 0, st, (const int32_t*)cols_sorted,
                        (const int32_t*)pos_sorted, total, prev);
-    hipLaunchKernelGGL(k_model_sample, dim3((unsigned)samples_per_slice, (unsigned)slices), dim3(64), 0, st,
+    hipLaunchKernelGGL(k_model_sample, dim3((unsigned)samples_per_slice, (unsigned)slices), dim3(kModelSampleThreads), 0, st,
                        (const int32_t*)prev, (const SliceInfo*)info, slices, samples_per_slice, (long long)window, cnt,
                        cnt + 16);
     GESPMM_TRY(hipGetLastError());
@@ -1592,6 +1637,8 @@ hipError_t device_cut_tasks(int64_t M, const int32_t* rowptr_p, const int64_t bu
 namespace {
 
 constexpr int kStageHistBins = 256;
+constexpr int kStageCounters = 64;  // partial sums of the staged-entry count (power of two)
+constexpr int kStageKeysLds = 8192;  // keys of a block kept in LDS by k_stage_select (32 KB)
 
 __global__ void k_stage_offsets(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int32_t* __restrict__ blkoff) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1617,14 +1664,22 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
     const int64_t blk = blockIdx.x;
     const int b = blkoff[blk], e = blkoff[blk + 1];
     hist[tid] = 0;
+    // the block's sorted keys are walked run by run, twice, by the thread at each run's head: from LDS when they fit (they do unless the
+    // block holds more than kStageKeysLds entries) — the walk is a chain of dependent loads as long as the longest run, and from global
+    // memory that chain was most of this kernel's 180-197 us on the headline graph
+    __shared__ int32_t s_keys[kStageKeysLds];
+    const bool in_lds = e - b <= kStageKeysLds;
+    if (in_lds)
+        for (int p = b + tid; p < e; p += 256) s_keys[p - b] = keys[p];
     __syncthreads();
+    auto key_at = [&](int p) -> int32_t { return in_lds ? s_keys[p - b] : keys[p]; };
     // length of the run starting at p (0 if p is not the head of a run), clamped to the histogram
     auto run_at = [&](int p, int& key) -> int {
         if (p >= e) return 0;
-        key = keys[p];
-        if (p > b && keys[p - 1] == key) return 0;
+        key = key_at(p);
+        if (p > b && key_at(p - 1) == key) return 0;
         int len = 1;
-        while (p + len < e && keys[p + len] == key) ++len;
+        while (p + len < e && key_at(p + len) == key) ++len;
         return len;
     };
     for (int p0 = b; p0 < e; p0 += 256) {
@@ -1633,21 +1688,26 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
         if (len >= 2) atomicAdd(&hist[len < kStageHistBins ? len : kStageHistBins - 1], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        // every run longer than t is staged (ngt of them), `quota` runs of length exactly t fill the rest
-        int cum = 0, t = 1, ngt = 0, quota = 0;
-        for (int L = kStageHistBins - 1; L >= 2; --L) {
-            if (cum + hist[L] > H) {
-                t = L;
-                quota = H - cum;
-                break;
-            }
-            cum += hist[L];
+    {
+        // every run longer than t is staged (ngt of them), `quota` runs of length exactly t fill the rest. Thread i looks at length
+        // L = 255 - i: a scan over the histogram from the long end finds where the H slots run out (one thread walking the 254 bins
+        // was 25 us of dependent LDS reads per workgroup: the kernel took 197 us on the headline graph)
+        static_assert(kStageHistBins == 256, "one histogram bin per thread");
+        const int L = kStageHistBins - 1 - tid;
+        const int h = L >= 2 ? hist[L] : 0;
+        int incl = 0;
+        BlockScan().inclusive_scan(h, incl, scan_storage, rocprim::plus<int>());
+        if (tid == 0) {
+            s_t = 1;
+            s_quota = 0;
         }
-        ngt = cum;
-        s_t = t;
-        s_ngt = ngt;
-        s_quota = quota;
+        if (L == 2) s_ngt = incl;  // (if nothing overflows: every run of two or more is staged)
+        __syncthreads();
+        if (L >= 2 && incl > H && incl - h <= H) {
+            s_t = L;
+            s_ngt = incl - h;
+            s_quota = H - (incl - h);
+        }
     }
     __syncthreads();
     const int t = s_t, ngt = s_ngt, quota = s_quota;
@@ -1679,7 +1739,15 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
     }
     if (tid == 0) nhot[blk] = ngt + (base_eq < quota ? base_eq : quota);
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-    if ((tid & 63) == 0 && mine) atomicAdd(staged_entries, mine);
+    // (one atomic per workgroup, spread over kStageCounters addresses the host adds up: 14 000 same-address 64-bit atomics, one per
+    //  wavefront, were 130 of this kernel's 180 us on the headline graph)
+    __shared__ unsigned long long s_mine[4];
+    if ((tid & 63) == 0) s_mine[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long all = s_mine[0] + s_mine[1] + s_mine[2] + s_mine[3];
+        if (all) atomicAdd(&staged_entries[blk & (kStageCounters - 1)], all);
+    }
 }
 
 __global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int kStagedWaves,
@@ -1869,11 +1937,11 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     GESPMM_TRY(sc.get(&idx_in, nnz));
     GESPMM_TRY(sc.get(&idx_out, nnz));
     GESPMM_TRY(sc.get(&code, nnz));
-    GESPMM_TRY(sc.get(&staged, 1));
+    GESPMM_TRY(sc.get(&staged, kStageCounters));
     GESPMM_TRY(sc.get(&tmp, (int64_t)(sort_bytes ? sort_bytes : 256)));
     StagingTables t;  // the four tables built here; merged into *out on success
     auto body = [&]() -> hipError_t {
-        GESPMM_TRY(hipMemsetAsync(staged, 0, 8, st));
+        GESPMM_TRY(hipMemsetAsync(staged, 0, 8 * kStageCounters, st));
         hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, R, blkoff);
         hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
         GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, sort_bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
@@ -1899,8 +1967,9 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
                            t.ev);
         hipLaunchKernelGGL(k_stage_rowends, dim3(grid_for(M + kStagedPad)), dim3(256), 0, st, rowptr_p, perm, M, nnz, t.ev);
         GESPMM_TRY(hipGetLastError());
-        unsigned long long h = 0;
-        GESPMM_TRY(fetch(&h, (const unsigned long long*)staged, 1, st));  // (synchronises: the temporaries may go)
+        unsigned long long hs[kStageCounters], h = 0;
+        GESPMM_TRY(fetch(hs, (const unsigned long long*)staged, kStageCounters, st));  // (synchronises: the temporaries may go)
+        for (int i = 0; i < kStageCounters; ++i) h += hs[i];
         t.nblocks = (int32_t)nblk;
         t.staged_fraction = (double)h / (double)nnz;
         return hipSuccess;

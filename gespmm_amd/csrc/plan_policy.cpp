@@ -41,9 +41,8 @@ static bool crc_family(int v) { return v >= GESPMM_VARIANT_CRC && v <= GESPMM_VA
 //     the share of sampled (row r; two of its columns c1, c2) wedges with c2 in row c1. Structureless graphs close none (1e-4: gains
 //     0.02-0.15), every graph with communities, triangles or geometry closes 6-58 % (gains 0.29-0.90): 0.1 + 0.9 sqrt(probe), capped
 //     at 0.85; unknown (rectangular matrix, host analysis): 0.6 — the benefit of the doubt;
-//   cost of the analysis = 3.4 ms of launch and synchronisation latency at any size + 1.6 ns per entry up to 2 M + 0.6 ns per entry
-//     (7.4 ms at 1.85 M entries, 75 ms at 124 M: profiles/r04/small_graph_plans.log, bench_round4.log) — device analysis; the host
-//     form is ~30x that.
+//   cost of the analysis = a fixed part (launch and synchronisation latency at any size) + 1.2-1.8 ns per entry up to 12 M + 0.55 ns
+//     per entry beyond, by the plan's expected life (below) — device analysis; the host form is ~30x that.
 CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     CostEstimate c;
     if (f.wedge_probe < 0.0) c.hits_gain = 0.60;  // unknown: the benefit of the doubt — only matrices too small to ever pay are skipped
@@ -59,7 +58,12 @@ CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     const double gathered_mb = 4.0 * (double)f.nnz * (double)f.N / 1e6;
     c.gain_us = gathered_mb * c.hits_gain * 0.085;
     const double e = (double)f.nnz;
-    c.cost_us = 3400.0 + 1.6e-3 * (e < 2e6 ? e : 2e6) + 0.6e-3 * e;
+    // (round 5, after the analysis kernels were reworked — profiles/r05/plan_ms.log: 3.7 / 6.9 / 10.1 / 17.8 / 74.7 ms at 1.85 / 4.7 /
+    //  7.2 / 11.0 / 124 M entries for plans with a short life (three levels, three sweeps, 1 024 model samples per slice), 7.4 / 16.2 /
+    //  80-90 ms at 1.85 / 7.2 / 124 M for the others)
+    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+    const double head = e < 12e6 ? e : 12e6, tail = e - head;
+    c.cost_us = launches < 2000 ? 1500.0 + 1.2e-3 * head + 0.55e-3 * tail : 3400.0 + 1.8e-3 * head + 0.55e-3 * tail;
     if (f.host_analysis) c.cost_us *= 30.0;
     return c;
 }
@@ -120,6 +124,14 @@ int cluster_sweeps_for(const PlanFacts& f) {
     // within the noise of a box (89.1 / 197.8 / 171.6 us against 90.6 / 196.4 / 174.0; small-world 350 against 333-345: 200 launches lose
     // 1-3 ms and the plan saves 7). Two sweeps cost the launch 2-4 %. Plans that expect a long life keep all five.
     return launches < 2000 ? 3 : 0;
+}
+
+int model_points_for(const PlanFacts& f) {
+    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+    // sampled accesses per XCD slice in the L2 model. A sample walks back through its slice until it has seen a window of distinct
+    // columns: 32 768 samples are ~0.3 GB of reads per model, 0.39 ms on the headline graph, twice per plan. A quarter of them puts the
+    // standard error of a modelled hit rate at 0.55 % (0.28 % before) — the rules that read it have margins of 3 % and more.
+    return launches < 2000 ? 1024 : 4096;
 }
 
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after) {
