@@ -120,7 +120,7 @@ def main():
                     if kern == "staged" and (N not in (64, 128, 256, 512) or not order):
                         continue
                     try:
-                        p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=order, kernel=kern)
+                        p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=order, kernel=kern, expected_launches=1000000)
                     except Exception as ex:  # noqa: BLE001
                         alts["%s/%s" % ("clustered" if order else "storage", kern)] = (None, str(ex)[:40])
                         continue
@@ -138,7 +138,7 @@ def main():
             if nnz / M > 96:  # dense graphs: the clustered order is reachable only without the cache-blocked path
                 from gespmm_amd import _lib
                 for kern in ("stream", "seg-stream"):
-                    p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=kern, flags=_lib.FLAG_NO_SLAB_BLOCKED)
+                    p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=kern, flags=_lib.FLAG_NO_SLAB_BLOCKED, expected_launches=1000000)
                     t2 = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p2), iters)
                     ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
                     alts["clustered-noslab/%s" % kern] = (t2, ("" if ok else "BITS-DIFFER ") + "(model %s)" % p2.describe().split("l2_model=")[1].split(" ")[0])
