@@ -847,6 +847,31 @@ __global__ void k_parent_rank(const int32_t* __restrict__ parent, const int32_t*
     ids[i] = (int32_t)i;
 }
 
+// The same order from ONE sort of the rows (round 5): key = the row's ancestors (cluster of level hi, ..., cluster of level lo + 1), the
+// coarser the more significant; parent[l][node of level l] = its cluster of level l + 1.
+constexpr int kOrderMaxLevels = 16;
+struct OrderLevels {
+    const int32_t* parent[kOrderMaxLevels];
+    int bits[kOrderMaxLevels];
+};
+__global__ void k_order_keys(OrderLevels lv, const int32_t* __restrict__ rows /* nullptr: row i */, int64_t M, int lo, int hi,
+                             unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int row = rows ? rows[i] : (int)i;
+    int node = row, shift = 0;
+    unsigned long long key = 0;
+    for (int l = 0; l < hi; ++l) {
+        node = lv.parent[l][node];
+        if (l >= lo) {
+            key |= (unsigned long long)(uint32_t)node << shift;
+            shift += lv.bits[l];
+        }
+    }
+    keys[i] = key;
+    vals[i] = row;
+}
+
 __global__ void k_invert(const int32_t* __restrict__ sorted_ids, int64_t n, int32_t* __restrict__ rank) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rank[sorted_ids[i]] = (int32_t)i;
@@ -1475,6 +1500,36 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
     sc.use(Scratch::kTemp);
     if (parents.empty()) {
         hipLaunchKernelGGL(k_iota, dim3(grid_for(M)), dim3(256), 0, st, perm, M);
+    } else if ((int)parents.size() <= kOrderMaxLevels) {
+        // ... which is the order of the rows by the composite key (cluster of the coarsest level, ..., cluster of the finest level), ties
+        // by row id: ONE stable sort of the rows when the fields fit 64 bits (three levels of a com-Amazon-sized graph: 46), else one
+        // stable sort per group of levels from the finest group up. (The level-by-level ranking below took three sorts plus their
+        // scatter kernels for three levels: 0.26 ms of the headline graph's analysis; this is ~0.07.)
+        const int L = (int)parents.size();
+        OrderLevels lv;
+        for (int l = 0; l < kOrderMaxLevels; ++l) {
+            lv.parent[l] = l < L ? parents[l] : nullptr;
+            lv.bits[l] = l < L ? bits_for(cluster_count[l]) : 0;
+        }
+        unsigned long long *keys = nullptr, *keys_out = nullptr;
+        int32_t *vals = nullptr, *vals_tmp[2] = {nullptr, nullptr};
+        GESPMM_TRY(sc.get(&keys, M));
+        GESPMM_TRY(sc.get(&keys_out, M));
+        GESPMM_TRY(sc.get(&vals, M));
+        GESPMM_TRY(sc.get(&vals_tmp[0], M));
+        GESPMM_TRY(sc.get(&vals_tmp[1], M));
+        const int32_t* rows = nullptr;  // the rows in the order of the passes so far (nullptr: storage order)
+        int lo = 0, pass = 0;
+        while (lo < L) {
+            int hi = lo, bits = 0;
+            while (hi < L && bits + lv.bits[hi] <= 64) bits += lv.bits[hi++];
+            int32_t* out = hi == L ? perm : vals_tmp[pass & 1];
+            hipLaunchKernelGGL(k_order_keys, dim3(grid_for(M)), dim3(256), 0, st, lv, rows, M, lo, hi, keys, vals);
+            GESPMM_TRY(sort_pairs<unsigned long long>(sc, keys, keys_out, vals, out, M, bits, st));
+            rows = out;
+            lo = hi;
+            ++pass;
+        }
     } else {
         const int L = (int)parents.size();
         int32_t* rank = nullptr;  // rank of the nodes of level l + 1 (nullptr: their ids)
