@@ -16,9 +16,10 @@ through a gespmm plan (the analysis stage: row clustering + task table, built ON
 time reported as `plan_ms`; the plain entry point is timed beside it in `extra`). Inputs are resident in HBM
 before the timed region. `roofline.kernel_us` is the AVERAGE launch duration over the timed region: one pair of HIP
 events on the launch stream around the K steps, divided by K (what rocprofv3's per-kernel average of the same command
-agrees with to ~1 %); `roofline.kernel_us_median_of_pairs` — every launch between its own pair of events, >= 200 of them
-whatever --steps is, the statistic of every OTHER entry of the record — reads ~3 us higher on a 90 us kernel: the event
-handling between launches is in it.
+agrees with to ~1 %); `roofline.kernel_us_median_of_pairs` is the statistic of every OTHER entry of the record: the
+median over event pairs around ten launches each (one launch each from 300 us up), >= 200 launches whatever --steps is —
+a pair around every single launch, the statistic of rounds 2-4, reads ~3 us higher: the event handling between launches
+is in it.
 
 Several GPUs (the SCALE lines, one process per GPU): the north_star's experiment — ONE RMAT graph (Graph500
 parameters; scale 26 = 2^30 edges unless --rmat-scale says otherwise) cut into nnz-balanced contiguous row shards
@@ -208,10 +209,13 @@ class BenchEnv:
         return out
 
     def kernel_times_us(self, fn, n):
-        """Each launch between its own pair of HIP events on the launch stream (the torch current stream IS the stream
-        handed to the C ABI). (Host environment of the CPU suite: wall clock per call.)"""
+        """n launches timed by HIP events on the launch stream (the torch current stream IS the stream handed to the C ABI); returns
+        one duration per event pair. A pair around EVERY launch puts ~3 us of event handling between launches (35 against rocprofv3's
+        33 us on a 33 us kernel): launches shorter than 300 us are timed ten to a pair — at least 20 pairs — and each pair reports its
+        average launch. (Host environment of the CPU suite: wall clock per call.)"""
         torch = self.torch
         n = max(int(n), 1)
+        self.launches_per_event_pair = 1
         if not self.cuda:
             out = []
             for _ in range(n):
@@ -219,15 +223,25 @@ class BenchEnv:
                 fn()
                 out.append((time.perf_counter() - t0) * 1e6)
             return out
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        for i in range(n):
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        batch = 10 if e0.elapsed_time(e1) * 1e3 < 300.0 and n >= 10 else 1
+        pairs = max(n // batch, 20) if batch > 1 else n
+        self.launches_per_event_pair = batch
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(pairs)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(pairs)]
+        torch.cuda.synchronize()
+        for i in range(pairs):
             starts[i].record()
-            fn()
+            for _ in range(batch):
+                fn()
             ends[i].record()
         torch.cuda.synchronize()
-        return [s.elapsed_time(e) * 1e3 for s, e in zip(starts, ends)]
+        return [s.elapsed_time(e) * 1e3 / batch for s, e in zip(starts, ends)]
 
     def max_over_ranks(self, seconds):
         if not self.use_dist:
@@ -379,7 +393,8 @@ def main():
         us = kernel_times_us(step, samples)
         ab = algorithmic_bytes(M, K, N, nnz, valued)
         med = statistics.median(us)
-        out = {"kernel_us": med, "kernel_us_mean": sum(us) / len(us), "kernel_us_min": min(us), "launches": len(us),
+        out = {"kernel_us": med, "kernel_us_mean": sum(us) / len(us), "kernel_us_min": min(us), "launches": len(us) * env.launches_per_event_pair,
+               "launches_per_event_pair": env.launches_per_event_pair,
                "gflops": 2.0 * nnz * N / med / 1e3, "achieved_GBs": ab / med / 1e3, "frac": ab / med / 1e3 / HBM_PEAK_GBS,
                "roof_gflops": roof_gflops(M, K, N, nnz, valued)}
         if plan_ms is not None:
@@ -1129,7 +1144,7 @@ def run_rmat(args, env, N, with_cpu_baseline=False):
         "roofline": {
             "bound": "hbm", "achieved": abytes / med / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / med / 1e3 / HBM_PEAK_GBS,
             "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_us": med,
-            "kernel_us_stat": "median of %d launches, one HIP event pair each (rank 0)" % len(us),
+            "kernel_us_stat": "median of %d event pairs around %d launch(es) each (rank 0)" % (len(us), env.launches_per_event_pair),
             "gather_bytes_per_launch": 4 * nnz * N, "gather_GBs": 4.0 * nnz * N / med / 1e3,
         },
         "exchange": {
