@@ -413,9 +413,11 @@ struct DAdj {
 constexpr int kDefaultClusterLevels = 6;  // == reorder.cpp. Levels 4-6 merge little (8872 > 6372 > 5957 > 5932 clusters on the structureless com-Amazon
                                           // stand-in) yet its plan runs 138.6 instead of 145.1 us at N = 128 (47.4 / 50.0 at 32, 537 / 545 at 512) with them:
                                           // profiles/r04/like_regression.log; round 3 had cut them for 2 ms of analysis time
-constexpr int kBins = 4;  // degree classes 1..8, 9..64, 65..2048, > 2048
+constexpr int kBins = 6;  // degree classes 1..8, 9..16, 17..32, 33..64 (one lane per entry in a group of that many lanes), 65..2048, > 2048
+                          // (round 5: 9..64 was ONE class of 64-lane groups — 0.6 ms of the headline graph's 3.6 ms analysis went into wavefronts
+                          //  that were three quarters empty; a node's result does not depend on the width of its group)
 constexpr int kHashSlots = 4096;
-__device__ inline int bin_of(int d) { return d <= 8 ? 0 : (d <= 64 ? 1 : (d <= 2048 ? 2 : 3)); }
+__device__ inline int bin_of(int d) { return d <= 8 ? 0 : (d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 3 : (d <= 2048 ? 4 : 5)))); }
 
 // lists[b * n + ...] = nodes of class b (order irrelevant: every node's result depends only on the snapshot). A workgroup counts its
 // nodes per class in LDS and claims its share of each list with ONE global atomic per class (one per wavefront and class before:
@@ -1213,8 +1215,10 @@ hipError_t launch_half_sweep(const LpArgs& base, const int32_t* lists, const int
         a.list = lists + (int64_t)b * n_side;
         a.count = counts_dev + b;
         if (b == 0) hipLaunchKernelGGL((k_lp_small<8, ROWS>), dim3(grid_for((int64_t)cnt * 8)), dim3(256), 0, st, a);
-        else if (b == 1) hipLaunchKernelGGL((k_lp_small<64, ROWS>), dim3(grid_for((int64_t)cnt * 64)), dim3(256), 0, st, a);
-        else if (b == 2) hipLaunchKernelGGL((k_lp_wave<ROWS>), dim3((unsigned)cnt), dim3(64), 0, st, a);
+        else if (b == 1) hipLaunchKernelGGL((k_lp_small<16, ROWS>), dim3(grid_for((int64_t)cnt * 16)), dim3(256), 0, st, a);
+        else if (b == 2) hipLaunchKernelGGL((k_lp_small<32, ROWS>), dim3(grid_for((int64_t)cnt * 32)), dim3(256), 0, st, a);
+        else if (b == 3) hipLaunchKernelGGL((k_lp_small<64, ROWS>), dim3(grid_for((int64_t)cnt * 64)), dim3(256), 0, st, a);
+        else if (b == 4) hipLaunchKernelGGL((k_lp_wave<ROWS>), dim3((unsigned)cnt), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_lp_dense<ROWS>), dim3((unsigned)std::min(cnt, acc_wgs)), dim3(256), 0, st, a, acc, nlabels);
     }
     return hipGetLastError();
@@ -1264,7 +1268,7 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         const size_t E = (size_t)nnz, V = (size_t)(M + K);
         const size_t persist = 4 * (3 * (size_t)M + 4096);
         const size_t level = 4 * (4 * E + 2 * V + 64) + 16 * 256;
-        const size_t temp = 48 * E + 40 * V + 2 * sort_tmp + (1 << 20);
+        const size_t temp = 48 * E + 56 * V + 2 * sort_tmp + (1 << 20);
         GESPMM_TRY(sc.init(persist, level, temp));
     }
 
@@ -1289,7 +1293,8 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
     std::vector<int32_t> parent_count;  // nodes of level l (length of parents[l])
     std::vector<int32_t> cluster_count; // nodes of level l + 1
 
-    int32_t* flags_dev = nullptr;  // {done, changed, ticket, -, counts_rows[4], counts_cols[4], -}
+    int32_t* flags_dev = nullptr;  // {done, changed, ticket, -, counts_rows[kBins], counts_cols[kBins]}
+    static_assert(4 + 2 * kBins <= 16, "k_level_init zeroes 16 flags");
     sc.use(Scratch::kPersist);
     GESPMM_TRY(sc.get(&flags_dev, 16));
 
@@ -1331,19 +1336,19 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
         int32_t* changed = flags_dev + 1;
         int32_t* ticket = flags_dev + 2;
         int32_t* rcounts = flags_dev + 4;
-        int32_t* ccounts = flags_dev + 8;
+        int32_t* ccounts = flags_dev + 4 + kBins;
         hipLaunchKernelGGL(k_bin_nodes, dim3((unsigned)((R + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0, st, lv.rows.ptr,
                            (const int32_t*)nullptr, R, rlists, rcounts);
         hipLaunchKernelGGL(k_bin_nodes, dim3((unsigned)((C + kBinThreads - 1) / kBinThreads)), dim3(kBinThreads), 0, st, lv.cols.ptr,
                            lv.twin, C, clists, ccounts);
         GESPMM_TRY(hipGetLastError());
-        int32_t h_counts[8];
-        GESPMM_TRY(fetch(h_counts, (const int32_t*)(flags_dev + 4), 8, st));
+        int32_t h_counts[2 * kBins];
+        GESPMM_TRY(fetch(h_counts, (const int32_t*)(flags_dev + 4), 2 * kBins, st));
         // dense accumulators of the > 2048-entry class (label space = the row labels of this level)
         unsigned long long* acc = nullptr;
         int acc_wgs = 0;
-        if (h_counts[3] > 0 || h_counts[7] > 0) {
-            const int want = std::max(h_counts[3], h_counts[7]);
+        if (h_counts[kBins - 1] > 0 || h_counts[2 * kBins - 1] > 0) {
+            const int want = std::max(h_counts[kBins - 1], h_counts[2 * kBins - 1]);
             int64_t wgs = std::min<int64_t>(want, 64);
             while (wgs > 1 && wgs * (int64_t)R * 8 > (1ll << 30)) wgs >>= 1;
             acc_wgs = (int)wgs;
@@ -1366,7 +1371,7 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
             a.size = nullptr;
             a.rweight = nullptr;
             a.skip_half = 0;
-            GESPMM_TRY(launch_half_sweep<false>(a, clists, ccounts, h_counts + 4, C, acc, acc_wgs, R, st));
+            GESPMM_TRY(launch_half_sweep<false>(a, clists, ccounts, h_counts + kBins, C, acc, acc_wgs, R, st));
             hipLaunchKernelGGL(k_commit_cols, dim3(grid_for(C)), dim3(256), 0, st, clab, (const int32_t*)cnext, lv.twin,
                                (const int32_t*)rlab, C, (const int32_t*)done);
             // rows <- heaviest column label, within the size cap (sizes: as of the start of the half-sweep)

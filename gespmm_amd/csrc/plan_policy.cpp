@@ -41,8 +41,8 @@ static bool crc_family(int v) { return v >= GESPMM_VARIANT_CRC && v <= GESPMM_VA
 //     the share of sampled (row r; two of its columns c1, c2) wedges with c2 in row c1. Structureless graphs close none (1e-4: gains
 //     0.02-0.15), every graph with communities, triangles or geometry closes 6-58 % (gains 0.29-0.90): 0.1 + 0.9 sqrt(probe), capped
 //     at 0.85; unknown (rectangular matrix, host analysis): 0.6 — the benefit of the doubt;
-//   cost of the analysis = a fixed part (launch and synchronisation latency at any size) + 1.2-1.8 ns per entry up to 12 M + 0.55 ns
-//     per entry beyond, by the plan's expected life (below) — device analysis; the host form is ~30x that.
+//   cost of the analysis = a fixed part (launch and synchronisation latency at any size: 3 / 5 ms by the plan's expected life, below)
+//     + 0.55-0.6 ns per entry — device analysis; the host form is ~30x that.
 CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     CostEstimate c;
     if (f.wedge_probe < 0.0) c.hits_gain = 0.60;  // unknown: the benefit of the doubt — only matrices too small to ever pay are skipped
@@ -58,12 +58,12 @@ CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     const double gathered_mb = 4.0 * (double)f.nnz * (double)f.N / 1e6;
     c.gain_us = gathered_mb * c.hits_gain * 0.085;
     const double e = (double)f.nnz;
-    // (round 5, after the analysis kernels were reworked — profiles/r05/plan_ms.log: 3.7 / 6.9 / 10.1 / 17.8 / 74.7 ms at 1.85 / 4.7 /
-    //  7.2 / 11.0 / 124 M entries for plans with a short life (three levels, three sweeps, 1 024 model samples per slice), 7.4 / 16.2 /
-    //  80-90 ms at 1.85 / 7.2 / 124 M for the others)
+    // (round 5, after the analysis kernels were reworked — profiles/r05/plan_ms_after_kernel_work.log: 3.4 / 5.0 / 5.4 / 7.9 / 73.6 ms at
+    //  1.85 / 4.7 / 7.2 / 11.0 / 124 M entries for plans with a short life (three levels, three sweeps, 1 024 model samples per slice),
+    //  6.4 / 7.9 / 78.9 ms at 1.85 / 7.2 / 124 M for the others; the fixed parts carry ~0.6 ms of margin: the gain side of the rule is an
+    //  estimate from a probe — Barabasi-Albert: 30 us estimated, 16 measured)
     const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
-    const double head = e < 12e6 ? e : 12e6, tail = e - head;
-    c.cost_us = launches < 2000 ? 1500.0 + 1.2e-3 * head + 0.55e-3 * tail : 3400.0 + 1.8e-3 * head + 0.55e-3 * tail;
+    c.cost_us = launches < 2000 ? 3000.0 + 0.55e-3 * e : 5000.0 + 0.6e-3 * e;
     if (f.host_analysis) c.cost_us *= 30.0;
     return c;
 }
