@@ -29,6 +29,7 @@ int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags) {
 }
 
 static bool crc_family(int v) { return v >= GESPMM_VARIANT_CRC && v <= GESPMM_VARIANT_CRC_CWM8; }
+static bool deep_analysis(const PlanFacts& f);  // (below: how much analysis a plan's expected life buys)
 
 // Cost awareness (round 5). Until round 4 AUTO clustered every matrix with >= 16 384 rows and a B beyond 8 MB, whatever the analysis
 // cost and however few launches would use it: the reference's own GCN configuration (pubmed, hidden 128, cached=True) got 52 % SLOWER
@@ -62,8 +63,7 @@ CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     //  1.85 / 4.7 / 7.2 / 11.0 / 124 M entries for plans with a short life (three levels, three sweeps, 1 024 model samples per slice),
     //  6.4 / 7.9 / 78.9 ms at 1.85 / 7.2 / 124 M for the others; the fixed parts carry ~0.6 ms of margin: the gain side of the rule is an
     //  estimate from a probe — Barabasi-Albert: 30 us estimated, 16 measured)
-    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
-    c.cost_us = launches < 2000 ? 3000.0 + 0.55e-3 * e : 5000.0 + 0.6e-3 * e;
+    c.cost_us = !deep_analysis(f) ? 3000.0 + 0.55e-3 * e : 5000.0 + 0.6e-3 * e;
     if (f.host_analysis) c.cost_us *= 30.0;
     return c;
 }
@@ -110,28 +110,30 @@ AnalysisDecision decide_analysis(const PlanFacts& f) {
     return a;
 }
 
-int cluster_levels_for(const PlanFacts& f) {
-    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
-    // 2 ms buy 4.5 % of ~140 us = 6 us per launch on the one graph family they help: ~330 launches to break even there, nothing
-    // to gain elsewhere; with a margin for graphs between the two families
-    return launches < 2000 ? 3 : 0;
+// How much analysis a plan's expected life buys. Deep = the clustering's defaults (six levels, five sweeps per level), shallow = three
+// of each: 3.4 ms less on a com-Amazon-sized graph, and a launch that is 2-4 % slower (profiles/r05/plan_life_compare.log: com-Amazon-
+// shaped 95.3 / 179 / 381 us against 93.2 / 174 / 366 at N = 128 / 256 / 512, geometric 205 / 352 / 692 against 197 / 341 / 661) — a
+// share of a time that grows with N, so the launches it takes to pay for the depth shrink with N: ~1 600 / 220 at N = 128 / 512 on the
+// first graph, ~340 / 90 on the second. launches x N >= 100 000 (780 launches at N = 128, 200 at N = 512) sits between them.
+static bool deep_analysis(const PlanFacts& f) {
+    const long long launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+    return launches * (long long)(f.N > 0 ? f.N : 1) >= 100000ll;
 }
 
+int cluster_levels_for(const PlanFacts& f) { return deep_analysis(f) ? 0 : 3; }
+
 int cluster_sweeps_for(const PlanFacts& f) {
-    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
     // label-propagation sweeps per level. Five (the default of cluster_rows) against three, profiles/r05/cluster_sweeps.log: the analysis
     // of the com-Amazon-shaped graph 5.8 -> 5.0 ms, of the geometric graph 15.9 -> 12.0, of LFR 10.1 -> 8.1, while the launch is the same
-    // within the noise of a box (89.1 / 197.8 / 171.6 us against 90.6 / 196.4 / 174.0; small-world 350 against 333-345: 200 launches lose
-    // 1-3 ms and the plan saves 7). Two sweeps cost the launch 2-4 %. Plans that expect a long life keep all five.
-    return launches < 2000 ? 3 : 0;
+    // within the noise of a box at N = 128 (89.1 / 197.8 / 171.6 us against 90.6 / 196.4 / 174.0). Two sweeps cost the launch 2-4 %.
+    return deep_analysis(f) ? 0 : 3;
 }
 
 int model_points_for(const PlanFacts& f) {
-    const int launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
     // sampled accesses per XCD slice in the L2 model. A sample walks back through its slice until it has seen a window of distinct
     // columns: 32 768 samples are ~0.3 GB of reads per model, 0.39 ms on the headline graph, twice per plan. A quarter of them puts the
     // standard error of a modelled hit rate at 0.55 % (0.28 % before) — the rules that read it have margins of 3 % and more.
-    return launches < 2000 ? 1024 : 4096;
+    return deep_analysis(f) ? 4096 : 1024;
 }
 
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after) {
@@ -190,8 +192,11 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
                       (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && !narrow && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
                        f.nnz >= (1 << 20) && v4) ||
                       // the lane-group form at N = 32 / 64 (spmm_staged_narrow.hip): worth its tables where most of the entries will be
-                      // staged — rows of 10+ entries in an order modelled at >= 0.75 hits (keep_staged_tables decides on the share)
-                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && narrow && (f.N == 32 || f.N == 64) && mean >= 10 && hits_after >= 0.75 &&
+                      // staged — rows of 10+ entries in an order modelled at >= 0.65 hits; keep_staged_tables decides on the share, which is
+                      // what the kernel's time follows. (0.75 until the plans with a short life clustered less: the small-world graph
+                      // modelled just below it through such a plan, kept the streaming kernel at N = 32 and ran 150 instead of 124 us —
+                      // profiles/r05/plan_life_compare.log. Tables that are then not kept cost 0.3-0.7 ms.)
+                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && narrow && (f.N == 32 || f.N == 64) && mean >= 10 && hits_after >= 0.65 &&
                        f.nnz >= (1 << 20) && f.variant == GESPMM_VARIANT_AUTO);
     d.build_staged = fits && want && !f.host_analysis;
     // Where the clustered order is modelled to hit L2 (>= 40 % of the gathers) four B rows in flight per lane group beat eight
@@ -218,8 +223,11 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
         //   share 0.93-0.98 geometric x1.35 (N = 32) / x1.35 (64) · 0.85-0.90 small-world x1.23 / x1.45 · 0.65-0.75 products-shaped
         //   communities (mean degree 50) x1.10 / x1.12 · 0.75-0.80 com-Amazon-shaped (mean degree 5.5) x0.91 / x0.84 ·
         //   0.63-0.75 LFR mu = 0.1 (mean degree 16) x0.69 / x0.74 · 0.22 structureless x0.57
-        // — most entries staged, or long rows with two thirds staged
-        return staged_fraction >= 0.85 || (f.mean_ceil() >= 32 && staged_fraction >= 0.62);
+        // — most entries staged, or long rows with two thirds staged. (0.85 until the plans with a short life clustered less: the
+        //   small-world graph through such a plan stages 0.844 / 0.831 of its entries at N = 32 / 64 instead of 0.876 / 0.856, lost its
+        //   tables and ran 153 / 285 us instead of ~125 / ~200 — profiles/r05/plan_life_compare.log. Between LFR's x0.69 at 0.71 and the
+        //   small-world graph's x1.23 at 0.87 the break-even interpolates to ~0.79; tables are only BUILT for rows of 10+ entries.)
+        return staged_fraction >= 0.80 || (f.mean_ceil() >= 32 && staged_fraction >= 0.62);
     }
     return staged_fraction >= (f.N == 128 ? 0.60 : 0.42);  // (128-column tiles : 256-column tiles)
 }

@@ -35,6 +35,8 @@ TABLE = [
     ("C3 products-sbm N=64", (2449029, 123718280, 64, 1446, 0.01, 0.85, 0.651), dict(keep_clustered=1, build_staged=1, keep_staged=1, segmented=0)),
     ("C3 products-sbm N=16: streaming kernels", (2449029, 123718280, 16, 1446, 0.01, 0.85, 0.0), dict(keep_clustered=1, build_staged=0)),
     ("geometric N=32: share 0.93", (600000, 7175884, 32, 30, 0.02, 0.93, 0.931), dict(build_staged=1, keep_staged=1)),
+    ("small-world N=32 through a default-life plan: share 0.844 wins (~125 vs 153 us)", (1000000, 11001376, 32, 18, 0.019, 0.807, 0.844), dict(build_staged=1, keep_staged=1)),
+    ("small-world N=64 through a default-life plan: share 0.831", (1000000, 11001376, 64, 18, 0.011, 0.805, 0.831), dict(build_staged=1, keep_staged=1)),
     ("LFR mu=0.1 N=32: share 0.71 on rows of 16 loses (105 vs 69 us)", (300000, 4717400, 32, 306, 0.144, 0.786, 0.709), dict(build_staged=1, keep_staged=0)),
     ("com-amazon-sbm N=64: short rows stay with the streaming kernels", (334863, 1851744, 64, 120, 0.05, 0.68, 0.0), dict(build_staged=0)),
     ("C3 products-sbm N=512", (2449029, 123718280, 512, 1446, 0.001, 0.833, 0.503), dict(keep_clustered=1, build_staged=1, keep_staged=1, task_entries=102)),
@@ -124,12 +126,16 @@ def test_cost_rule(name, shape, expect):
 
 
 def test_clustering_effort_follows_the_expected_launches():
-    """Plans with a short life cluster three levels deep with three sweeps each (profiles/r05/cluster_sweeps.log: the launch is the same
-    within the noise of a box, the analysis 15-25 % shorter); plans with a long life take the clustering's defaults (six / five)."""
-    short = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42)
-    assert (short["analyse"], short["cluster_levels"], short["cluster_sweeps"]) == (1, 3, 3)
-    long_ = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42, expected_launches=2000)
-    assert (long_["analyse"], long_["cluster_levels"], long_["cluster_sweeps"]) == (1, 0, 0)
+    """Plans with a short life cluster three levels deep with three sweeps each (profiles/r05/cluster_sweeps.log, plan_life_compare.log:
+    the launch is 2-4 % slower, the analysis 3.4 ms shorter); the launches it takes to pay for the depth shrink with the width, so the
+    switch is launches x N >= 100 000; deep plans take the clustering's defaults (six / five)."""
+    def effort(N, launches, **kw):
+        got = _lib.plan_policy(334863, 334863, 1851744, N, 100, wedge_probe=0.42, expected_launches=launches, **kw)
+        return got["analyse"], got["cluster_levels"], got["cluster_sweeps"]
+    assert effort(128, 0) == (1, 3, 3)  # the default: 200 launches
+    assert effort(128, 781) == (1, 3, 3) and effort(128, 782) == (1, 0, 0)
+    assert effort(512, 195) == (1, 3, 3) and effort(512, 200) == (1, 0, 0)
+    assert effort(32, 3000, reorder=_lib.PLAN_REORDER) == (1, 3, 3) and effort(32, 3125) == (1, 0, 0)
     none = _lib.plan_policy(19717, 19717, 108365, 128, 100, wedge_probe=0.11)
     assert (none["analyse"], none["cluster_levels"], none["cluster_sweeps"]) == (0, 0, 0)
 
