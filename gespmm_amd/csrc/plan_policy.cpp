@@ -42,7 +42,7 @@ static bool deep_analysis(const PlanFacts& f);  // (below: how much analysis a p
 //     the share of sampled (row r; two of its columns c1, c2) wedges with c2 in row c1. Structureless graphs close none (1e-4: gains
 //     0.02-0.15), every graph with communities, triangles or geometry closes 6-58 % (gains 0.29-0.90): 0.1 + 0.9 sqrt(probe), capped
 //     at 0.85; unknown (rectangular matrix, host analysis): 0.6 — the benefit of the doubt;
-//   cost of the analysis = a fixed part (launch and synchronisation latency at any size: 3 / 5 ms by the plan's expected life, below)
+//   cost of the analysis = a fixed part (launch and synchronisation latency at any size: 3.3 / 5 ms by the plan's expected life, below)
 //     + 0.55-0.6 ns per entry — device analysis; the host form is ~30x that.
 CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     CostEstimate c;
@@ -60,10 +60,10 @@ CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     c.gain_us = gathered_mb * c.hits_gain * 0.085;
     const double e = (double)f.nnz;
     // (round 5, after the analysis kernels were reworked — profiles/r05/plan_ms_after_kernel_work.log: 3.4 / 5.0 / 5.4 / 7.9 / 73.6 ms at
-    //  1.85 / 4.7 / 7.2 / 11.0 / 124 M entries for plans with a short life (three levels, three sweeps, 1 024 model samples per slice),
+    //  1.85 / 4.7 / 7.2 / 11.0 / 124 M entries for plans with a short life (three levels, 1 024 model samples per slice; +0.5 ms with five sweeps),
     //  6.4 / 7.9 / 78.9 ms at 1.85 / 7.2 / 124 M for the others; the fixed parts carry ~0.6 ms of margin: the gain side of the rule is an
     //  estimate from a probe — Barabasi-Albert: 30 us estimated, 16 measured)
-    c.cost_us = !deep_analysis(f) ? 3000.0 + 0.55e-3 * e : 5000.0 + 0.6e-3 * e;
+    c.cost_us = !deep_analysis(f) ? 3300.0 + 0.55e-3 * e : 5000.0 + 0.6e-3 * e;
     if (f.host_analysis) c.cost_us *= 30.0;
     return c;
 }
@@ -123,10 +123,12 @@ static bool deep_analysis(const PlanFacts& f) {
 int cluster_levels_for(const PlanFacts& f) { return deep_analysis(f) ? 0 : 3; }
 
 int cluster_sweeps_for(const PlanFacts& f) {
-    // label-propagation sweeps per level. Five (the default of cluster_rows) against three, profiles/r05/cluster_sweeps.log: the analysis
-    // of the com-Amazon-shaped graph 5.8 -> 5.0 ms, of the geometric graph 15.9 -> 12.0, of LFR 10.1 -> 8.1, while the launch is the same
-    // within the noise of a box at N = 128 (89.1 / 197.8 / 171.6 us against 90.6 / 196.4 / 174.0). Two sweeps cost the launch 2-4 %.
-    return deep_analysis(f) ? 0 : 3;
+    // label-propagation sweeps per level: five (the default of cluster_rows) or three. With one lane group per degree class the two extra
+    // sweeps cost 0.5-1.5 ms (profiles/r05/levels_vs_sweeps.log, N = 128: com-Amazon-shaped 3.85 -> 4.32 ms, geometric 6.08 -> 6.63,
+    // Holme-Kim 7.13 -> 8.63) and buy 2-5 % of the launch (93.9 -> 89.4 us, 200.9 -> 196.1, 409 -> 391): paid back within ~100 launches
+    // at N = 128 — more than the three extra LEVELS buy on the same graphs. Three sweeps only for plans that will not live that long.
+    const long long launches = f.expected_launches > 0 ? f.expected_launches : kDefaultExpectedLaunches;
+    return launches * (long long)(f.N > 0 ? f.N : 1) >= 12800ll ? 0 : 3;
 }
 
 int model_points_for(const PlanFacts& f) {

@@ -288,7 +288,7 @@ typedef struct gespmm_plan_options {
     int32_t expected_launches; /* products this plan is expected to serve, 0 = 200 (the reference's ITER, spmm_test.cu:714; its GCN runs 200
                               epochs, gcn_custom.py:134). reorder = AUTO weighs the analysis against them: clustering is skipped when the
                               estimated gain per launch x launches does not pay for its estimated time, and plans with launches x N < 100 000
-                              cluster three levels of three sweeps instead of six of five (since 0.3, gespmm_plan_create_v2 only) */
+                              cluster three levels deep instead of six (since 0.3, gespmm_plan_create_v2 only) */
 } gespmm_plan_options;
 /*
  * Plan options and versions. Every field's default is 0 and fields are only ever APPENDED. gespmm_plan_create is the
