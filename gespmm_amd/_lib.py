@@ -116,7 +116,7 @@ class PlanPolicyAnswer(Structure):
                                                                                        ("cost_skipped", c_int32), ("cluster_levels", c_int32),
                                                                                        ("est_gain_us", ctypes.c_double),
                                                                                        ("est_cost_us", ctypes.c_double), ("cluster_sweeps", c_int32),
-                                                                                       ("reserved1", c_int32)]
+                                                                                       ("staged_rows", c_int32)]
 
 
 class Coo(Structure):

@@ -281,7 +281,8 @@ int gespmm_plan_debug_tasks(const gespmm_plan* p, int32_t which, int32_t* out_ho
 static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
     const auto ts = std::chrono::steady_clock::now();
     const int64_t M = p->M, K = p->K, nnz = p->nnz, N = p->N;
-    const gespmm::StagedShape shape = gespmm::staged_shape_any(N);  // (the wide kernel's block shape, or the narrow kernel's at N <= 64)
+    gespmm::StagedShape shape = gespmm::staged_shape_any(N);  // (the wide kernel's block shape, or the narrow kernel's at N <= 64)
+    if (!getenv("GESPMM_STAGED_ROWS")) shape.rows = gespmm::staged_rows_for(p->facts, shape.rows, shape.waves);  // (by mean degree: plan_policy.cpp)
     hipError_t e = hipSuccess;
     const int32_t* rp_s = p->d_rowptr;
     const int32_t* ci_s = p->d_colind;

@@ -234,6 +234,19 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     return staged_fraction >= (f.N == 128 ? 0.60 : 0.42);  // (128-column tiles : 256-column tiles)
 }
 
+// Rows per block of the staged-rows kernel (the kernel does not need the number: blocks are tasks + a staging list; the plan cuts them).
+// The shape's default — as many rows as LDS holds staged rows, 96 / 64 at 128- / 256-column tiles — dates from round 3's walk. With the
+// record stream (profiles/r05/staged_rows_per_block.log, us at 80 / 96 / 112 / 128 rows, N = 128): com-Amazon-shaped (mean degree 5.5)
+// 91.8 / 91.3 / 88.0 / 88.6, LFR mu = 0.1 (16) 177.7 / 176.5 / 170.1 / 168.9, geometric and small-world (11-12) flat, products-shaped
+// (50) 2792 / 2789 / 2880 / 2901; 256-column tiles at 48 / 64 / 80 rows: com-Amazon-shaped 180.8 / 175.3 / 176.5, geometric 341.9 /
+// 335.6 / 341.8, products-shaped 5271 / 5502 / 5600. Short rows want more of them per block, long rows fewer.
+int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves) {
+    if (shape_waves != kStagedMaxWaves || !staged_serves(f.M, f.K, f.N)) return shape_rows;  // (narrow widths, experiment shapes)
+    const int64_t mean = f.mean_ceil();
+    if (f.N == 128) return mean <= 24 ? 112 : shape_rows;
+    return mean > 32 ? 48 : shape_rows;
+}
+
 // Which streaming kernel a clustered plan launches (AUTO rule + the caller's choice).
 //   segmented-stream (one continuous gather stream per lane group): ahead of the batch kernel on clustered matrices with
 //     longer rows at one column tile (products-shaped communities, N = 128: 3.95 vs 4.37 ms; N = 16: 1.06 vs 1.17 ms; N = 32:
@@ -374,6 +387,10 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     a->est_cost_us = ad.cost.cost_us;
     a->cluster_levels = ad.analyse ? gespmm::cluster_levels_for(f) : 0;
     a->cluster_sweeps = ad.analyse ? gespmm::cluster_sweeps_for(f) : 0;
+    {
+        const gespmm::StagedShape sh = gespmm::staged_shape_any(q->N);
+        a->staged_rows = sh.waves ? gespmm::staged_rows_for(f, sh.rows, sh.waves) : 0;
+    }
     std::memcpy(a_out, &aa, (size_t)(a_bytes < (int64_t)sizeof aa ? a_bytes : (int64_t)sizeof aa));
     return 0;
 }

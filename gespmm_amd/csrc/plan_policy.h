@@ -64,7 +64,8 @@ AnalysisDecision decide_analysis(const PlanFacts& f);
 // (profiles/r04/like_regression.log, cluster_levels.log) — a plan that expects fewer than 2000 launches stops at three.
 int cluster_levels_for(const PlanFacts& f);
 int cluster_sweeps_for(const PlanFacts& f);
-int model_points_for(const PlanFacts& f);   // sampled accesses per slice in the L2 model  // 0 = the clustering's own default
+int model_points_for(const PlanFacts& f);
+int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves);  // rows per block of the staged-rows kernel   // sampled accesses per slice in the L2 model  // 0 = the clustering's own default
 
 // ---- after the model: is the clustered order worth its per-launch indirection?
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after);

@@ -413,7 +413,7 @@ typedef struct gespmm_plan_policy_answer {
     double est_gain_us;        /* estimated saving per launch if the clustered order is kept */
     double est_cost_us;        /* estimated time of the analysis */
     int32_t cluster_sweeps;    /* label-propagation sweeps per level (0 = the clustering's own default: five) */
-    int32_t reserved1;
+    int32_t staged_rows;       /* rows per block of the staged-rows tables at this width (0: the width is not served) */
 } gespmm_plan_policy_answer;
 int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);  /* the 0.2 layouts (up to staged_fraction / model_sample) */
 int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q, int64_t q_bytes, gespmm_plan_policy_answer* a, int64_t a_bytes);

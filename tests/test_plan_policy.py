@@ -141,6 +141,16 @@ def test_clustering_effort_follows_the_expected_launches():
     assert (none["analyse"], none["cluster_levels"], none["cluster_sweeps"]) == (0, 0, 0)
 
 
+def test_rows_per_staged_block_follow_the_mean_degree():
+    """profiles/r05/staged_rows_per_block.log: short rows want more rows per block (com-Amazon-shaped 88.0 us at 112 rows against 91.3 at
+    96), long rows fewer (products-shaped at 256 columns: 5.27 ms at 48 rows against 5.50 at 64)."""
+    rows = lambda M, nnz, N: _lib.plan_policy(M, M, nnz, N, 100, hits_after=0.7)["staged_rows"]
+    assert rows(334863, 1851744, 128) == 112 and rows(334863, 1851744, 256) == 64 and rows(334863, 1851744, 512) == 64
+    assert rows(2449029, 123718280, 128) == 96 and rows(2449029, 123718280, 256) == 48
+    assert rows(600000, 7175884, 128) == 112  # (mean degree 12: level between 96 and 112)
+    assert rows(334863, 1851744, 32) == 512 and rows(334863, 1851744, 64) == 256 and rows(334863, 1851744, 48) == 0
+
+
 def test_policy_respects_the_callers_choices():
     base = (334863, 334863, 1851744, 128, 120, 0.018, 0.651, 0.0)
     assert _lib.plan_policy(*base, reorder=_lib.PLAN_NO_REORDER)["analyse"] == 0
