@@ -231,7 +231,9 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
         //   small-world graph's x1.23 at 0.87 the break-even interpolates to ~0.79; tables are only BUILT for rows of 10+ entries.)
         return staged_fraction >= 0.80 || (f.mean_ceil() >= 32 && staged_fraction >= 0.62);
     }
-    return staged_fraction >= (f.N == 128 ? 0.60 : 0.42);  // (128-column tiles : 256-column tiles)
+    // (128-column tiles: 0.60 until the blocks of graphs with short rows grew to 112 rows — LFR mu = 0.1 then stages 0.552 of its entries and
+    //  runs 167 us against 172-178 through the streaming kernels, LFR mu = 0.3 at 0.409 loses 17 %: profiles/r05/kernel_ab_rows_rule.log)
+    return staged_fraction >= (f.N == 128 ? 0.55 : 0.42);  // (128-column tiles : 256-column tiles)
 }
 
 // Rows per block of the staged-rows kernel (the kernel does not need the number: blocks are tasks + a staging list; the plan cuts them).

@@ -41,8 +41,9 @@ TABLE = [
     ("com-amazon-sbm N=64: short rows stay with the streaming kernels", (334863, 1851744, 64, 120, 0.05, 0.68, 0.0), dict(build_staged=0)),
     ("C3 products-sbm N=512", (2449029, 123718280, 512, 1446, 0.001, 0.833, 0.503), dict(keep_clustered=1, build_staged=1, keep_staged=1, task_entries=102)),
     # ---- hold-out graphs (profiles/r04/holdout_audit.log): the rows that moved thresholds in round 4
-    ("LFR mu=0.1 N=128: share 0.565 loses 21 % staged", (300000, 4717400, 128, 306, 0.041, 0.768, 0.565),
-     dict(keep_clustered=1, build_staged=1, keep_staged=0, segmented=0)),
+    ("LFR mu=0.1 N=128: share 0.552 with 112-row blocks wins 3-6 % (round 4's walk lost 21 % at 0.565)", (300000, 4717400, 128, 306, 0.041, 0.768, 0.552),
+     dict(keep_clustered=1, build_staged=1, keep_staged=1, segmented=0)),
+    ("LFR mu=0.3 N=128: share 0.409 loses 17 %", (300000, 4759166, 128, 305, 0.041, 0.534, 0.409), dict(build_staged=1, keep_staged=0)),
     ("LFR mu=0.1 N=256: share 0.44 level (x0.99; x0.93 at 512) without the nt marks", (300000, 4717400, 256, 306, 0.021, 0.763, 0.440), dict(build_staged=1, keep_staged=1)),
     ("LFR mu=0.3 N=256: share 0.33 loses 13 % staged", (300000, 4759166, 256, 305, 0.021, 0.521, 0.332), dict(build_staged=1, keep_staged=0, segmented=1)),
     ("geometric N=128: share 0.94 wins", (600000, 7175884, 128, 30, 0.010, 0.910, 0.937), dict(build_staged=1, keep_staged=1)),
