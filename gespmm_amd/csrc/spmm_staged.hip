@@ -408,7 +408,12 @@ StagedShape staged_shape(int64_t N) {
     StagedShape sh = {0, 0, 0};
     if (!tc) return sh;
     sh.waves = (waves_env == 4 || waves_env == 8 || waves_env == 16) ? waves_env : kStagedMaxWaves;
-    constexpr int lds_kb = 4;  // per wavefront
+    // LDS per wavefront: 5 KB — two 16-wavefront blocks of 80 KB fill the CU's 160 KB exactly, 160 / 80 staged rows per block instead of
+    // 128 / 64 (profiles/r05/staged_lds5.log, 4 -> 5 KB at N = 128 / 256: geometric 202.6 -> 187.6 / 341.6 -> 326.3 us, small-world 350 ->
+    // 329 / 618 -> 559, LFR 170 -> 168 / 338 -> 327, products-shaped 2.81 -> 2.77 / 5.27 -> 5.10 ms, com-Amazon-shaped level). 8 KB — ONE
+    // block per CU — lost 20-40 % (staged_lds_per_wave.log). GESPMM_STAGED_LDS_KB=4 brings the 64 KB blocks back; smaller blocks keep 4.
+    static const int lds_env = getenv("GESPMM_STAGED_LDS_KB") ? atoi(getenv("GESPMM_STAGED_LDS_KB")) : 0;
+    const int lds_kb = (sh.waves == 16 && lds_env != 4) ? 5 : 4;
     sh.rows = (tc == 128 ? 6 : 4) * sh.waves;
     if (rows_env > 0) sh.rows = rows_env;
     sh.slots = sh.waves * lds_kb * 1024 / (tc * 4);
@@ -449,10 +454,11 @@ hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t M, int64_t K, int6
     // (8 KB per wavefront — one 16-wavefront block per CU with twice the staged rows — was built and measured: 20-40 % slower on every
     //  graph, products-shaped 3.92 vs 2.79 ms, geometric 240 vs 193 us: two blocks per CU hide each other's staging round trips, one does
     //  not. profiles/r05/staged_lds_per_wave.log; the kernel stays generic in LK, only 4 is instantiated)
-    if (lds_kb != 4) return hipErrorInvalidValue;
+    if (lds_kb != 4 && !(lds_kb == 5 && a.waves == 16)) return hipErrorInvalidValue;
 #define GESPMM_STAGED_LAUNCH(VEC, U, TS, PG)                                                                                   \
     do {                                                                                                                       \
-        if (a.waves == 16) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 16, 4>), grid, block, 0, st, a);        \
+        if (a.waves == 16 && lds_kb == 5) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 16, 5>), grid, block, 0, st, a);   \
+        else if (a.waves == 16) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 16, 4>), grid, block, 0, st, a);   \
         else if (a.waves == 8) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 8, 4>), grid, block, 0, st, a);          \
         else if (a.waves == 4) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 4, 4>), grid, block, 0, st, a);          \
         else return hipErrorInvalidValue;                                                                                      \
