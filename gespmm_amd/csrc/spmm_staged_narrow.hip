@@ -57,14 +57,14 @@ __device__ __forceinline__ int group_bcast(int v) {
     return __builtin_amdgcn_ds_swizzle(v, (SRC << 5) | kAnd);
 }
 
-template <int W, int WAVES>
+template <int W, int WAVES, int LKB>
 __global__ __launch_bounds__(WAVES * 64, 8) void spmm_staged_narrow_kernel(StagedArgs a) {  // (8 wavefronts per SIMD: <= 64 VGPRs)
     constexpr int G = 64 / W;                        // rows (lane groups) per wavefront step
     constexpr int kRowBytes = W * 16;                // N * 4
     constexpr int kRowShift = (W == 4) ? 6 : (W == 8 ? 7 : 8);
-    constexpr int kLdsBytes = WAVES * kStagedLdsPerWave;
+    constexpr int kLdsBytes = WAVES * LKB * 1024;    // LKB KB of staged B rows per wavefront (5: two 16-wavefront blocks fill the CU's 160 KB)
     constexpr int H = kLdsBytes / kRowBytes;         // staged rows per block
-    constexpr int P = kStagedLdsPerWave / 1024;      // 16-byte pieces of the staging copy per thread
+    constexpr int P = LKB;                           // 16-byte pieces of the staging copy per thread
     constexpr int S = (kNarrowWin + W - 1) / W;      // window registers per lane: record r of a window sits in lane r % W, register r / W
     static_assert(W == 4 || W == 8 || W == 16, "N = 16, 32 or 64");
     static_assert(kStagedPad >= 4 * kNarrowWin, "windows are read whole and three ahead: records past a task's end must be readable");
@@ -226,10 +226,12 @@ StagedShape staged_narrow_shape(int64_t N) {
     if (!W) return sh;
     static const int waves_env = getenv("GESPMM_STAGED_NARROW_WAVES") ? atoi(getenv("GESPMM_STAGED_NARROW_WAVES")) : 0;
     sh.waves = waves_env == 8 ? 8 : kStagedMaxWaves;
-    sh.slots = sh.waves * kStagedLdsPerWave / (W * 16);
+    static const int lds_env = getenv("GESPMM_STAGED_LDS_KB") ? atoi(getenv("GESPMM_STAGED_LDS_KB")) : 0;
+    const int lkb = (sh.waves == kStagedMaxWaves && lds_env != 4) ? 5 : 4;  // (as for the wide kernel: spmm_staged.hip, staged_shape)
+    sh.slots = sh.waves * lkb * 1024 / (W * 16);
     // as many rows per block as staged slots (N = 32: 384 / 512 / 640 / 768 / 1024 rows -> geometric 80.7 / 76.4 / 77.9 / 89.0 / 94.7 us,
     // products-shaped 1214 / 1185 / 1157 / 1188 / 1269; N = 64: 192 / 256 / 384 / 512 -> 127.6 / 124.5 / 132.1 / 139.9 us: profiles/r05/narrow_shapes.log)
-    sh.rows = rows_env > 0 ? rows_env : sh.slots;
+    sh.rows = rows_env > 0 ? rows_env : sh.waves * 4096 / (W * 16);  // (512 / 256 rows at N = 32 / 64: what the sweep above found)
     return sh;
 }
 
@@ -248,17 +250,30 @@ hipError_t launch_spmm_staged_narrow(const StagedArgs& a, int64_t M, int64_t K, 
     if (!staged_narrow_serves(M, K, N) || (a.waves != kStagedMaxWaves && a.waves != 8)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)a.nblocks), block((unsigned)a.waves * 64);
     const int W = narrow_lanes(N);
+    const int lkb = a.slots > 0 ? (int)((int64_t)a.slots * W * 16 / ((int64_t)a.waves * 1024)) : 4;  // what the tables were built for
     if (a.waves == 8) {  // (experiments: half-size blocks, GESPMM_STAGED_NARROW_WAVES=8)
-        if (W == 8) hipLaunchKernelGGL((spmm_staged_narrow_kernel<8, 8>), grid, block, 0, st, a);
-        else if (W == 16) hipLaunchKernelGGL((spmm_staged_narrow_kernel<16, 8>), grid, block, 0, st, a);
+        if (lkb != 4) return hipErrorInvalidValue;
+        if (W == 8) hipLaunchKernelGGL((spmm_staged_narrow_kernel<8, 8, 4>), grid, block, 0, st, a);
+        else if (W == 16) hipLaunchKernelGGL((spmm_staged_narrow_kernel<16, 8, 4>), grid, block, 0, st, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    switch (W) {
-        case 4: hipLaunchKernelGGL((spmm_staged_narrow_kernel<4, kStagedMaxWaves>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((spmm_staged_narrow_kernel<8, kStagedMaxWaves>), grid, block, 0, st, a); break;
-        case 16: hipLaunchKernelGGL((spmm_staged_narrow_kernel<16, kStagedMaxWaves>), grid, block, 0, st, a); break;
-        default: return hipErrorInvalidValue;
+    if (lkb == 5) {
+        switch (W) {
+            case 4: hipLaunchKernelGGL((spmm_staged_narrow_kernel<4, kStagedMaxWaves, 5>), grid, block, 0, st, a); break;
+            case 8: hipLaunchKernelGGL((spmm_staged_narrow_kernel<8, kStagedMaxWaves, 5>), grid, block, 0, st, a); break;
+            case 16: hipLaunchKernelGGL((spmm_staged_narrow_kernel<16, kStagedMaxWaves, 5>), grid, block, 0, st, a); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (lkb == 4) {
+        switch (W) {
+            case 4: hipLaunchKernelGGL((spmm_staged_narrow_kernel<4, kStagedMaxWaves, 4>), grid, block, 0, st, a); break;
+            case 8: hipLaunchKernelGGL((spmm_staged_narrow_kernel<8, kStagedMaxWaves, 4>), grid, block, 0, st, a); break;
+            case 16: hipLaunchKernelGGL((spmm_staged_narrow_kernel<16, kStagedMaxWaves, 4>), grid, block, 0, st, a); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
