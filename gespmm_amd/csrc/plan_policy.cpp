@@ -233,6 +233,10 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     }
     // (128-column tiles: 0.60 until the blocks of graphs with short rows grew to 112 rows — LFR mu = 0.1 then stages 0.552 of its entries and
     //  runs 167 us against 172-178 through the streaming kernels, LFR mu = 0.3 at 0.409 loses 17 %: profiles/r05/kernel_ab_rows_rule.log)
+    // Short rows gain from the record stream itself (no row pointers, no per-row round trips), not only from the rows in LDS: planted
+    // communities of mean degree 4 / 5 / 6 run x1.05 / x1.06 / x1.09 ahead of the streaming kernels at shares of 0.45 / 0.47 / 0.53
+    // (profiles/r05/staged_degree_sweep_retuned.log; mean degree 3: level) where LFR's 16-entry rows lose 17 % at 0.41.
+    if (f.N == 128 && f.mean_ceil() <= 8 && staged_fraction >= 0.42) return true;
     return staged_fraction >= (f.N == 128 ? 0.55 : 0.42);  // (128-column tiles : 256-column tiles)
 }
 

@@ -34,7 +34,7 @@ int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags);
 // mean degree from which AUTO considers the staged-rows kernel at width N (round 5: 5 at every width — with the record-stream walk the
 // kernel is ahead on short rows at 128 columns too: com-Amazon-shaped communities 92.7 vs 107 us, planted communities of mean degree
 // 6 / 8 / 12: x1.06 / x1.14 / x1.19, profiles/r05/staged_degree_sweep.log; until round 4 short rows were level at best and 12 was asked)
-inline int staged_min_mean_degree(int64_t N) { (void)N; return 5; }
+inline int staged_min_mean_degree(int64_t N) { return N == 128 ? 4 : 5; }  // (rounded-up mean degree; staged_degree_sweep_retuned.log)
 
 // ---- before the analysis: launch flags, whether to cluster at all, how to model the L2s
 constexpr int kDefaultExpectedLaunches = 200;  // the reference's protocols: ITER = 200 (spmm_test.cu:714), 200 epochs (gcn_custom.py:134)

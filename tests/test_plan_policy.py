@@ -13,8 +13,11 @@ TABLE = [
     ("C2a com-amazon-sbm N=128", (334863, 1851744, 128, 120, 0.018, 0.651, 0.750),  # round 5: staged-rows on short rows too (92.7 vs 107 us)
      dict(analyse=1, dense_try=0, keep_clustered=1, task_entries=40, group_task_entries=16, build_staged=1, keep_staged=1, shallow_unroll=1,
           segmented=0, launch_flags=STRICT, sddmm_route=2, narrow_vec4=0)),
-    ("planted communities, mean degree 6, N=128: share 0.515 stays with the streaming kernels", (600000, 3600000, 128, 40, 0.01, 0.60, 0.515),
-     dict(keep_clustered=1, build_staged=1, keep_staged=0)),
+    ("planted communities, mean degree 6, N=128: share 0.527 on short rows wins x1.09 (the record stream, not the LDS)", (600000, 3600000, 128, 40, 0.01, 0.60, 0.527),
+     dict(keep_clustered=1, build_staged=1, keep_staged=1)),
+    ("planted communities, mean degree 4, N=128: share 0.448 x1.05", (600000, 2400000, 128, 30, 0.01, 0.55, 0.448), dict(build_staged=1, keep_staged=1)),
+    ("planted communities, mean degree 3, N=128: level, not built", (600000, 1800000, 128, 30, 0.01, 0.55, 0.0), dict(build_staged=0)),
+    ("planted communities, mean degree 4, N=256: level, not built", (600000, 2400000, 256, 30, 0.01, 0.55, 0.0), dict(build_staged=0)),
     ("C2a com-amazon-like N=128", (334863, 1851744, 128, 499, 0.025, 0.176, 0.0),
      dict(analyse=1, keep_clustered=1, task_entries=40, build_staged=0, shallow_unroll=0, segmented=0, sddmm_route=1)),
     ("C2a com-amazon-sbm N=32", (334863, 1851744, 32, 120, 0.09, 0.70, 0.0),
