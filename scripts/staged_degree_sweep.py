@@ -34,6 +34,6 @@ for mean in [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else '
             del plan
         best_stream = min(t["stream"], t["seg-stream"])
         verdict = "" if (took == "staged-rows") == (t["staged"] < best_stream) or abs(t["staged"] / best_stream - 1) < 0.03 else "   <-- AUTO picked the slower one"
-        print("mean degree %2d N=%3d: staged %8.1f us  streaming %8.1f us  x%.2f  staged share %s | AUTO took %s (%.1f us)%s"
-              % (mean, N, t["staged"], best_stream, best_stream / t["staged"], frac, took, t["auto"], verdict), flush=True)
+        print("mean degree %2d N=%3d: staged %8.1f us  streaming %8.1f us (batch %.1f, segmented %.1f)  x%.2f  staged share %s | AUTO took %s (%.1f us)%s"
+              % (mean, N, t["staged"], best_stream, t["stream"], t["seg-stream"], best_stream / t["staged"], frac, took, t["auto"], verdict), flush=True)
     del rp, ci, val
