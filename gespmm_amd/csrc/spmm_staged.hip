@@ -463,7 +463,11 @@ hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t M, int64_t K, int6
         else if (a.waves == 4) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 4, 4>), grid, block, 0, st, a);          \
         else return hipErrorInvalidValue;                                                                                      \
     } while (0)
-    if (tc == 128 && u_env == 16) GESPMM_STAGED_LAUNCH(2, 16, 0, false);
+    // 128 columns: 16 gathers per chunk (57 registers: still eight wavefronts per SIMD). With the retuned blocks, interleaved three times
+    // (profiles/r05/staged_u16_lds5.log, 8 -> 16): products-shaped 2.80 -> 2.69 ms, LFR 169 -> 164 us, com-Amazon-shaped 91.2 -> 89.4,
+    // small-world 336 -> 330, geometric 188 -> 190; with round 5's first blocks it was level (staged_gathers_per_chunk.log). The
+    // 256-column tiles hold four registers per gathered row: 16 rows would not fit 64 registers.
+    if (tc == 128 && u_env != 8) GESPMM_STAGED_LAUNCH(2, 16, 0, false);
     else if (tc == 128) GESPMM_STAGED_LAUNCH(2, 8, 0, false);
     else if (tc == 256 && t == 0) GESPMM_STAGED_LAUNCH(4, 8, 0, false);
     else if (tc == 256 && t == 1 && !paged) GESPMM_STAGED_LAUNCH(4, 8, 1, false);
