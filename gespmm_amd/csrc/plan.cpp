@@ -281,7 +281,7 @@ int gespmm_plan_debug_tasks(const gespmm_plan* p, int32_t which, int32_t* out_ho
 static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
     const auto ts = std::chrono::steady_clock::now();
     const int64_t M = p->M, K = p->K, nnz = p->nnz, N = p->N;
-    gespmm::StagedShape shape = gespmm::staged_shape_any(N);  // (the wide kernel's block shape, or the narrow kernel's at N <= 64)
+    gespmm::StagedShape shape = gespmm::staged_shape_any(N);  // (the block shape of whichever staged kernel serves the width)
     if (!getenv("GESPMM_STAGED_ROWS")) shape.rows = gespmm::staged_rows_for(p->facts, shape.rows, shape.waves);  // (by mean degree: plan_policy.cpp)
     hipError_t e = hipSuccess;
     const int32_t* rp_s = p->d_rowptr;
@@ -682,8 +682,13 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     const int kchoice = use_tuned ? p->tuned_kernel : p->kernel_choice;
     gespmm::PlanFacts facts = p->facts;
     facts.kernel_choice = kchoice;
-    // staged-rows kernel: its tables exist (the plan decided at creation), same width, sum reducer, 16-byte operands
-    const bool staged = p->reordered && p->stg.ev && N == p->N && reduce == gespmm::kReduceSum && variant_v4 &&
+    // staged-rows kernels: the tables exist (the plan decided at creation), same width, 16-byte operands. Which kernel walks them follows
+    // from the width and the reducer (spmm_kernels.h: staged_kernel_class): lane groups at N = 16 / 32 / 64, the tuned shapes at N = 128 and
+    // 256 * 2^t, the general kernel at every other width and for the max reducer (round 6)
+    const int sclass = gespmm::staged_kernel_class(p->M, p->K, N, reduce);
+    const bool shape_ok = sclass != gespmm::kStagedGeneral ||
+                          (p->stg.waves == gespmm::staged_gen_shape(N).waves && p->stg.slots == gespmm::staged_gen_shape(N).slots);
+    const bool staged = p->reordered && p->stg.ev && N == p->N && sclass != gespmm::kStagedNone && shape_ok && variant_v4 &&
                         (use_tuned ? kchoice == GESPMM_PLAN_KERNEL_STAGED
                                    : ((kchoice == GESPMM_PLAN_KERNEL_AUTO && p->staging_kept_by_policy) || kchoice == GESPMM_PLAN_KERNEL_STAGED)) &&
                         (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
@@ -691,9 +696,11 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
-                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, p->stg.slots, 0, nullptr};
-        rc = gespmm::staged_shape(N).waves ? (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream))
-                                           : (int)gespmm::launch_spmm_staged_narrow(sa, p->M, p->K, N, reinterpret_cast<hipStream_t>(stream));
+                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, p->stg.slots, 0, nullptr, 0, 0, 0.0f};
+        hipStream_t hst = reinterpret_cast<hipStream_t>(stream);
+        if (sclass == gespmm::kStagedTuned) rc = (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, hst);
+        else if (sclass == gespmm::kStagedNarrow) rc = (int)gespmm::launch_spmm_staged_narrow(sa, p->M, p->K, N, hst);
+        else rc = (int)gespmm::launch_spmm_staged_gen(sa, p->M, p->K, N, reduce, empty, hst);
         if (rc == 0 && p->stg.nlong > 0) {
             // hub rows (written as empty rows above): one-row tasks through the batch-stream kernel, whose long-row pass splits
             // them — under GESPMM_FLAG_STRICT_ORDER each is one lane group's chain instead, as everywhere else
@@ -802,7 +809,12 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     }
     p->tuned_kernel = cand[best];
     p->tuned_vec = best == 3 ? 1 : 0;
-    if (best != 2 && p->stg.ev && !p->staging_kept_by_policy) gespmm::free_staging(&p->stg);  // not kept for a kernel that lost
+    // tables of a kernel that lost are not kept (~16 bytes per entry): launches at p->N take the winner, other widths never use the
+    // staged-rows kernel, and a later tune rebuilds them (above) if it is asked again
+    if (best != 2 && p->stg.ev) {
+        gespmm::free_staging(&p->stg);
+        p->staging_kept_by_policy = false;
+    }
     if (best != 2) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // (C is the winner's product either way: same bits)
     return rc;
 }

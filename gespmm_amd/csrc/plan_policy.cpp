@@ -188,10 +188,15 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
     // multiply-adds) they win at both widths: com-Amazon-shaped 92.7 vs 107 us (N = 128), 175 vs 216 us (N = 256); mean degree 6 / 8:
     // x1.06 / x1.14 at N = 128 (profiles/r05/staged_degree_sweep.log, kernel_ab_record_stream.log). Device analysis only.
     const bool v4 = f.variant == GESPMM_VARIANT_AUTO || f.variant == GESPMM_VARIANT_CRC_CWM4 || f.variant == GESPMM_VARIANT_CRC_CWM8;
-    const bool fits = f.nnz > 0 && staged_serves_any(f.M, f.K, f.N) && staged_stream_fits(f.M, f.nnz);
-    const bool narrow = !staged_serves(f.M, f.K, f.N);  // N = 16 / 32 / 64: the lane-group form of the kernel (spmm_staged_narrow.hip)
+    const int sclass = staged_kernel_class(f.M, f.K, f.N);
+    const bool fits = f.nnz > 0 && sclass != kStagedNone && staged_stream_fits(f.M, f.nnz);
+    const bool narrow = sclass == kStagedNarrow;  // N = 16 / 32 / 64: the lane-group form of the kernel (spmm_staged_narrow.hip)
+    // the wide kernels AUTO considers: the tuned widths, and (round 6, spmm_staged_gen.hip) every even width beyond 64 columns — two or four
+    // floats per lane, i.e. 128- or 256-column tiles, judged by the thresholds of that tile class; odd widths (one float per lane, two
+    // gather instructions per 128 columns) and widths up to 64 other than 32 / 64 are served on request only
+    const bool wide_auto = sclass == kStagedTuned || (sclass == kStagedGeneral && f.N > 64 && f.N % 2 == 0);
     const bool want = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED ||
-                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && !narrow && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
+                      (f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && wide_auto && mean >= staged_min_mean_degree(f.N) && hits_after >= 0.40 &&
                        f.nnz >= (1 << 20) && v4) ||
                       // the lane-group form at N = 32 / 64 (spmm_staged_narrow.hip): worth its tables where most of the entries will be
                       // staged — rows of 10+ entries in an order modelled at >= 0.65 hits; keep_staged_tables decides on the share, which is
@@ -220,6 +225,7 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     //                      (without the `nt` marks of round 3, which cost this tile width 4-9 %: holdout_audit.log after far_marks_by_graph.log)
     // (round 3 asked for 0.40 at both widths: fitted on the planted-community generator alone, 20-41 % behind on the LFR graphs)
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return true;
+    const bool tile128 = staged_tile_class(f.N) <= 128;  // (two floats per lane: N = 128 and the even widths the general kernel walks that way)
     if (f.N <= 64) {
         // Narrow widths (round 5, profiles/r05/kernel_ab_narrow.log; time of the best streaming kernel / lane-group staged kernel):
         //   share 0.93-0.98 geometric x1.35 (N = 32) / x1.35 (64) · 0.85-0.90 small-world x1.23 / x1.45 · 0.65-0.75 products-shaped
@@ -236,8 +242,8 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     // Short rows gain from the record stream itself (no row pointers, no per-row round trips), not only from the rows in LDS: planted
     // communities of mean degree 4 / 5 / 6 run x1.05 / x1.06 / x1.09 ahead of the streaming kernels at shares of 0.45 / 0.47 / 0.53
     // (profiles/r05/staged_degree_sweep_retuned.log; mean degree 3: level) where LFR's 16-entry rows lose 17 % at 0.41.
-    if (f.N == 128 && f.mean_ceil() <= 8 && staged_fraction >= 0.42) return true;
-    return staged_fraction >= (f.N == 128 ? 0.55 : 0.42);  // (128-column tiles : 256-column tiles)
+    if (tile128 && f.mean_ceil() <= 8 && staged_fraction >= 0.42) return true;
+    return staged_fraction >= (tile128 ? 0.55 : 0.42);  // (128-column tiles : 256-column tiles)
 }
 
 // Rows per block of the staged-rows kernel (the kernel does not need the number: blocks are tasks + a staging list; the plan cuts them).
@@ -247,10 +253,13 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
 // (50) 2792 / 2789 / 2880 / 2901; 256-column tiles at 48 / 64 / 80 rows: com-Amazon-shaped 180.8 / 175.3 / 176.5, geometric 341.9 /
 // 335.6 / 341.8, products-shaped 5271 / 5502 / 5600. Short rows want more of them per block, long rows fewer.
 int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves) {
-    if (shape_waves != kStagedMaxWaves || !staged_serves(f.M, f.K, f.N)) return shape_rows;  // (narrow widths, experiment shapes)
+    const int sclass = staged_kernel_class(f.M, f.K, f.N);
+    if (shape_waves != kStagedMaxWaves || (sclass != kStagedTuned && sclass != kStagedGeneral)) return shape_rows;  // (narrow widths, experiment shapes)
     const int64_t mean = f.mean_ceil();
-    if (f.N == 128) return mean <= 24 ? 112 : shape_rows;
-    return mean > 32 ? 48 : shape_rows;
+    const int tc = staged_tile_class(f.N);
+    if (tc == 128) return mean <= 24 ? 112 : shape_rows;
+    if (tc == 256) return mean > 32 ? 48 : shape_rows;
+    return shape_rows;  // (64-column tiles: the general kernel's default)
 }
 
 // Which streaming kernel a clustered plan launches (AUTO rule + the caller's choice).

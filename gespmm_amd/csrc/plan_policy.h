@@ -6,6 +6,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "spmm_kernels.h"
+
 namespace gespmm {
 
 // What is known before / after the analysis passes.
@@ -31,10 +33,11 @@ struct PlanFacts {
 
 // user flags + the long-row decision from the longest row (SPLIT_LONG_ROWS or STRICT_ORDER is always set on return)
 int long_row_flags(int64_t M, int64_t nnz, int32_t max_degree, int user_flags);
-// mean degree from which AUTO considers the staged-rows kernel at width N (round 5: 5 at every width — with the record-stream walk the
-// kernel is ahead on short rows at 128 columns too: com-Amazon-shaped communities 92.7 vs 107 us, planted communities of mean degree
-// 6 / 8 / 12: x1.06 / x1.14 / x1.19, profiles/r05/staged_degree_sweep.log; until round 4 short rows were level at best and 12 was asked)
-inline int staged_min_mean_degree(int64_t N) { return N == 128 ? 4 : 5; }  // (rounded-up mean degree; staged_degree_sweep_retuned.log)
+// rounded-up mean degree from which AUTO considers the staged-rows kernel at width N (round 5: 4 at 128 columns, 5 elsewhere — with the
+// record-stream walk the kernel is ahead on short rows at 128 columns too: com-Amazon-shaped communities 92.7 vs 107 us, planted
+// communities of mean degree 4 / 5 / 6 / 8 / 12: x1.05 / x1.06 / x1.09 / x1.14 / x1.19, profiles/r05/staged_degree_sweep{,_retuned}.log;
+// until round 4 short rows were level at best and 12 was asked)
+inline int staged_min_mean_degree(int64_t N) { return staged_tile_class(N) <= 128 ? 4 : 5; }  // (rounded-up mean degree; staged_degree_sweep_retuned.log)
 
 // ---- before the analysis: launch flags, whether to cluster at all, how to model the L2s
 constexpr int kDefaultExpectedLaunches = 200;  // the reference's protocols: ITER = 200 (spmm_test.cu:714), 200 epochs (gcn_custom.py:134)
@@ -63,9 +66,9 @@ AnalysisDecision decide_analysis(const PlanFacts& f);
 // com-Amazon-sized graph; they are worth 4.5 % per launch on the structureless stand-in and nothing on graphs with communities
 // (profiles/r04/like_regression.log, cluster_levels.log) — a plan that expects fewer than 2000 launches stops at three.
 int cluster_levels_for(const PlanFacts& f);
-int cluster_sweeps_for(const PlanFacts& f);
-int model_points_for(const PlanFacts& f);
-int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves);  // rows per block of the staged-rows kernel   // sampled accesses per slice in the L2 model  // 0 = the clustering's own default
+int cluster_sweeps_for(const PlanFacts& f);  // label-propagation sweeps per level (0 = the clustering's own default)
+int model_points_for(const PlanFacts& f);    // sampled accesses per slice in the L2 model
+int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves);  // rows per block of the staged-rows kernel
 
 // ---- after the model: is the clustered order worth its per-launch indirection?
 bool keep_clustered_order(const PlanFacts& f, const AnalysisDecision& a, double hits_before, double hits_after);

@@ -130,6 +130,10 @@ struct StagedArgs {
     int32_t debug;            // experiments only (GESPMM_STAGED_DEBUG): 1 = skip the staging copy, 2 = every gather from LDS — WRONG results;
                               // 4 = phase clocks summed into dbg_clk
     unsigned long long* dbg_clk;
+    // spmm_staged_gen.hip (filled in by its launcher): width, column tiles of 64 * VEC columns, value of rows without entries (max reducer)
+    int32_t n;
+    int32_t ntiles;
+    float empty;
 };
 // Shape of a block at width N: `waves` wavefronts (0 = width not served) own `rows` consecutive rows of the clustered matrix and
 // stage up to `slots` B rows (waves x 4 KB of LDS). GESPMM_STAGED_WAVES / GESPMM_STAGED_ROWS override it for experiments.
@@ -147,17 +151,39 @@ StagedShape staged_narrow_shape(int64_t N);  // waves = 0: width not served
 int staged_narrow_groups(int64_t N);         // lane groups (tasks) per wavefront
 bool staged_narrow_serves(int64_t M, int64_t K, int64_t N);
 hipError_t launch_spmm_staged_narrow(const StagedArgs& a, int64_t M, int64_t K, int64_t N, hipStream_t st);
-// either kernel: the block shape of width N (waves = 0: neither serves it) and the tasks per block
+// spmm_staged_gen.hip — the same kernel for ANY width and for the max reducer (round 6): VEC = staged_gen_vec(N) floats per lane, column
+// tiles of 64 * VEC columns, lanes past N masked at the row-end store, row strides by a scalar multiply. Tables: 16 tasks per block,
+// 80 KB / (256 * VEC) slots (for N = 128 and 256 * 2^t the shapes of spmm_staged.hip: one set of tables serves its sum kernel and this
+// file's max kernel).
+int staged_gen_vec(int64_t N);  // 1, 2 or 4 (0: N < 1)
+StagedShape staged_gen_shape(int64_t N);
+bool staged_gen_serves(int64_t M, int64_t K, int64_t N);
+hipError_t launch_spmm_staged_gen(const StagedArgs& a, int64_t M, int64_t K, int64_t N, int reduce, float empty, hipStream_t st);
+// Which of the three kernels walks a plan's tables at width N: 1 = lane groups (N = 16 / 32 / 64, sum), 2 = spmm_staged.hip's tuned shapes
+// (N = 128, 256 * 2^t, sum), 3 = the general kernel (every other width; the max reducer at every width but 16 / 32 / 64), 0 = none.
+enum { kStagedNone = 0, kStagedNarrow = 1, kStagedTuned = 2, kStagedGeneral = 3 };
+inline int staged_kernel_class(int64_t M, int64_t K, int64_t N, int reduce = kReduceSum) {
+    if (staged_narrow_shape(N).waves) return (reduce == kReduceSum && staged_narrow_serves(M, K, N)) ? kStagedNarrow : kStagedNone;
+    if (reduce == kReduceSum && staged_serves(M, K, N)) return kStagedTuned;
+    return staged_gen_serves(M, K, N) ? kStagedGeneral : kStagedNone;
+}
+// Columns of one tile of the wide kernels at width N (128 / 256: the tile classes the policy's thresholds are measured for; 64: odd widths)
+inline int staged_tile_class(int64_t N) { return 64 * staged_gen_vec(N); }
+// any kernel: the block shape of width N (waves = 0: none serves it) and the tasks per block
 inline StagedShape staged_shape_any(int64_t N) {
     const StagedShape w = staged_shape(N);
-    return w.waves ? w : staged_narrow_shape(N);
+    if (w.waves) return w;
+    const StagedShape nw = staged_narrow_shape(N);
+    return nw.waves ? nw : staged_gen_shape(N);
 }
 inline int staged_tasks_per_block(int64_t N) {
     const StagedShape w = staged_shape(N);
     if (w.waves) return w.waves;
-    return staged_narrow_shape(N).waves * staged_narrow_groups(N);
+    const StagedShape nw = staged_narrow_shape(N);
+    if (nw.waves) return nw.waves * staged_narrow_groups(N);
+    return staged_gen_shape(N).waves;
 }
-inline bool staged_serves_any(int64_t M, int64_t K, int64_t N) { return staged_serves(M, K, N) || staged_narrow_serves(M, K, N); }
+inline bool staged_serves_any(int64_t M, int64_t K, int64_t N) { return staged_kernel_class(M, K, N) != kStagedNone; }
 
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form
@@ -171,9 +197,6 @@ hipError_t launch_slabplan(const int32_t* rowptr, const int32_t* colind, int32_t
 // baseline_kernels.hip — Gunrock-style edge-parallel atomicAdd scatter (comparison column only)
 hipError_t launch_atomic_scatter(const int32_t* rowptr, const int32_t* colind, const float* in, float* out, int64_t M,
                                  int64_t K, int64_t N, int64_t nnz, hipStream_t st);
-
-// ... and a plain streaming copy dst[i] = src[i] (the read + write rate of the box: bench.py's yardstick for ceiling_frac)
-hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st);
 
 // ... and a plain streaming copy dst[i] = src[i] (the read + write rate of the box: bench.py's yardstick for ceiling_frac)
 hipError_t launch_copy(const float* src, float* dst, int64_t n, hipStream_t st);

@@ -48,10 +48,9 @@
 #include "spmm_device.h"
 #include "spmm_kernels.h"
 
-#if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__) || defined(__gfx942__)
-// (the inline assembly below spells its memory instructions — sc1 / nt modifiers, SGPR-base global loads — for gfx942 / gfx950)
-#else
-#error "spmm_staged.hip is written for gfx950 (gfx942 ISA compatible): its inline assembly does not assemble elsewhere"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+// (80 KB of static LDS per workgroup — gfx942 stops at 64 KB — and inline assembly that spells sc1 / nt modifiers and SGPR-base global loads)
+#error "spmm_staged.hip is written for gfx950: its LDS shapes and inline assembly do not build elsewhere"
 #endif
 
 // Experiments only: -DGESPMM_STAGED_INSTRUMENT=1 compiles the GESPMM_STAGED_DEBUG knobs in (1 = no staging copy, 2 = every gather from

@@ -26,9 +26,8 @@
 #include "spmm_device.h"
 #include "spmm_kernels.h"
 
-#if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__) || defined(__gfx942__)
-#else
-#error "spmm_staged_narrow.hip is written for gfx950 (gfx942 ISA compatible): its inline assembly does not assemble elsewhere"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "spmm_staged_narrow.hip is written for gfx950: 80 KB of LDS per workgroup and its inline assembly do not build elsewhere"
 #endif
 
 namespace gespmm {
@@ -160,12 +159,14 @@ __global__ __launch_bounds__(WAVES * 64, 8) void spmm_staged_narrow_kernel(Stage
                 "s_mov_b64 exec, -1"
                 : "=&v"(bj)
                 : "v"(off), "s"(mm), "s"(bp)
-                : "memory");
+                : "memory", "scc");  // (s_andn2 writes SCC; both blocks rewrite EXEC and rely on EXEC == -1 on entry: the walk has no divergent region)
             b[j] = bj;
         });
         // the window three ahead, requested AFTER this chunk's gathers: `vmcnt(S)` then waits for the gathers (and for everything older —
         // the window requested one chunk ago, which had that chunk's whole round trip to arrive) and leaves the new request in flight
-        load_window(pos + 3 * kNarrowWin, req);
+        // (a group that is done keeps stepping with its wavefront: its requests are clamped to its own end — whole windows behind `ge` are
+        //  inside the stream's padding, positions a task's length further on are not)
+        load_window(pos + 3 * kNarrowWin < ge ? pos + 3 * kNarrowWin : ge, req);
         if constexpr (S == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void spmm_staged_narrow_kernel(Stage
                 : [a4] "+{v[60:63]}"(acc), [t] "=&v"(t32)
                 : [fm] "s"(fm[j]), [em] "s"(em[j]), [v] "v"(vb[j]), [b0] "v"(b[j][0]), [b1] "v"(b[j][1]), [b2] "v"(b[j][2]), [b3] "v"(b[j][3]),
                   [sh] "n"(kRowShift), [lo] "v"(loff), [C] "s"(Cp)
-                : "memory");
+                : "memory", "scc");
         }
         pos += kNarrowWin;  // (every group steps; a finished one stays finished)
     };

@@ -152,7 +152,26 @@ def test_rows_per_staged_block_follow_the_mean_degree():
     assert rows(334863, 1851744, 128) == 112 and rows(334863, 1851744, 256) == 64 and rows(334863, 1851744, 512) == 64
     assert rows(2449029, 123718280, 128) == 96 and rows(2449029, 123718280, 256) == 48
     assert rows(600000, 7175884, 128) == 112  # (mean degree 12: level between 96 and 112)
-    assert rows(334863, 1851744, 32) == 512 and rows(334863, 1851744, 64) == 256 and rows(334863, 1851744, 48) == 0
+    assert rows(334863, 1851744, 32) == 512 and rows(334863, 1851744, 64) == 256
+    # round 6: every other width has the general kernel's blocks — the rules of its tile class (two floats per lane: 128-column tiles,
+    # four: 256-column tiles), 192 rows where a lane holds one float (odd widths, widths up to 64)
+    assert rows(334863, 1851744, 100) == 112 and rows(2449029, 123718280, 100) == 96
+    assert rows(334863, 1851744, 200) == 64 and rows(2449029, 123718280, 200) == 48 and rows(334863, 1851744, 602) == 112
+    assert rows(334863, 1851744, 48) == 192 and rows(334863, 1851744, 41) == 192
+
+
+def test_auto_considers_the_staged_kernel_at_even_widths_beyond_64():
+    """Round 6 (csrc/spmm_staged_gen.hip): AUTO builds staged tables at N = 100 / 200 / 602 under the rules of N = 128 / 256, not at odd
+    widths or below 65 columns (those are served on request: kernel = staged)."""
+    q = lambda N, **kw: _lib.plan_policy(334863, 334863, 1851744, N, 120, 0.018, 0.651, 0.75, **kw)
+    for N in (100, 128, 200, 256, 602):
+        assert q(N)["build_staged"] == 1 and q(N)["keep_staged"] == 1, N
+    for N in (41, 47, 65, 129, 48, 20):
+        assert q(N)["build_staged"] == 0, N
+        assert q(N, kernel=_lib.PLAN_KERNEL_STAGED, reorder=_lib.PLAN_REORDER)["build_staged"] == 1, N
+    # the share thresholds of the tile class: 0.55 (0.42 on short rows) at two floats per lane, 0.42 at four
+    lfr = lambda N, share: _lib.plan_policy(500000, 500000, 8000000, N, 300, 0.02, 0.6, share)["keep_staged"]
+    assert lfr(100, 0.50) == 0 and lfr(100, 0.56) == 1 and lfr(200, 0.43) == 1 and lfr(200, 0.40) == 0
 
 
 def test_policy_respects_the_callers_choices():
