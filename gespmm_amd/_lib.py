@@ -78,6 +78,10 @@ EXPORTS = [
     "gespmm_device_l2_model",
     "gespmm_plan_debug_tasks",
     "gespmm_release_cached_memory",
+    "gespmm_init",
+    "gespmm_set_auto_plan",
+    "gespmm_auto_plan_clear",
+    "gespmm_auto_plan_get_stats",
 ]
 
 PLAN_REORDER_AUTO = 0
@@ -106,7 +110,7 @@ class PlanPolicyQuery(Structure):
                 ("max_degree", c_int32), ("reorder", c_int32), ("kernel", c_int32), ("analysis", c_int32), ("flags", c_int32),
                 ("task_entries", c_int32), ("row_floor", c_int32), ("hits_before", ctypes.c_double),
                 ("hits_after", ctypes.c_double), ("staged_fraction", ctypes.c_double), ("expected_launches", c_int32),
-                ("reserved0", c_int32), ("wedge_probe", ctypes.c_double)]
+                ("cold_start", c_int32), ("wedge_probe", ctypes.c_double)]
 
 
 class PlanPolicyAnswer(Structure):
@@ -117,6 +121,10 @@ class PlanPolicyAnswer(Structure):
                                                                                        ("est_gain_us", ctypes.c_double),
                                                                                        ("est_cost_us", ctypes.c_double), ("cluster_sweeps", c_int32),
                                                                                        ("staged_rows", c_int32)]
+
+
+class AutoPlanStats(Structure):
+    _fields_ = [(n, c_int64) for n in ("calls_planned", "plans_created", "invalidated", "values_refreshed", "fingerprints", "cached_plans")]
 
 
 class Coo(Structure):
@@ -224,6 +232,14 @@ def _load():
     lib.gespmm_simulate_l2_hits.argtypes = [p, p, c_int64, c_int64, p, c_int32, c_int64]
     lib.gespmm_row_partition.restype = c_int
     lib.gespmm_row_partition.argtypes = [p, c_int64, c_int32, p]
+    lib.gespmm_init.restype = c_int
+    lib.gespmm_init.argtypes = [c_int64, c_int64, p]
+    lib.gespmm_set_auto_plan.restype = c_int
+    lib.gespmm_set_auto_plan.argtypes = [c_int32]
+    lib.gespmm_auto_plan_clear.restype = None
+    lib.gespmm_auto_plan_clear.argtypes = []
+    lib.gespmm_auto_plan_get_stats.restype = c_int
+    lib.gespmm_auto_plan_get_stats.argtypes = [POINTER(AutoPlanStats)]
     return lib
 
 
@@ -238,16 +254,49 @@ class GespmmError(RuntimeError):
 
 def plan_policy(M, K, nnz, N, max_degree, hits_before=0.0, hits_after=0.0, staged_fraction=0.0, N_launch=0, variant=VARIANT_AUTO,
                 reorder=PLAN_REORDER_AUTO, kernel=PLAN_KERNEL_AUTO, analysis=PLAN_ANALYSIS_DEVICE, flags=0, task_entries=0,
-                row_floor=0, expected_launches=0, wedge_probe=-1.0):
+                row_floor=0, expected_launches=0, wedge_probe=-1.0, cold_start=0):
     """What a plan would decide for a matrix of this shape (gespmm_plan_policy_v2: host only, no device) — a dict.
     `wedge_probe` is the plan's structure probe (share of sampled wedges that close; negative = unknown), `expected_launches` the
     number of products the analysis has to pay for itself in (0 = 200)."""
     q = PlanPolicyQuery(int(M), int(K), int(nnz), int(N), int(N_launch), int(variant), int(max_degree), int(reorder), int(kernel),
                         int(analysis), int(flags), int(task_entries), int(row_floor), float(hits_before), float(hits_after),
-                        float(staged_fraction), int(expected_launches), 0, float(wedge_probe))
+                        float(staged_fraction), int(expected_launches), int(cold_start), float(wedge_probe))
     a = PlanPolicyAnswer()
     check(lib.gespmm_plan_policy_v2(ctypes.byref(q), ctypes.sizeof(q), ctypes.byref(a), ctypes.sizeof(a)), "gespmm_plan_policy_v2")
     return {n: getattr(a, n) for n, _ in PlanPolicyAnswer._fields_ if not n.startswith("reserved")}
+
+
+def init(rows_hint=0, nnz_hint=0, stream=None):
+    """gespmm_init: load the analysis kernels and make the analysis arena NOW (the first plan of a process otherwise pays ~29 ms for
+    both), optionally sized for a matrix of (rows_hint, nnz_hint). Needs a HIP device; idempotent per device."""
+    check(lib.gespmm_init(int(rows_hint), int(nnz_hint), stream), "gespmm_init")
+
+
+_initialised = set()
+
+
+def ensure_init(device_index, stream=None):
+    """gespmm_init once per process and device: the Python layer never builds a plan cold (the ~29 ms of kernel loading and arena
+    allocation belong to start-up, not to the first plan's analysis time — and not to its cost rule)."""
+    if device_index not in _initialised:
+        init(0, 0, stream)
+        _initialised.add(device_index)
+
+
+def set_auto_plan(kth_call):
+    """gespmm_set_auto_plan: from the k-th identical stateless call on (gespmm_csr_spmm_f32 / _max / gespmm_dgl_csrmm_*), run through a
+    plan the library keeps (0 = off, the default). Every planned call fingerprints the CSR arrays first (one stream synchronisation)."""
+    check(lib.gespmm_set_auto_plan(int(kth_call)), "gespmm_set_auto_plan")
+
+
+def auto_plan_stats():
+    st = AutoPlanStats()
+    check(lib.gespmm_auto_plan_get_stats(ctypes.byref(st)), "gespmm_auto_plan_get_stats")
+    return {n: getattr(st, n) for n, _ in AutoPlanStats._fields_}
+
+
+def auto_plan_clear():
+    lib.gespmm_auto_plan_clear()
 
 
 def release_cached_memory():

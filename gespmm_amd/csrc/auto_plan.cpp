@@ -1,0 +1,352 @@
+// auto_plan.cpp — opt-in plan reuse behind the STATELESS boundaries, and the library's warm-up (round 6).
+//
+// The reference's callers keep no state across products: spmmWrapper (spmm_test.cu:456-492), spmm_cuda (spmm_kernel.cu:425-458) and the
+// DGL patch's CustomCsrmm (dgl-custom/binary_reduce_sum.cu:338-360) take the CSR arrays and launch. A caller shaped like that cannot
+// hold a gespmm_plan, so on a graph with structure it stays at the plain kernels' rate (0.30 of the roofline on the headline graph
+// against 0.50 through a plan). gespmm_set_auto_plan(k) lets the library keep the plan instead:
+//
+//   * a small cache keyed on what the caller passes — device, the rowptr / colind pointers, M, K, N, valued?, variant, reducer;
+//   * pointer identity is not pattern identity, so every call that would use a cached plan first runs a FINGERPRINT of the arrays on
+//     the device (one kernel: position-mixed 64-bit sums over ALL of rowptr and colind, separately over the values; rowptr[M]; the
+//     largest column) and reads 32 bytes back — one stream synchronisation, which the DGL entry points perform anyway to learn nnz.
+//     A pattern that changed in place drops the plan (the call runs the plain kernels, the count starts again); values that changed
+//     are re-permuted (gespmm_plan_set_values) before the launch;
+//   * the plan is made at the k-th call with the same key (k >= 1), synchronously (3-4 ms on a com-Amazon-sized graph after
+//     gespmm_init, section "cold plans" of DESIGN.md); earlier calls run the plain kernels;
+//   * never on a capturing stream (no synchronisation there), never when the switch is off (the default: one relaxed atomic load on
+//     the plain path, nothing else).
+//
+// A plan changes the ORDER rows are processed in, not the sums: the bits are the plain call's (tests/test_gpu_auto_plan.py).
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/gespmm.h"
+#include "auto_plan.h"
+#include "plan.h"
+#include "spmm_kernels.h"
+
+namespace gespmm {
+
+namespace {
+
+constexpr int kAutoEntries = 8;
+constexpr int kAutoDevices = 16;
+
+struct AutoEntry {
+    bool used = false;
+    int device = 0;
+    const int32_t* rowptr = nullptr;
+    const int32_t* colind = nullptr;
+    int64_t M = 0, K = 0, N = 0;
+    bool valued = false;
+    int variant = 0, reduce = 0;
+    int count = 0;  // calls seen with this key since the entry was (re)started
+    gespmm_plan* plan = nullptr;
+    bool no_gain = false;  // the analysis kept the storage order (or was not worth its cost): the plain path is the plan's own launch
+    const float* val_seen = nullptr;  // the values the plan was last given (pointer; their content is fingerprinted)
+    unsigned long long fp_pattern = 0, fp_values = 0;
+    int64_t nnz = 0;
+    unsigned long long stamp = 0;  // last use (LRU)
+};
+
+std::atomic<int> g_auto_k{0};
+std::mutex g_lock;
+AutoEntry g_entries[kAutoEntries];
+unsigned long long g_clock = 0;
+gespmm_auto_plan_stats g_stats = {0, 0, 0, 0, 0, 0};
+
+struct FpScratch {
+    unsigned long long* dev = nullptr;   // [4] accumulators on the device
+    unsigned long long* host = nullptr;  // [4] pinned
+};
+FpScratch g_fp[kAutoDevices];
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // splitmix64 finaliser
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+// out[0] += sum over rowptr and colind of mix(position-tagged word), out[1] += the same over the value bits, out[2] = rowptr[M],
+// out[3] = largest column index + 1. Sums of mixed terms: independent of the order the workgroups run in.
+__global__ void __launch_bounds__(256) k_fingerprint(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                     const float* __restrict__ val, long long M, unsigned long long* __restrict__ out) {
+    const long long nnz = rowptr[M];
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    unsigned long long hp = 0, hv = 0;
+    unsigned int mx = 0;
+    for (long long i = tid; i <= M; i += stride) hp += mix64(((unsigned long long)i << 32) ^ (unsigned int)rowptr[i] ^ (0xa5ull << 56));  // (tagged: a row pointer is not a column)
+    for (long long i = tid; i < nnz; i += stride) {
+        const unsigned int c = (unsigned int)colind[i];
+        hp += mix64(((unsigned long long)i << 32) ^ c);
+        mx = c + 1u > mx ? c + 1u : mx;
+        if (val) hv += mix64(((unsigned long long)i << 32) ^ __float_as_uint(val[i]));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        hp += __shfl_down(hp, o);
+        hv += __shfl_down(hv, o);
+        const unsigned int m2 = __shfl_down(mx, o);
+        mx = m2 > mx ? m2 : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], hp);
+        if (val) atomicAdd(&out[1], hv);
+        atomicMax(&out[3], (unsigned long long)mx);
+        if (tid == 0) out[2] = (unsigned long long)nnz;
+    }
+}
+
+// Fingerprint of the caller's arrays on `st`, read back (ONE synchronisation). fp = {pattern, values, nnz, columns}.
+hipError_t fingerprint(int dev, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M, hipStream_t st,
+                       unsigned long long fp[4]) {
+    if (dev < 0 || dev >= kAutoDevices) return hipErrorInvalidDevice;
+    FpScratch& s = g_fp[dev];
+    if (!s.dev) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.dev), 32);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.host), 32, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMemsetAsync(s.dev, 0, 32, st);
+    if (e != hipSuccess) return e;
+    // enough wavefronts to stream the arrays at the memory system's rate, few enough that the atomics do not show
+    long long blocks = (M + 256) / 256;
+    if (blocks < 256) blocks = 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fingerprint, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, colind, val, (long long)M, s.dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(s.host, s.dev, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) std::memcpy(fp, s.host, 32);
+    return e;
+}
+
+void drop_plan(AutoEntry& en) {
+    if (en.plan) gespmm_plan_destroy(en.plan);
+    en.plan = nullptr;
+}
+
+}  // namespace
+
+bool auto_plan_enabled() { return g_auto_k.load(std::memory_order_relaxed) > 0; }
+
+// Returns true when the call was served (then *rc is its result); false = the caller runs the plain path.
+bool auto_plan_try(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M, int64_t K,
+                   int64_t N, int64_t nnz_arg, int variant, int reduce, float empty, void* stream, int* rc) {
+    const int k = g_auto_k.load(std::memory_order_relaxed);
+    if (k <= 0 || M <= 0 || N <= 0 || !rowptr || !colind || !B || !C) return false;
+    if (reduce == kReduceMax && val) return false;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;  // no synchronisation on a capturing stream: stateless
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+
+    std::lock_guard<std::mutex> guard(g_lock);
+    AutoEntry* en = nullptr;
+    AutoEntry* victim = &g_entries[0];
+    for (AutoEntry& e : g_entries) {
+        if (e.used && e.device == dev && e.rowptr == rowptr && e.colind == colind && e.M == M && e.K == K && e.N == N &&
+            e.valued == (val != nullptr) && e.variant == variant && e.reduce == reduce) {
+            en = &e;
+            break;
+        }
+        if (!e.used || (victim->used && e.stamp < victim->stamp)) victim = &e;
+    }
+    if (!en) {
+        // a new key: remember it (the least recently used entry goes) and run the plain kernels
+        drop_plan(*victim);
+        *victim = AutoEntry();
+        victim->used = true;
+        victim->device = dev;
+        victim->rowptr = rowptr;
+        victim->colind = colind;
+        victim->M = M;
+        victim->K = K;
+        victim->N = N;
+        victim->valued = val != nullptr;
+        victim->variant = variant;
+        victim->reduce = reduce;
+        en = victim;
+    }
+    en->stamp = ++g_clock;
+    en->count += 1;
+    if (en->no_gain || (!en->plan && en->count < k)) return false;
+
+    unsigned long long fp[4] = {0, 0, 0, 0};
+    hipError_t e = fingerprint(dev, rowptr, colind, val, M, st, fp);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_stats.fingerprints += 1;
+    const int64_t nnz = (int64_t)fp[2];
+    if (nnz_arg >= 0 && nnz_arg != nnz) {  // the caller's nnz contradicts rowptr[M]: let the plain path report what it reports
+        drop_plan(*en);
+        en->count = 0;
+        return false;
+    }
+    if (en->plan && (fp[0] != en->fp_pattern || nnz != en->nnz)) {
+        // the pattern changed under the same pointers: the plan is void
+        drop_plan(*en);
+        en->count = 1;
+        g_stats.invalidated += 1;
+        if (en->count < k) return false;
+    }
+    if (!en->plan) {
+        // columns: the caller's K where it is a real bound, else what the arrays hold (the DGL entry points do not know K)
+        int64_t Kp = K;
+        if (Kp <= 0 || Kp >= 0x7fffffffLL) Kp = (int64_t)fp[3] > M ? (int64_t)fp[3] : M;
+        else if ((int64_t)fp[3] > Kp) return false;  // a column outside [0, K): the plain path's business
+        gespmm_plan_options opt;
+        std::memset(&opt, 0, sizeof opt);
+        opt.expected_launches = 0;  // the library's default: the reference's 200
+        gespmm_plan* p = nullptr;
+        const int prc = gespmm_plan_create_v2(&p, rowptr, colind, val, M, Kp, nnz, N, variant, &opt, (int64_t)sizeof opt, stream);
+        if (prc != 0 || !p) {
+            (void)hipGetLastError();
+            en->count = 0;  // (not again on the next call: the count starts over)
+            return false;
+        }
+        g_stats.plans_created += 1;
+        if (!plan_is_clustered(p)) {
+            // nothing to reuse: the plan's launch IS the plain call's. No fingerprint, no synchronisation from here on.
+            gespmm_plan_destroy(p);
+            en->no_gain = true;
+            return false;
+        }
+        en->plan = p;
+        en->fp_pattern = fp[0];
+        en->fp_values = fp[1];
+        en->nnz = nnz;
+        en->val_seen = val;
+    } else if (val && (fp[1] != en->fp_values || val != en->val_seen)) {
+        const int src = gespmm_plan_set_values(en->plan, val, stream);
+        if (src != 0) {
+            drop_plan(*en);
+            en->count = 0;
+            return false;
+        }
+        en->fp_values = fp[1];
+        en->val_seen = val;
+        g_stats.values_refreshed += 1;
+    }
+    *rc = reduce == kReduceMax ? gespmm_plan_spmm_max_f32(en->plan, B, C, N, empty, stream) : gespmm_plan_spmm_f32(en->plan, B, C, N, stream);
+    g_stats.calls_planned += 1;
+    return true;
+}
+
+}  // namespace gespmm
+
+namespace gespmm {
+namespace {
+
+// gespmm_init's matrix: 16 communities of 1 024 rows, every row six neighbours inside its community and two anywhere — small, and the
+// clustering, the model, the task cutting and the staging tables all have something to do
+__global__ void k_init_matrix(int32_t* __restrict__ rowptr, int32_t* __restrict__ colind, int M, int deg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= M) rowptr[i] = i * deg;
+    if (i >= M) return;
+    const int base = i & ~1023;
+    for (int j = 0; j < deg; ++j) {
+        const unsigned int h = (unsigned int)mix64(((unsigned long long)i << 8) | (unsigned int)j);
+        colind[i * deg + j] = j < deg - 2 ? base + (int)(h & 1023u) : (int)(h % (unsigned int)M);
+    }
+}
+
+std::atomic<unsigned int> g_init_done{0};  // bit d: gespmm_init has run on device d
+
+}  // namespace
+}  // namespace gespmm
+
+extern "C" {
+
+int gespmm_init(int64_t rows_hint, int64_t nnz_hint, void* stream) {
+    if (rows_hint < 0 || nnz_hint < 0) return GESPMM_EINVAL;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return GESPMM_EINVAL;
+    const unsigned int bit = dev >= 0 && dev < 32 ? 1u << dev : 0u;
+    int rc = 0;
+    if (!(gespmm::g_init_done.load() & bit)) {
+        constexpr int M = 16384, deg = 8, N = 128;
+        constexpr int64_t nnz = (int64_t)M * deg;
+        char* block = nullptr;  // rowptr | colind | B | C
+        const size_t b_rp = ((size_t)(M + 1) * 4 + 255) & ~(size_t)255, b_ci = (size_t)nnz * 4, b_d = (size_t)M * N * 4;
+        e = hipMalloc(reinterpret_cast<void**>(&block), b_rp + b_ci + 2 * b_d);
+        if (e != hipSuccess) return (int)e;
+        int32_t* rp = reinterpret_cast<int32_t*>(block);
+        int32_t* ci = reinterpret_cast<int32_t*>(block + b_rp);
+        float* B = reinterpret_cast<float*>(block + b_rp + b_ci);
+        float* C = B + (size_t)M * N;
+        hipLaunchKernelGGL(gespmm::k_init_matrix, dim3((M + 256) / 256), dim3(256), 0, st, rp, ci, M, deg);
+        e = hipMemsetAsync(B, 0, 2 * b_d, st);
+        rc = e != hipSuccess ? (int)e : (int)hipGetLastError();
+        // every kernel family once: the plain call, a clustered plan on the streaming kernels (both), the staged-rows kernels (tuned,
+        // general, lane groups) — building the plans runs every analysis pass
+        if (rc == 0) rc = gespmm::run_spmm(rp, ci, nullptr, B, C, M, M, N, nnz, GESPMM_VARIANT_AUTO, nullptr, gespmm::kReduceSum, 0.0f, stream, nullptr, 0, nullptr);
+        const int kernels[4] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STAGED};
+        const int widths[4] = {N, N, N, 32};
+        for (int i = 0; i < 4 && rc == 0; ++i) {
+            gespmm_plan_options opt;
+            std::memset(&opt, 0, sizeof opt);
+            opt.reorder = GESPMM_PLAN_REORDER;
+            opt.kernel = kernels[i];
+            gespmm_plan* p = nullptr;
+            rc = gespmm_plan_create_v2(&p, rp, ci, nullptr, M, M, nnz, widths[i], GESPMM_VARIANT_AUTO, &opt, (int64_t)sizeof opt, stream);
+            if (rc == 0) rc = gespmm_plan_spmm_f32(p, B, C, widths[i], stream);
+            if (rc == 0 && i == 2) rc = gespmm_plan_spmm_max_f32(p, B, C, widths[i], -10000.0f, stream);  // (the general kernel)
+            if (p) {
+                (void)hipStreamSynchronize(st);
+                gespmm_plan_destroy(p);
+            }
+        }
+        const hipError_t es = hipStreamSynchronize(st);
+        (void)hipFree(block);
+        if (rc == 0 && es != hipSuccess) rc = (int)es;
+        if (rc != 0) return rc;
+        gespmm::g_init_done.fetch_or(bit);
+        gespmm::mark_analysis_warm();
+    }
+    if (rows_hint > 0 && nnz_hint > 0) rc = gespmm::reserve_analysis_arena(rows_hint, rows_hint, nnz_hint, stream);
+    return rc;
+}
+
+int gespmm_set_auto_plan(int32_t kth_call) {
+    if (kth_call < 0) return GESPMM_EINVAL;
+    gespmm::g_auto_k.store(kth_call, std::memory_order_relaxed);
+    if (kth_call == 0) gespmm_auto_plan_clear();
+    return 0;
+}
+
+void gespmm_auto_plan_clear(void) {
+    std::lock_guard<std::mutex> guard(gespmm::g_lock);
+    for (gespmm::AutoEntry& e : gespmm::g_entries) {
+        gespmm::drop_plan(e);
+        e = gespmm::AutoEntry();
+    }
+}
+
+int gespmm_auto_plan_get_stats(gespmm_auto_plan_stats* out) {
+    if (!out) return GESPMM_EINVAL;
+    std::lock_guard<std::mutex> guard(gespmm::g_lock);
+    *out = gespmm::g_stats;
+    out->cached_plans = 0;
+    for (const gespmm::AutoEntry& e : gespmm::g_entries) out->cached_plans += e.plan ? 1 : 0;
+    return 0;
+}
+
+}  // extern "C"

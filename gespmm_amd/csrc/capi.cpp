@@ -14,6 +14,7 @@
 
 #include "../../include/gespmm.h"
 #include "select.h"
+#include "auto_plan.h"
 #include "plan.h"
 #include "spmm_kernels.h"
 
@@ -187,6 +188,13 @@ const char* gespmm_error_string(int code) {
 
 int gespmm_csr_spmm_f32(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C,
                         int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, void* stream) {
+    if (gespmm::auto_plan_enabled()) {  // (gespmm_set_auto_plan: off by default — one relaxed load)
+        int rc = 0;
+        if (check_common(rowptr, colind, val, B, C, M, K, N, nnz) == 0 && variant >= GESPMM_VARIANT_AUTO && variant < GESPMM_NUM_VARIANTS &&
+            variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE &&  // (a plan runs the CRC family)
+            gespmm::auto_plan_try(rowptr, colind, val, B, C, M, K, N, nnz, variant, gespmm::kReduceSum, 0.0f, stream, &rc))
+            return rc;
+    }
     return run_spmm(rowptr, colind, val, B, C, M, K, N, nnz, variant, nullptr, gespmm::kReduceSum, 0.0f, stream);
 }
 
@@ -198,6 +206,12 @@ int gespmm_csr_spmm_f32_cfg(const int32_t* rowptr, const int32_t* colind, const 
 
 int gespmm_csr_spmm_max_f32(const int32_t* rowptr, const int32_t* colind, const float* B, float* C, int64_t M,
                             int64_t K, int64_t N, int64_t nnz, float empty_value, int variant, void* stream) {
+    if (gespmm::auto_plan_enabled() && variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE) {
+        int rc = 0;
+        if (check_common(rowptr, colind, nullptr, B, C, M, K, N, nnz) == 0 && variant >= GESPMM_VARIANT_AUTO && variant < GESPMM_NUM_VARIANTS &&
+            gespmm::auto_plan_try(rowptr, colind, nullptr, B, C, M, K, N, nnz, variant, gespmm::kReduceMax, empty_value, stream, &rc))
+            return rc;
+    }
     return run_spmm(rowptr, colind, nullptr, B, C, M, K, N, nnz, variant, nullptr, gespmm::kReduceMax, empty_value,
                     stream);
 }
@@ -229,6 +243,13 @@ int gespmm_csr_spmm_f32_ws(const int32_t* rowptr, const int32_t* colind, const f
                            int64_t M, int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg,
                            void* workspace, int64_t workspace_bytes, void* stream) {
     if (workspace_bytes < 0 || (workspace_bytes > 0 && workspace == nullptr)) return GESPMM_EINVAL;
+    if (cfg == nullptr && gespmm::auto_plan_enabled()) {  // (no launch knobs: the stateless call with the caller's scratch — what the torch op makes)
+        int rc = 0;
+        if (check_common(rowptr, colind, val, B, C, M, K, N, nnz) == 0 && variant >= GESPMM_VARIANT_AUTO && variant < GESPMM_NUM_VARIANTS &&
+            variant != GESPMM_VARIANT_NAIVE && variant != GESPMM_VARIANT_PARREDUCE &&
+            gespmm::auto_plan_try(rowptr, colind, val, B, C, M, K, N, nnz, variant, gespmm::kReduceSum, 0.0f, stream, &rc))
+            return rc;
+    }
     return run_spmm(rowptr, colind, val, B, C, M, K, N, nnz, variant, cfg, gespmm::kReduceSum, 0.0f, stream, workspace,
                     workspace_bytes);
 }
@@ -295,6 +316,11 @@ static int dgl_csrmm(int m, int n, const int32_t* indptr, const int32_t* indices
     int64_t nnz = -1, K = 0x7fffffffLL;
     gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (gespmm::auto_plan_enabled() && m > 0 && n > 0 && indptr && indices && B && C) {
+        // (the fingerprint's read-back is the synchronisation this entry point performs anyway; K and nnz come out of it)
+        int rc = 0;
+        if (gespmm::auto_plan_try(indptr, indices, nullptr, B, C, m, 0, n, -1, GESPMM_VARIANT_AUTO, reduce, empty, stream, &rc)) return rc;
+    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     const int64_t rb_rows = g_dgl_readback_rows.load(std::memory_order_relaxed);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "../../include/gespmm.h"
+#include "auto_plan.h"
 #include "plan.h"
 #include "plan_device.h"
 #include "plan_policy.h"
@@ -180,6 +182,13 @@ hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace gespmm {
+bool plan_is_clustered(const gespmm_plan* p) { return p && p->reordered; }
+static std::atomic<bool> g_analysis_warm{false};
+bool analysis_is_warm() { return g_analysis_warm.load(std::memory_order_relaxed); }
+void mark_analysis_warm() { g_analysis_warm.store(true, std::memory_order_relaxed); }
+}  // namespace gespmm
 
 extern "C" {
 
@@ -399,6 +408,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         f.opt_row_floor = opt ? opt->row_floor : 0;
         f.expected_launches = opt ? opt->expected_launches : 0;
         f.wedge_probe = wedge_probe;
+        f.cold_start = !gespmm::analysis_is_warm();
         {
             gespmm::Selection sel;
             int max_vec = 4;
@@ -638,6 +648,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         return GESPMM_ENOMEM;
     }
     p->analysis_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (p->reordered || p->hits_after >= 0.0) gespmm::mark_analysis_warm();  // (the analysis passes ran: their kernels are loaded now)
     *out = p;
     return 0;
 }

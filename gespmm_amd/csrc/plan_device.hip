@@ -43,6 +43,7 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/functional.hpp>
 
+#include "auto_plan.h"
 #include "plan_device.h"
 #include "spmm_kernels.h"
 #include "workspace.h"
@@ -1250,6 +1251,33 @@ hipError_t device_validate_csr(const int32_t* rowptr, const int32_t* colind, int
     return hipSuccess;
 }
 
+// Region sizes of the clustering's arena (upper bounds for level 0, every later level is smaller; see Scratch for what happens beyond them)
+static void cluster_arena_regions(int64_t M, int64_t K, int64_t nnz, hipStream_t st, size_t* persist, size_t* level, size_t* temp) {
+    size_t sort_tmp = 0;
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)nnz, 0u, 64u, st);
+    const size_t E = (size_t)nnz, V = (size_t)(M + K);
+    *persist = 4 * (3 * (size_t)M + 4096);
+    *level = 4 * (4 * E + 2 * V + 64) + 16 * 256;
+    *temp = 48 * E + 56 * V + 2 * sort_tmp + (1 << 20);
+}
+
+// gespmm_init: the arena the first plan of a matrix of this size will ask for, made now and parked in the per-device cache (when it
+// fits the cache's limit; a larger one would be freed again at once, so nothing is done)
+int reserve_analysis_arena(int64_t M, int64_t K, int64_t nnz, void* stream) {
+    if (M <= 0 || nnz <= 0) return 0;
+    size_t persist = 0, level = 0, temp = 0;
+    cluster_arena_regions(M, K, nnz, reinterpret_cast<hipStream_t>(stream), &persist, &level, &temp);
+    const size_t total = Scratch::up(persist) + 2 * Scratch::up(level) + Scratch::up(temp);
+    if (total > arena_cache_cap()) return 0;
+    void* p = nullptr;
+    bool cached = false;
+    const hipError_t e = arena_acquire(total, &p, &cached);
+    if (e != hipSuccess) return (int)e;
+    arena_release(p, cached);
+    return 0;
+}
+
 hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr, const int32_t* colind,
                                const ClusterOptions& opt, int32_t* perm, ClusterStats* stats, hipStream_t st) {
     if (stats) *stats = ClusterStats{};
@@ -1260,15 +1288,8 @@ hipError_t device_cluster_rows(int64_t M, int64_t K, int64_t nnz, const int32_t*
     }
     Scratch sc(st);
     {
-        // region sizes (upper bounds for level 0, every later level is smaller; see Scratch for what happens beyond them)
-        size_t sort_tmp = 0;
-        (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_tmp, (const unsigned long long*)nullptr,
-                                                    (unsigned long long*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                                    (size_t)nnz, 0u, 64u, st);
-        const size_t E = (size_t)nnz, V = (size_t)(M + K);
-        const size_t persist = 4 * (3 * (size_t)M + 4096);
-        const size_t level = 4 * (4 * E + 2 * V + 64) + 16 * 256;
-        const size_t temp = 48 * E + 56 * V + 2 * sort_tmp + (1 << 20);
+        size_t persist = 0, level = 0, temp = 0;
+        cluster_arena_regions(M, K, nnz, st, &persist, &level, &temp);
         GESPMM_TRY(sc.init(persist, level, temp));
     }
 

@@ -65,6 +65,10 @@ CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     //  estimate from a probe — Barabasi-Albert: 30 us estimated, 16 measured)
     c.cost_us = !deep_analysis(f) ? 3300.0 + 0.55e-3 * e : 5000.0 + 0.6e-3 * e;
     if (f.host_analysis) c.cost_us *= 30.0;
+    // The first analysis of a process also loads the analysis kernels and makes the arena: 33.0 ms against 3.7 on the headline graph
+    // (BENCH_r05 plan_ms_first_creation; profiles/r06/plan_cold.log). Under the reference's protocol — one process per matrix, 200
+    // launches — that is the cost that counts: 200 x 89 us + 33 ms is slower than 200 plain launches of 150 us. gespmm_init removes it.
+    if (f.cold_start && !f.host_analysis) c.cost_us += 29000.0;
     return c;
 }
 
@@ -325,9 +329,11 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     if (!q_in || !a_out || q_bytes < kQueryBytesV1 || a_bytes < kAnswerBytesV1 || q_bytes % 4 != 0 || a_bytes % 4 != 0) return GESPMM_EINVAL;
     gespmm_plan_policy_query qq;
     std::memset(&qq, 0, sizeof qq);
-    qq.wedge_probe = -1.0;  // (a 0.2 caller: unknown)
+    qq.wedge_probe = -1.0;
+    if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, cold_start) + 4) qq.cold_start = 0;  // (a 0.2 caller: unknown)
     std::memcpy(&qq, q_in, (size_t)(q_bytes < (int64_t)sizeof qq ? q_bytes : (int64_t)sizeof qq));
     if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, wedge_probe) + 8) qq.wedge_probe = -1.0;
+    if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, cold_start) + 4) qq.cold_start = 0;
     gespmm_plan_policy_answer aa;
     std::memset(&aa, 0, sizeof aa);
     const gespmm_plan_policy_query* q = &qq;
@@ -355,6 +361,7 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     f.opt_row_floor = q->row_floor;
     f.expected_launches = q->expected_launches;
     f.wedge_probe = q->wedge_probe;
+    f.cold_start = q->cold_start != 0;
     gespmm::Selection sel;
     int max_vec = 4;
     while (max_vec > 1 && (q->N % max_vec) != 0) max_vec >>= 1;

@@ -24,6 +24,7 @@ struct PlanFacts {
     int user_flags = 0;                    // gespmm_plan_options.flags
     int opt_task_entries = 0, opt_row_floor = 0;
     int expected_launches = 0;             // gespmm_plan_options.expected_launches (0 = kDefaultExpectedLaunches)
+    bool cold_start = false;               // the process has built no plan and gespmm_init has not run: the analysis also loads its kernels
     double wedge_probe = -1.0;             // share of sampled wedges (c1, c2 in one row) that close (c2 in row c1); < 0: unknown
 
     int64_t mean_ceil() const { return M > 0 ? (nnz + M - 1) / M : 0; }

@@ -426,6 +426,13 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipEventCreate(&g.start));
     CHECK_HIP(hipEventCreate(&g.stop));
     for (int i = 0; i < 200; i++) hipLaunchKernelGGL(warmup, dim3(1), dim3(1), 0, 0);
+    if (use_plan) {
+        // the library's own warm-up, next to the reference's 200 empty launches (spmm_test.cu:720-721) and like them outside every timed
+        // region: analysis kernels loaded, the analysis arena of a matrix this size allocated (gespmm.h: gespmm_init)
+        const auto t0 = std::chrono::steady_clock::now();
+        CHECK_GE(gespmm_init(M > K ? M : K, nnz, nullptr));
+        printf("gespmm_init: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
     printf("running tests...\n");
 
     if (ncols_list.empty())
@@ -455,6 +462,7 @@ int main(int argc, char** argv) {
         if (g.fpo) fprintf(g.fpo, "%f,", vendor_gflops);
 
         gespmm_plan* plan = nullptr;
+        double plan_secs = 0.0;
         if (use_plan) {
             const auto t0 = std::chrono::steady_clock::now();
             gespmm_plan_options po;
@@ -465,6 +473,7 @@ int main(int argc, char** argv) {
                                            &po, (int64_t)sizeof po, nullptr));
             if (tune_plan) CHECK_GE(gespmm_plan_tune(plan, g.B_dev, g.C_dev, N, 3, nullptr));
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            plan_secs = secs;
             char what[768];
             if (gespmm_plan_describe(plan, what, sizeof what) > 0) printf("N=%d plan (%.3f s%s): %s\n", N, secs, tune_plan ? ", tuned" : "", what);
         }
@@ -481,6 +490,10 @@ int main(int argc, char** argv) {
         if (g.fpo) fprintf(g.fpo, "%f,", gflop / (rt / iters));
         printf("N=%d method=%d%s: %f ms/iter, %f GFLOP/s (rocsparse %f GFLOP/s)\n", N, method, plan ? " plan" : "", rt / iters,
                gflop / (rt / iters), vendor_gflops);
+        // the same launches with the analysis INSIDE the time: what one process per matrix (run_test.sh:5-11) pays for its plan
+        if (plan)
+            printf("N=%d plan incl. analysis: %f ms for %d launches, %f GFLOP/s\n", N, plan_secs * 1e3 + rt, iters,
+                   gflop * iters / (plan_secs * 1e3 + rt));
         if (plan) gespmm_plan_destroy(plan);
         if (atomic_baseline) {
             // out = A^T * B[0:M] by one atomicAdd per edge and feature; reuses C_dev when it is large enough (M == K)

@@ -56,7 +56,7 @@ extern "C" {
 #endif
 
 #define GESPMM_VERSION_MAJOR 0
-#define GESPMM_VERSION_MINOR 2
+#define GESPMM_VERSION_MINOR 3
 
 /* Negative return codes (positive values are hipError_t). */
 #define GESPMM_EINVAL   (-1)  /* bad argument (null pointer, negative size, unknown variant) */
@@ -348,6 +348,41 @@ void gespmm_set_cached_memory_limit(int64_t bytes);
 void gespmm_release_cached_memory(void);
 
 /*
+ * Warm-up (since 0.3). The FIRST plan a process builds pays ~29 ms on top of its analysis: the analysis kernels are loaded on first use
+ * and the scratch arena is allocated (profiles/r06/plan_cold.log). A process that follows the reference's protocol — one process per
+ * matrix, 200 launches (run_test.sh:5-11) — cannot amortise that, so the driver and the Python layer call gespmm_init before they time
+ * anything: it builds and destroys plans on a small built-in matrix (every analysis pass, the staging tables, one product through each
+ * kernel family) and reserves the arena a matrix of (rows_hint, nnz_hint) will ask for (0 / 0: nothing reserved; within the limit of
+ * gespmm_set_cached_memory_limit). Idempotent per device; returns 0 or an error code. Until it (or a first plan) has run, a plan made
+ * with reorder = AUTO adds the cold cost to its cost rule (gespmm_plan_policy_query.cold_start).
+ */
+int gespmm_init(int64_t rows_hint, int64_t nnz_hint, void* stream);
+
+/*
+ * Plan reuse behind the STATELESS entry points (since 0.3; off by default). The reference's callers keep no state between products
+ * (spmmWrapper spmm_test.cu:456-492, spmm_cuda spmm_kernel.cu:425-458, DGL's CustomCsrmm binary_reduce_sum.cu:338-360), so they cannot
+ * hold a gespmm_plan. gespmm_set_auto_plan(k), k >= 1: gespmm_csr_spmm_f32, gespmm_csr_spmm_max_f32 and gespmm_dgl_csrmm_{sum,max}_f32
+ * keep a small cache (8 entries, least recently used) keyed on (device, rowptr, colind, M, K, N, valued, variant, reducer); the k-th
+ * call with one key builds a plan (synchronously), later calls run through it. Pointer identity is not pattern identity: every call
+ * that uses a cached plan first fingerprints ALL of rowptr / colind / val on the device (one small kernel + a 32-byte read-back = one
+ * stream synchronisation per call — the price of the switch; ~10 us on a com-Amazon-sized graph against ~60 us saved). A pattern
+ * changed in place drops the plan, changed values are re-permuted. Never on a capturing stream. Matrices whose analysis keeps the
+ * storage order run the plain path without fingerprint from then on. Results: the plain call's bits.
+ * k = 0 switches it off and frees the cached plans; gespmm_auto_plan_clear frees them and keeps the switch.
+ */
+typedef struct gespmm_auto_plan_stats {
+    int64_t calls_planned;     /* products that ran through a cached plan */
+    int64_t plans_created;
+    int64_t invalidated;       /* plans dropped because the pattern's fingerprint changed */
+    int64_t values_refreshed;  /* gespmm_plan_set_values calls after the values' fingerprint changed */
+    int64_t fingerprints;      /* fingerprint passes (= stream synchronisations the switch added) */
+    int64_t cached_plans;      /* plans alive now */
+} gespmm_auto_plan_stats;
+int gespmm_set_auto_plan(int32_t kth_call);
+void gespmm_auto_plan_clear(void);
+int gespmm_auto_plan_get_stats(gespmm_auto_plan_stats* out);
+
+/*
  * The clustering by itself, HOST pointers (what gespmm_plan_create runs on its host copy): multi-level label
  * propagation on the bipartite row/column graph; perm_out[i] = row at position i. Deterministic, independent of
  * `threads`. levels_out / clusters_out[16] (row clusters after each level) may be NULL.
@@ -391,7 +426,8 @@ typedef struct gespmm_plan_policy_query {
     double staged_fraction;  /* share of the entries whose B row a staged-rows block holds in LDS */
     /* since 0.3 (read by gespmm_plan_policy_v2 when q_bytes covers them) */
     int32_t expected_launches; /* as in gespmm_plan_options (0 = 200) */
-    int32_t reserved0;
+    int32_t cold_start;        /* since 0.3: 1 = the process has built no plan and gespmm_init has not run — the first analysis also loads
+                                  its kernels and makes its arena (~29 ms): the cost rule is asked with that on top */
     double wedge_probe;      /* share of sampled (row r; c1, c2 in r) wedges with c2 in row c1 — the plan's cheap structure probe on square
                                 matrices; negative = unknown (rectangular matrix, host analysis) */
 } gespmm_plan_policy_query;

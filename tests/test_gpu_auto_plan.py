@@ -1,0 +1,154 @@
+"""Opt-in plan reuse behind the stateless entry points (csrc/auto_plan.cpp, round 6) and the library's warm-up.
+
+The reference's callers pass the CSR arrays with every product and keep nothing (spmmWrapper spmm_test.cu:456-492, spmm_cuda
+spmm_kernel.cu:425-458, DGL's CustomCsrmm binary_reduce_sum.cu:338-360). With gespmm_set_auto_plan(k) the library keeps the plan for
+them: same bits as the plain call, a pattern or values changed IN PLACE under the same pointers are noticed (a fingerprint of the
+arrays before every planned launch), the default (off) is untouched."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _plain(_lib, rp, ci, val, B):
+    """The reference product: the _cfg entry point is never planned."""
+    M, (K, N) = rp.numel() - 1, B.shape
+    C = torch.empty((M, N), device="cuda")
+    cfg = _lib.LaunchCfg(0, 0, 0, 0, 0, 0)
+    _lib.check(_lib.lib.gespmm_csr_spmm_f32_cfg(_p(rp), _p(ci), _p(val), _p(B), _p(C), M, K, N, ci.numel(), -1, ctypes.byref(cfg), _stream()), "cfg")
+    return C
+
+
+def _call(_lib, rp, ci, val, B):
+    M, (K, N) = rp.numel() - 1, B.shape
+    C = torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(_lib.lib.gespmm_csr_spmm_f32(_p(rp), _p(ci), _p(val), _p(B), _p(C), M, K, N, ci.numel(), -1, _stream()), "gespmm_csr_spmm_f32")
+    return C
+
+
+@pytest.fixture()
+def auto(pkg):
+    from gespmm_amd import _lib
+
+    _lib.set_auto_plan(0)
+    yield _lib
+    _lib.set_auto_plan(0)
+
+
+def test_off_by_default_and_switch_validation(auto, oracle):
+    _lib = auto
+    assert _lib.auto_plan_stats()["cached_plans"] == 0
+    with pytest.raises(_lib.GespmmError):
+        _lib.set_auto_plan(-1)
+
+
+def test_planned_from_the_kth_call_same_bits_and_changes_in_place_are_noticed(auto, oracle):
+    _lib = auto
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    rp, ci, K, nnz = g["rowptr"], g["colind"], g["K"], g["nnz"]
+    val = torch.from_numpy(oracle.hash_val(nnz, seed=3)).cuda()
+    B = torch.from_numpy(oracle.hash_B(K, 128, seed=4)).cuda()
+    ref = _plain(_lib, rp, ci, val, B)
+    before = _lib.auto_plan_stats()
+    _lib.set_auto_plan(3)
+    outs = [_call(_lib, rp, ci, val, B) for _ in range(5)]
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), ref.view(torch.int32))
+    st = _lib.auto_plan_stats()
+    assert st["plans_created"] - before["plans_created"] == 1 and st["cached_plans"] == 1, st
+    assert st["calls_planned"] - before["calls_planned"] == 3, st  # calls 3, 4, 5
+    assert st["fingerprints"] - before["fingerprints"] == 3, st
+    # another dense operand, same key: still the cached plan
+    B2 = torch.from_numpy(oracle.hash_B(K, 128, seed=5)).cuda()
+    assert torch.equal(_call(_lib, rp, ci, val, B2).view(torch.int32), _plain(_lib, rp, ci, val, B2).view(torch.int32))
+    # VALUES changed in place (same pointer): re-permuted before the launch
+    val.mul_(-0.5)
+    got = _call(_lib, rp, ci, val, B)
+    assert torch.equal(got.view(torch.int32), _plain(_lib, rp, ci, val, B).view(torch.int32))
+    assert _lib.auto_plan_stats()["values_refreshed"] - before["values_refreshed"] == 1
+    # PATTERN changed in place: two entries of different rows swap their columns — same pointers, same nnz, same row lengths
+    rph = rp.cpu().numpy()
+    r1, r2 = 1000, 200000
+    p1, p2 = int(rph[r1]), int(rph[r2])
+    assert rph[r1 + 1] > p1 and rph[r2 + 1] > p2
+    c1, c2 = int(ci[p1]), int(ci[p2])
+    assert c1 != c2
+    ci[p1], ci[p2] = c2, c1
+    got = _call(_lib, rp, ci, val, B)
+    want = _plain(_lib, rp, ci, val, B)
+    assert not torch.equal(want.view(torch.int32), ref.view(torch.int32))  # (the product did change)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    st2 = _lib.auto_plan_stats()
+    assert st2["invalidated"] - before["invalidated"] == 1 and st2["cached_plans"] == 0, st2
+    # ... and the key earns a new plan after k more calls
+    for _ in range(3):
+        got = _call(_lib, rp, ci, val, B)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert _lib.auto_plan_stats()["cached_plans"] == 1
+    _lib.auto_plan_clear()
+    assert _lib.auto_plan_stats()["cached_plans"] == 0
+
+
+def test_dgl_entry_points_and_the_max_reducer(auto, oracle):
+    _lib = auto
+    from gespmm_amd import graphs, spmm
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    rp, ci, M, K = g["rowptr"], g["colind"], g["M"], g["K"]
+    N = 128
+    B = torch.from_numpy(oracle.hash_B(K, N, seed=6)).cuda()
+    ref_sum = _plain(_lib, rp, ci, None, B)
+    ref_max = spmm.csr_spmm_max(rp, ci, B)
+    before = _lib.auto_plan_stats()
+    _lib.set_auto_plan(2)
+    for fn, ref in ((_lib.lib.gespmm_dgl_csrmm_sum_f32, ref_sum), (_lib.lib.gespmm_dgl_csrmm_max_f32, ref_max)):
+        for _ in range(4):
+            C = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(fn(M, N, _p(rp), _p(ci), _p(B), _p(C), _stream()), "dgl")
+            assert torch.equal(C.view(torch.int32), ref.view(torch.int32))
+    st = _lib.auto_plan_stats()
+    assert st["plans_created"] - before["plans_created"] == 2 and st["calls_planned"] - before["calls_planned"] == 6, st
+
+
+def test_no_structure_no_plan_no_fingerprint(auto, oracle):
+    """A matrix whose analysis keeps the storage order (here: the cost rule declines) is remembered as such: the plain path, without a
+    fingerprint or a synchronisation, from then on."""
+    _lib = auto
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("com-amazon-like", seed=42, device="cuda")
+    rp, ci, K = g["rowptr"], g["colind"], g["K"]
+    B = torch.from_numpy(oracle.hash_B(K, 128, seed=7)).cuda()
+    ref = _plain(_lib, rp, ci, None, B)
+    _lib.set_auto_plan(1)
+    before = _lib.auto_plan_stats()
+    for _ in range(4):
+        assert torch.equal(_call(_lib, rp, ci, None, B).view(torch.int32), ref.view(torch.int32))
+    st = _lib.auto_plan_stats()
+    assert st["cached_plans"] == 0 and st["calls_planned"] == before["calls_planned"], st
+    assert st["fingerprints"] - before["fingerprints"] == 1, st  # only the call that asked the analysis
+
+
+def test_init_is_idempotent_and_warms_the_analysis(pkg):
+    from gespmm_amd import _lib
+
+    _lib.init()
+    _lib.init(334863, 1851744)
+    # after the warm-up the cost rule no longer adds the cold cost (the query's cold_start is what a cold process would send)
+    warm = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42)
+    cold = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42, cold_start=1)
+    assert cold["est_cost_us"] - warm["est_cost_us"] == pytest.approx(29000.0)
+    assert warm["analyse"] == 1 and cold["analyse"] == 0
