@@ -92,7 +92,7 @@ def compact_line(full):
                      if k in ("workload", "rows_per_gpu", "nnz_per_gpu", "ncols", "partition", "stand_in", "kernel")}
     out["roofline"] = _pick(full.get("roofline", {}), (
         "bound", "achieved", "peak", "unit", "frac", "traffic", "l2_hit_rate", "algorithmic_bytes_per_launch", "kernel_us",
-        "launches", "ceiling_frac", "achieved_over_ceiling", "traffic_floor", "ceiling_note", "gather_GBs"))
+        "kernel_us_median_of_pairs", "launches", "ceiling_frac", "achieved_over_ceiling", "traffic_floor", "ceiling_note", "gather_GBs"))
     out["roofline"].setdefault("traffic", None)
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -102,7 +102,8 @@ def compact_line(full):
         out["cpu_baseline"] = c2
     else:
         out["cpu_baseline"] = None
-    for k in ("verified_vs_oracle", "plan_ms", "plan_ms_first_creation", "value_incl_plan_over_200_launches", "series", "widths",
+    for k in ("verified_vs_oracle", "plan_ms", "plan_ms_first_creation", "init_ms", "value_incl_plan_over_200_launches",
+              "value_incl_first_plan_over_200_launches", "stateless_auto_plan", "series", "widths",
               "reference_kernel", "other_configs", "exchange", "one_gpu_reference", "extra_file"):
         if full.get(k) is not None:
             out[k] = _r(full[k])
@@ -355,6 +356,16 @@ def main():
     strong = graph == "rmat"
     N = args.ncols or (256 if strong else 128)
 
+    # the library's warm-up, outside every timed region like the reference driver's 200 empty launches (spmm_test.cu:720-721): analysis
+    # kernels loaded, analysis arena made (gespmm.h: gespmm_init). Without it the FIRST plan of a process costs ~36 ms instead of ~4
+    # (profiles/r06/plan_cold.log) — under the reference's one-process-per-matrix protocol that decides whether a plan pays at all.
+    torch.cuda.synchronize()
+    t_init0 = time.perf_counter()
+    _lib.init(400000, 2000000)
+    _lib._initialised.add(local_rank)
+    torch.cuda.synchronize()
+    init_ms = (time.perf_counter() - t_init0) * 1e3
+
     env = BenchEnv(torch, dist, dev, world, rank, use_dist, variant=args.variant)
     sync_all, make_B, kernel_times_us, timed_region, verify = env.sync_all, env.make_B, env.kernel_times_us, env.timed_region, env.verify
 
@@ -403,6 +414,7 @@ def main():
             out["plan"] = what
             # the reference's own protocol is ITER = 200 launches per width (spmm_test.cu:714): rate with the analysis paid
             out["gflops_incl_plan_over_200_launches"] = 2.0 * nnz * N * 200 / (plan_ms * 1e3 + 200 * med) / 1e3
+            out["gflops_incl_first_plan_over_200_launches"] = 2.0 * nnz * N * 200 / (plan_first_ms * 1e3 + 200 * med) / 1e3
             out["launches_to_amortise_plan_note"] = "plan_ms / (plain-call kernel_us - kernel_us); see plain_call_* beside this entry"
         if keep:
             return out, step, B, C, plan
@@ -522,6 +534,7 @@ def main():
     series = {}   # headline-grade blocks that stay in the stdout line: the other com-Amazon stand-in (rounds 1-2's headline)
     widths = {}   # the metric's other widths on the headline graph
     reference_kernel = None
+    stateless = None
     if not args.no_extra and world == 1:
         # the plain entry point on the same operands (what a caller without a plan gets; r01's headline)
         def plain():
@@ -556,6 +569,66 @@ def main():
                     widths["N%d" % n2].update({k: v for k, v in ceiling_for(g, n2, rw["frac"]).items()
                                                if k in ("ceiling_frac", "achieved_over_ceiling")})
         extra["N%d_unweighted" % N] = measure_graph(g, val, N, False, samples=50)
+        # ---- round 6: feature widths that are not powers of two (100 / 200 features, 41 / 47 classes) through the
+        #      general staged-rows kernel, and the max reducer through a plan
+        for n2 in (100, 200, 47):
+            torch.cuda.empty_cache()
+            rw = measure_graph(g, val, n2, True, expected_launches=STEADY_STATE)
+            rp2_ = measure_graph(g, val, n2, True, use_plan=False)
+            extra["N%d_valued" % n2] = rw
+            widths["N%d" % n2] = {"kernel_us": rw["kernel_us"], "frac": rw["frac"], "plain_call_kernel_us": rp2_["kernel_us"],
+                                  "kernel": (rw.get("plan") or "").split("|")[-1].strip()[:24]}
+        try:
+            Bm = make_B(K, N)
+            Cm = torch.empty((M, N), dtype=torch.float32, device=dev)
+            pm = spmm.SpmmPlan(g["rowptr"], g["colind"], K, N, expected_launches=STEADY_STATE)
+            want = spmm.csr_spmm_max(g["rowptr"], g["colind"], Bm)
+            pm.run(None, Bm, out=Cm, reduce_max=-10000.0)
+            t_max_plan = statistics.median(kernel_times_us(lambda: pm.run(None, Bm, out=Cm, reduce_max=-10000.0), 50))
+            t_max_plain = statistics.median(kernel_times_us(lambda: spmm.csr_spmm_max(g["rowptr"], g["colind"], Bm), 50))
+            extra["max_reducer_N%d" % N] = {"plan_kernel_us": t_max_plan, "plain_call_kernel_us": t_max_plain,
+                                            "bits_equal_plain_call": bool(torch.equal(Cm.view(torch.int32), want.view(torch.int32))),
+                                            "plan": pm.describe()}
+            widths["N%d_max_reducer" % N] = {"kernel_us": t_max_plan, "plain_call_kernel_us": t_max_plain}
+            del Bm, Cm, pm, want
+        except Exception as ex:  # noqa: BLE001
+            extra["max_reducer_N%d" % N] = {"skipped": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+        # ---- round 6: the STATELESS entry points with gespmm_set_auto_plan (csrc/auto_plan.cpp): wall clock per call over 200 calls
+        #      (the fingerprint's synchronisation is part of every call), DGL's argument list, unweighted; switch off / on
+        try:
+            import ctypes as _ct
+
+            Bs = make_B(K, N)
+            Cs = torch.empty((M, N), dtype=torch.float32, device=dev)
+            P_ = lambda t: _ct.c_void_p(t.data_ptr())
+
+            def dgl_call():
+                _lib.check(_lib.lib.gespmm_dgl_csrmm_sum_f32(M, N, P_(g["rowptr"]), P_(g["colind"]), P_(Bs), P_(Cs), None), "dgl")
+
+            def wall_us(fn, n=200):
+                for _ in range(6):
+                    fn()
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n * 1e6
+
+            with torch.cuda.stream(torch.cuda.default_stream(dev)):
+                _lib.set_auto_plan(0)
+                off_us = wall_us(dgl_call)
+                ref_s = Cs.clone()
+                _lib.set_auto_plan(3)
+                on_us = wall_us(dgl_call)
+                same_s = bool(torch.equal(Cs.view(torch.int32), ref_s.view(torch.int32)))
+                st_ = _lib.auto_plan_stats()
+                _lib.set_auto_plan(0)
+            stateless = {"entry": "gespmm_dgl_csrmm_sum_f32 N=%d" % N, "switch_off_us_per_call": off_us, "switch_on_us_per_call": on_us,
+                         "bits_equal": same_s, "plans_created": st_["plans_created"]}
+            del Bs, Cs, ref_s
+        except Exception as ex:  # noqa: BLE001
+            stateless = {"skipped": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
         if graph in ("com-amazon-sbm", "com-amazon-like") and args.locality == 0.0:
             # ---- the OTHER com-Amazon stand-in, same M and nnz, same fields as the headline, so that every round has both:
@@ -663,6 +736,19 @@ def main():
                     del B3, C3
                 extra["%s_sweep_valued" % pname] = sweep
                 del g3, val3, plan3, wide
+
+            # ---- power-law graphs without communities (round-5 review: "the record should carry the power-law figures next to the
+            #      headline"): Barabasi-Albert m = 6 and Holme-Kim m = 16 (the hold-out audit's networkx models, generated on the device:
+            #      graphs.preferential_csr), N = 128, steady-state AUTO plan and the plain call
+            for pname in ("ba-m6", "holme-kim-m16"):
+                torch.cuda.empty_cache()
+                gp_ = graphs.synthetic_graph(pname, seed=42, device=dev)
+                vp_ = torch.rand(gp_["nnz"], device=dev) - 0.5
+                rp_w = measure_graph(gp_, vp_, N, True, samples=50, expected_launches=STEADY_STATE)
+                rp_w["plain_call_kernel_us"] = measure_graph(gp_, vp_, N, True, use_plan=False, samples=50)["kernel_us"]
+                rp_w["nnz"], rp_w["rows"] = gp_["nnz"], gp_["M"]
+                extra["powerlaw-%s_N%d_valued" % (pname, N)] = rp_w
+                del gp_, vp_
 
             # ---- BASELINE configs[0] and [3]: the small graphs (launch-latency territory), unweighted as the reference's driver and
             #      its GCN run them; plain call and plan
@@ -816,6 +902,11 @@ def main():
             # what a caller that runs the reference's protocol (200 launches, spmm_test.cu:714) gets with the analysis
             # stage INSIDE the time; the plain entry point (no analysis) is extra.plain_call_*: compare the two
             "value_incl_plan_over_200_launches": head.get("gflops_incl_plan_over_200_launches"),
+            # ... and priced with the FIRST creation of this process (after gespmm_init, whose time is `init_ms`: start-up, like loading
+            # the library; a process that skips gespmm_init pays ~32 ms more for its first plan — profiles/r06/plan_cold.log)
+            "value_incl_first_plan_over_200_launches": head.get("gflops_incl_first_plan_over_200_launches"),
+            "init_ms": init_ms,
+            "stateless_auto_plan": stateless,
             "cpu_baseline": cpu,
             "verified_vs_oracle": verified,
             "series": {k: {kk: _r(vv) for kk, vv in v.items()} for k, v in series.items()} or None,
@@ -846,7 +937,7 @@ def other_configs(extra):
                 out[name]["of_ceil"] = _r(e["achieved_over_ceiling"], 2)
 
     for k, e in extra.items():
-        if k.startswith(("reddit-", "cit-hepth", "pubmed", "rmat-")):
+        if k.startswith(("reddit-", "cit-hepth", "pubmed", "rmat-", "powerlaw-")):
             put(k.replace("_valued", "").replace("_unweighted", ""), e)
         if k.endswith("_sweep_valued"):
             rows_ = {w: r for w, r in e.items() if isinstance(r, dict) and "plan" in r and isinstance(r["plan"], dict)}

@@ -60,9 +60,11 @@ AutoEntry g_entries[kAutoEntries];
 unsigned long long g_clock = 0;
 gespmm_auto_plan_stats g_stats = {0, 0, 0, 0, 0, 0};
 
+constexpr int kFpSlots = 64;  // partial fingerprints: workgroup b adds into slot b % 64 (same-address atomics serialise at ~9 ns each)
+
 struct FpScratch {
-    unsigned long long* dev = nullptr;   // [4] accumulators on the device
-    unsigned long long* host = nullptr;  // [4] pinned
+    unsigned long long* dev = nullptr;   // [kFpSlots][4] accumulators on the device
+    unsigned long long* host = nullptr;  // the same, pinned
 };
 FpScratch g_fp[kAutoDevices];
 
@@ -75,8 +77,13 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
     return x;
 }
 
-// out[0] += sum over rowptr and colind of mix(position-tagged word), out[1] += the same over the value bits, out[2] = rowptr[M],
-// out[3] = largest column index + 1. Sums of mixed terms: independent of the order the workgroups run in.
+// slot[0] += sum over rowptr and colind of mix(position-tagged word), slot[1] += the same over the value bits, slot[2] = rowptr[M]
+// (slot 0 only), slot[3] = largest column index + 1. Sums of mixed terms: independent of the order the workgroups run in. One set of
+// atomics per WORKGROUP, spread over kFpSlots addresses; the host adds the slots up. What was measured on the headline graph
+// (profiles/r06/auto_plan_timing.log, wall clock per planned call; the plan held by the caller: 88-90 us): one set of atomics per
+// wavefront on ONE address (24 000 same-address atomics) 230-293 us; this form (memset + kernel + 2 KB copy + synchronise) 113-115 us;
+// every workgroup storing its partials into mapped host memory (no memset, no copy) 120-123 us; a last-workgroup ticket that stores one
+// 32-byte result into mapped host memory 122-126 us — stores to host memory make the synchronisation itself slower than a copy does.
 __global__ void __launch_bounds__(256) k_fingerprint(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                      const float* __restrict__ val, long long M, unsigned long long* __restrict__ out) {
     const long long nnz = rowptr[M];
@@ -96,11 +103,22 @@ __global__ void __launch_bounds__(256) k_fingerprint(const int32_t* __restrict__
         const unsigned int m2 = __shfl_down(mx, o);
         mx = m2 > mx ? m2 : mx;
     }
+    __shared__ unsigned long long s_hp[4], s_hv[4];
+    __shared__ unsigned int s_mx[4];
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&out[0], hp);
-        if (val) atomicAdd(&out[1], hv);
-        atomicMax(&out[3], (unsigned long long)mx);
-        if (tid == 0) out[2] = (unsigned long long)nnz;
+        s_hp[threadIdx.x >> 6] = hp;
+        s_hv[threadIdx.x >> 6] = hv;
+        s_mx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* slot = out + 4 * (blockIdx.x & (kFpSlots - 1));
+        atomicAdd(&slot[0], s_hp[0] + s_hp[1] + s_hp[2] + s_hp[3]);
+        if (val) atomicAdd(&slot[1], s_hv[0] + s_hv[1] + s_hv[2] + s_hv[3]);
+        unsigned int m = s_mx[0];
+        for (int w = 1; w < 4; ++w) m = s_mx[w] > m ? s_mx[w] : m;
+        atomicMax(&slot[3], (unsigned long long)m);
+        if (blockIdx.x == 0) slot[2] = (unsigned long long)nnz;
     }
 }
 
@@ -109,23 +127,31 @@ hipError_t fingerprint(int dev, const int32_t* rowptr, const int32_t* colind, co
                        unsigned long long fp[4]) {
     if (dev < 0 || dev >= kAutoDevices) return hipErrorInvalidDevice;
     FpScratch& s = g_fp[dev];
+    constexpr size_t kBytes = (size_t)kFpSlots * 4 * 8;
     if (!s.dev) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.dev), 32);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.host), 32, hipHostMallocDefault);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.dev), kBytes);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.host), kBytes, hipHostMallocDefault);
         if (e != hipSuccess) return e;
     }
-    hipError_t e = hipMemsetAsync(s.dev, 0, 32, st);
+    hipError_t e = hipMemsetAsync(s.dev, 0, kBytes, st);
     if (e != hipSuccess) return e;
-    // enough wavefronts to stream the arrays at the memory system's rate, few enough that the atomics do not show
+    // two workgroups per CU stream the arrays at the memory system's rate (grid-stride: coalesced)
     long long blocks = (M + 256) / 256;
-    if (blocks < 256) blocks = 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks < kFpSlots) blocks = kFpSlots;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(k_fingerprint, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, colind, val, (long long)M, s.dev);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(s.host, s.dev, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.host, s.dev, kBytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) std::memcpy(fp, s.host, 32);
-    return e;
+    if (e != hipSuccess) return e;
+    fp[0] = fp[1] = fp[3] = 0;
+    fp[2] = s.host[2];
+    for (int i = 0; i < kFpSlots; ++i) {
+        fp[0] += s.host[4 * i];
+        fp[1] += s.host[4 * i + 1];
+        if (s.host[4 * i + 3] > fp[3]) fp[3] = s.host[4 * i + 3];
+    }
+    return hipSuccess;
 }
 
 void drop_plan(AutoEntry& en) {
@@ -204,6 +230,9 @@ bool auto_plan_try(const int32_t* rowptr, const int32_t* colind, const float* va
         if (en->count < k) return false;
     }
     if (!en->plan) {
+        // the caller asked for plans: the first one of the process does not start cold (the analysis kernels are loaded and the arena is
+        // made now, once; a cold AUTO plan would price that into its cost rule and decline)
+        if (!analysis_is_warm()) (void)gespmm_init(M, nnz, stream);
         // columns: the caller's K where it is a real bound, else what the arrays hold (the DGL entry points do not know K)
         int64_t Kp = K;
         if (Kp <= 0 || Kp >= 0x7fffffffLL) Kp = (int64_t)fp[3] > M ? (int64_t)fp[3] : M;

@@ -304,9 +304,77 @@ COMMUNITY_SPECS = {
     "reddit-sbm": ("reddit-like", 290, 16, 330.0, 0.6),
 }
 
+# Power-law graphs WITHOUT planted communities — the families the plan's clustering finds least in (ba-m6 runs at 0.13 of
+# the roofline, holme-kim-m16 at 0.07). The hold-out audit (scripts/holdout_graphs.py) takes them from networkx; these are the same
+# models generated on the device so that bench.py can carry them in every record without files: (vertices, edges per new vertex,
+# probability of a triad-formation step).
+PREFERENTIAL_SPECS = {
+    "ba-m6": (500000, 6, 0.0),           # Barabasi-Albert: pure preferential attachment (hubs, clustering ~0)
+    "holme-kim-m16": (400000, 16, 0.6),  # Holme-Kim: preferential attachment + triad formation (triangles, no communities)
+}
+
+
+def preferential_csr(n, m, p_triad=0.0, seed=42, device="cpu", batch=2000):
+    """Growing-network model, batched: vertices arrive `batch` at a time and attach `m` edges each to the graph as it was when their
+    batch began. An edge is a preferential-attachment step — the endpoint of a uniformly drawn earlier half-edge, i.e. a vertex with
+    probability proportional to its degree (Barabasi-Albert) — or, after the first and with probability `p_triad`, a triad-formation
+    step: a uniformly drawn neighbour of the previous target (Holme-Kim, networkx.powerlaw_cluster_graph's model). Returns a
+    symmetric CSR without self loops or repeated entries, vertex ids shuffled by a seeded permutation."""
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed) * 7919 + n + 31 * m)
+    cap = (n + 1) * m + m + 1
+    src = torch.empty(cap, dtype=torch.int64, device=device)
+    dst = torch.empty(cap, dtype=torch.int64, device=device)
+    E = m + 1  # seed graph: a ring over the first m + 1 vertices
+    src[:E] = torch.arange(E, device=device)
+    dst[:E] = (torch.arange(E, device=device) + 1) % E
+    t = m + 1
+    while t < n:
+        b = max(1, min(batch, n - t, t // 32))  # (a batch never outweighs the graph it attaches to: early vertices arrive almost one by one)
+        if p_triad > 0.0:  # adjacency of the graph so far (both directions), for the triad steps
+            s2 = torch.cat([src[:E], dst[:E]])
+            d2 = torch.cat([dst[:E], src[:E]])
+            order = torch.argsort(s2)
+            adj = d2[order]
+            ptr = torch.zeros(t + 1, dtype=torch.int64, device=device)
+            ptr[1:] = torch.cumsum(torch.bincount(s2, minlength=t), 0)
+        nodes = torch.arange(t, t + b, device=device)
+        prev = None
+        for k in range(m):
+            r = torch.randint(0, 2 * E, (b,), generator=gen, device=device)
+            tgt = torch.where(r < E, src[r % E], dst[r % E])
+            if prev is not None and p_triad > 0.0:
+                lo = ptr[prev]
+                deg = ptr[prev + 1] - lo
+                pick = adj[lo + (torch.rand(b, generator=gen, device=device) * deg).long().clamp(max=deg - 1)]
+                tgt = torch.where(torch.rand(b, generator=gen, device=device) < p_triad, pick, tgt)
+            src[E + k * b:E + (k + 1) * b] = nodes
+            dst[E + k * b:E + (k + 1) * b] = tgt
+            prev = tgt
+        E += m * b
+        t += b
+    gperm = torch.Generator(device="cpu")
+    gperm.manual_seed(int(seed) + 1234)
+    perm = torch.randperm(n, generator=gperm).to(device)
+    u, v = perm[src[:E]], perm[dst[:E]]
+    keep = u != v
+    u, v = u[keep], v[keep]
+    key = torch.unique(torch.cat([u * n + v, v * n + u]))  # symmetric, entries once, sorted by (row, column)
+    rows, cols = key // n, key % n
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    return rowptr.to(torch.int32), cols.to(torch.int32)
+
+
 def synthetic_graph(name, seed=42, device="cpu", locality=0.0, band=2000, scale=1.0):
     """One of the named stand-ins. ``scale`` < 1 shrinks M and nnz
     proportionally (CPU-sized tests); scale == 1 reproduces the exact M / nnz."""
+    if name in PREFERENTIAL_SPECS:
+        n, m, p = PREFERENTIAL_SPECS[name]
+        n = max(int(n * scale), 4 * m + 8)
+        rowptr, colind = preferential_csr(n, m, p, seed, device)
+        return {"name": name, "M": n, "K": n, "nnz": int(colind.numel()), "rowptr": rowptr, "colind": colind}
     if name in COMMUNITY_SPECS:
         base, n_comm, n_groups, intra_deg, group_share = COMMUNITY_SPECS[name]
         M, nnz, _, gamma = SPECS[base]

@@ -365,7 +365,7 @@ int gespmm_init(int64_t rows_hint, int64_t nnz_hint, void* stream);
  * keep a small cache (8 entries, least recently used) keyed on (device, rowptr, colind, M, K, N, valued, variant, reducer); the k-th
  * call with one key builds a plan (synchronously), later calls run through it. Pointer identity is not pattern identity: every call
  * that uses a cached plan first fingerprints ALL of rowptr / colind / val on the device (one small kernel + a 32-byte read-back = one
- * stream synchronisation per call — the price of the switch; ~10 us on a com-Amazon-sized graph against ~60 us saved). A pattern
+ * stream synchronisation per call — the price of the switch: ~25 us on a com-Amazon-sized graph, where the plan saves ~60). A pattern
  * changed in place drops the plan, changed values are re-permuted. Never on a capturing stream. Matrices whose analysis keeps the
  * storage order run the plain path without fingerprint from then on. Results: the plain call's bits.
  * k = 0 switches it off and frees the cached plans; gespmm_auto_plan_clear frees them and keeps the switch.

@@ -19,6 +19,8 @@ import torch  # noqa: E402
 
 import gespmm_amd  # noqa: F401,E402
 from gespmm_amd import graphs, spmm  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_ab  # noqa: E402
 
 dev = torch.device("cuda")
 HOLD = os.environ.get("GESPMM_HOLDOUT_DIR", os.path.join(ROOT, "profiles", "r05", "holdout"))
@@ -117,7 +119,7 @@ def main():
             alts = {}
             for order in (True, False):
                 for kern in ("stream", "seg-stream", "staged"):
-                    if kern == "staged" and (N not in (64, 128, 256, 512) or not order):
+                    if kern == "staged" and (N < 32 or not order):  # (round 6: the staged-rows kernel serves every width)
                         continue
                     try:
                         p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=order, kernel=kern, expected_launches=1000000)
@@ -129,8 +131,7 @@ def main():
                         del p2
                         continue
                     t2 = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p2), iters)
-                    ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
-                    note = "" if ok else "BITS-DIFFER"
+                    note = kernel_ab.bits_note(C, ref, rp, ci, val, B).strip()
                     if kern == "staged":
                         note += "(share %s)" % d2.split("staged_entries=")[1].split(" ")[0]
                     alts["%s/%s" % ("clustered" if order else "storage", kern)] = (t2, note)
@@ -141,7 +142,7 @@ def main():
                     p2 = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel=kern, flags=_lib.FLAG_NO_SLAB_BLOCKED, expected_launches=1000000)
                     t2 = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p2), iters)
                     ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
-                    alts["clustered-noslab/%s" % kern] = (t2, ("" if ok else "BITS-DIFFER ") + "(model %s)" % p2.describe().split("l2_model=")[1].split(" ")[0])
+                    alts["clustered-noslab/%s" % kern] = (t2, kernel_ab.bits_note(C, ref, rp, ci, val, B).strip() + " (model %s)" % p2.describe().split("l2_model=")[1].split(" ")[0])
                     del p2
             best_k, best_t = min(((k, v[0]) for k, v in alts.items() if v[0] is not None), key=lambda kv: kv[1])
             best_t = min(best_t, t_plain)
