@@ -124,7 +124,7 @@ class PlanPolicyAnswer(Structure):
 
 
 class AutoPlanStats(Structure):
-    _fields_ = [(n, c_int64) for n in ("calls_planned", "plans_created", "invalidated", "values_refreshed", "fingerprints", "cached_plans")]
+    _fields_ = [(n, c_int64) for n in ("calls_planned", "plans_created", "invalidated", "values_refreshed", "fingerprints", "cached_plans", "calls_async")]
 
 
 class Coo(Structure):

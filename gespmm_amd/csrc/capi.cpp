@@ -47,7 +47,7 @@ namespace gespmm {
 // The one place every SpMM entry point ends up in (plan.cpp included: `pl` carries the plan's task table).
 int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
              int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
-             void* stream, void* ws, int64_t ws_bytes, const PlanLaunch* pl) {
+             void* stream, void* ws, int64_t ws_bytes, const PlanLaunch* pl, const LaunchGuard* guard) {
     const int rc = check_common(rowptr, colind, val, B, C, M, K, N, nnz);
     if (rc != 0) return rc;
     if (M == 0 || N == 0) return 0;
@@ -122,6 +122,13 @@ int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, con
     a.ntasks = pl ? pl->ntasks : 0;
     a.gtasks = pl ? pl->gtasks : nullptr;
     a.ngtasks = pl ? pl->ngtasks : 0;
+    a.guard = guard ? guard->word : nullptr;
+    a.guard_want = guard ? guard->want : 0;
+    // a guard covers ONE kernel: the two streaming kernels without the long-row pass
+    if (guard && (sel.variant == GESPMM_VARIANT_PARREDUCE || sel.variant == GESPMM_VARIANT_NAIVE || sel.geo.slab_blocked ||
+                  sel.geo.split_long_rows))
+        return gespmm::kNotGuardable;
+    if (guard && guard->word == nullptr) return 0;  // dry run (auto_plan.cpp): would this call be one guardable kernel? nothing is launched
 
     hipError_t e;
     a.rpw = sel.geo.rows_per_group;

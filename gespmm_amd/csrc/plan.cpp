@@ -671,7 +671,8 @@ int gespmm_plan_create_v2(gespmm_plan** out, const int32_t* rowptr, const int32_
     return plan_create_impl(out, rowptr, colind, val, M, K, nnz, N, variant, opt ? &o : nullptr, stream);
 }
 
-static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream) {
+static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int reduce, float empty, void* stream,
+                    const gespmm::LaunchGuard* guard = nullptr) {
     if (!p || N < 0) return GESPMM_EINVAL;
     if (reduce == gespmm::kReduceMax && p->valued) return GESPMM_EINVAL;
     gespmm_launch_cfg cfg = {0, 0, 0, 0, 0, p->launch_flags};
@@ -707,7 +708,10 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
-                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, p->stg.slots, 0, nullptr, 0, 0, 0.0f};
+                                 p->stg.nhot, B, C, p->stg.nblocks, p->stg.waves, p->stg.slots, 0, nullptr, 0, 0, 0.0f,
+                                 guard ? guard->word : nullptr, guard ? guard->want : 0};
+        if (guard && p->stg.nlong > 0) return gespmm::kNotGuardable;  // (hub rows take a second launch and the long-row pass)
+        if (guard && guard->word == nullptr) return 0;                 // (dry run: one kernel, guardable)
         hipStream_t hst = reinterpret_cast<hipStream_t>(stream);
         if (sclass == gespmm::kStagedTuned) rc = (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, hst);
         else if (sclass == gespmm::kStagedNarrow) rc = (int)gespmm::launch_spmm_staged_narrow(sa, p->M, p->K, N, hst);
@@ -730,10 +734,10 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         const bool vec4 = use_tuned ? p->tuned_vec == 1 : gespmm::narrow_vec4(facts, p->hits_after, N);
         gespmm::PlanLaunch pl = {p->d_tasks, p->ntasks, p->d_perm, p->d_gtasks, p->ngtasks, seg && !vec4};
         rc = gespmm::run_spmm(p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, B, C, p->M, p->K, N, p->nnz,
-                              vec4 ? GESPMM_VARIANT_CRC_CWM4 : p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl);
+                              vec4 ? GESPMM_VARIANT_CRC_CWM4 : p->variant, &cfg, reduce, empty, stream, ws, ws_bytes, &pl, guard);
     } else {
         rc = gespmm::run_spmm(p->rowptr, p->colind, p->valued ? p->val : nullptr, B, C, p->M, p->K, N, p->nnz, p->variant,
-                              &cfg, reduce, empty, stream, ws, ws_bytes, nullptr);
+                              &cfg, reduce, empty, stream, ws, ws_bytes, nullptr, guard);
     }
     if (rc == 0 && ws) {
         p->split_ready = true;
@@ -986,3 +990,9 @@ void gespmm_plan_destroy(gespmm_plan* p) {
 }
 
 }  // extern "C"
+
+namespace gespmm {
+int plan_spmm_guarded(gespmm_plan* plan, const float* B, float* C, int64_t N, int reduce, float empty, void* stream, const LaunchGuard* guard) {
+    return plan_run(plan, B, C, N, reduce, empty, stream, guard);
+}
+}  // namespace gespmm

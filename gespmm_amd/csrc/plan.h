@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include "../../include/gespmm.h"
+#include "spmm_kernels.h"
 
 namespace gespmm {
 
@@ -17,6 +18,9 @@ struct PlanLaunch {
 
 int run_spmm(const int32_t* rowptr, const int32_t* colind, const float* val, const float* B, float* C, int64_t M,
              int64_t K, int64_t N, int64_t nnz, int variant, const gespmm_launch_cfg* cfg, int reduce, float empty,
-             void* stream, void* ws, int64_t ws_bytes, const PlanLaunch* pl);
+             void* stream, void* ws, int64_t ws_bytes, const PlanLaunch* pl, const LaunchGuard* guard = nullptr);
+// A plan's product behind a launch guard (auto_plan.cpp): kNotGuardable — and nothing launched — when the plan's launch is more than
+// one kernel (hub rows handed to the long-row pass, the cache-blocked path).
+int plan_spmm_guarded(gespmm_plan* plan, const float* B, float* C, int64_t N, int reduce, float empty, void* stream, const LaunchGuard* guard);
 
 }  // namespace gespmm

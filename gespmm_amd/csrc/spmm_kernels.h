@@ -65,7 +65,18 @@ struct SpmmArgs {
     // the same for the segmented-stream kernel, whose unit of work is a lane GROUP: group q works on gtasks[q]
     const int32_t* gtasks;
     int32_t ngtasks;
+    // launch guard (auto_plan.cpp, asynchronous mode): when set, every workgroup first reads *guard and leaves unless it equals guard_want
+    // — a fingerprint kernel earlier on the stream decided whether the cached plan still describes the caller's arrays. NULL: no check.
+    const int32_t* guard;
+    int32_t guard_want;
 };
+
+// A device word + the value a guarded launch runs for (run_spmm / the plan's launch: only paths that are ONE kernel take a guard).
+struct LaunchGuard {
+    const int32_t* word;
+    int32_t want;
+};
+constexpr int kNotGuardable = -100;  // internal: the launch would be several kernels (long-row pass, cache blocking, ...): no guard
 
 // Launch geometry resolved by the host-side selector (select.cpp).
 struct Geometry {
@@ -134,6 +145,8 @@ struct StagedArgs {
     int32_t n;
     int32_t ntiles;
     float empty;
+    const int32_t* guard;  // launch guard, as in SpmmArgs (NULL: no check)
+    int32_t guard_want;
 };
 // Shape of a block at width N: `waves` wavefronts (0 = width not served) own `rows` consecutive rows of the clustered matrix and
 // stage up to `slots` B rows (waves x 4 KB of LDS). GESPMM_STAGED_WAVES / GESPMM_STAGED_ROWS override it for experiments.

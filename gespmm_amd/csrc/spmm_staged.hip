@@ -105,6 +105,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     static_assert(TSHIFT >= 0 && TSHIFT <= 3, "at most one tile per XCD");
     __shared__ f4v s_hot[H * kRowF4];
 
+    if (a.guard != nullptr && *a.guard != a.guard_want) return;  // (guarded launch: spmm_kernels.h — the whole grid, before any barrier)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

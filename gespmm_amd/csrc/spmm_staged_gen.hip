@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kGenWaves * 64, 8) void spmm_staged_gen_kernel(Stag
     using vec_t = typename GenVec<VEC>::type;
     __shared__ vec_t s_hot[H * 64];  // slot s, lane l: s_hot[s * 64 + l] (byte address s << kSlotShift | l * VEC * 4)
 
+    if (a.guard != nullptr && *a.guard != a.guard_want) return;  // (guarded launch: spmm_kernels.h — the whole grid, before any barrier)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void spmm_staged_narrow_kernel(Stage
     static_assert(kStagedPad >= 4 * kNarrowWin, "windows are read whole and three ahead: records past a task's end must be readable");
     __shared__ f4v s_hot[H * W];
 
+    if (a.guard != nullptr && *a.guard != a.guard_want) return;  // (guarded launch: spmm_kernels.h — the whole grid, before any barrier)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;

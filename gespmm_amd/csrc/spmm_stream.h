@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmArgs a) {
     __shared__ int s_ptr[kWaves][kMaxRowsPerWave + 1];
     __shared__ int s_perm[PLANNED ? kWaves : 1][PLANNED ? kMaxRowsPerWave : 1];
 
+    if (a.guard != nullptr && *a.guard != a.guard_want) return;  // (guarded launch: spmm_kernels.h, SpmmArgs::guard — wave-uniform)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane / W;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(kThreads) void spmm_segstream_kernel(SpmmArgs a) {
     __shared__ int s_ptr[kWaves][G][kMaxRowsPerWave + 1];
     __shared__ int s_perm[PLANNED ? kWaves : 1][PLANNED ? G : 1][PLANNED ? kMaxRowsPerWave : 1];
 
+    if (a.guard != nullptr && *a.guard != a.guard_want) return;  // (guarded launch: spmm_kernels.h, SpmmArgs::guard — wave-uniform)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane / W;

@@ -366,7 +366,10 @@ int gespmm_init(int64_t rows_hint, int64_t nnz_hint, void* stream);
  * call with one key builds a plan (synchronously), later calls run through it. Pointer identity is not pattern identity: every call
  * that uses a cached plan first fingerprints ALL of rowptr / colind / val on the device (one small kernel + a 32-byte read-back = one
  * stream synchronisation per call — the price of the switch: ~25 us on a com-Amazon-sized graph, where the plan saves ~60). A pattern
- * changed in place drops the plan, changed values are re-permuted. Never on a capturing stream. Matrices whose analysis keeps the
+ * changed in place drops the plan, changed values are re-permuted. Where the plan's launch and the plain launch are one kernel each (no
+ * long-row pass, no cache blocking) the calls after the plan's creation do not synchronise at all: the fingerprint is compared ON THE
+ * DEVICE, the plan's kernel and the plain kernel are both enqueued behind the result (one of them runs, the other's workgroups leave at
+ * once), and the host learns of a change from a record the check leaves in pinned memory, at the next call. Never on a capturing stream. Matrices whose analysis keeps the
  * storage order run the plain path without fingerprint from then on. Results: the plain call's bits.
  * k = 0 switches it off and frees the cached plans; gespmm_auto_plan_clear frees them and keeps the switch.
  */
@@ -377,6 +380,7 @@ typedef struct gespmm_auto_plan_stats {
     int64_t values_refreshed;  /* gespmm_plan_set_values calls after the values' fingerprint changed */
     int64_t fingerprints;      /* fingerprint passes (= stream synchronisations the switch added) */
     int64_t cached_plans;      /* plans alive now */
+    int64_t calls_async;       /* of calls_planned: launched behind a device-side guard, without any synchronisation (see above) */
 } gespmm_auto_plan_stats;
 int gespmm_set_auto_plan(int32_t kth_call);
 void gespmm_auto_plan_clear(void);

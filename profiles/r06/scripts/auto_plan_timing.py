@@ -58,8 +58,8 @@ for name in names:
             first.append((time.perf_counter() - t0) * 1e6)
         on = wall(fn)
         s1 = _lib.auto_plan_stats()
-        print("  %-24s switch off %.1f us | on: calls 1-4 %s us, then %.1f us per call (planned %d, fingerprints %d, plans %d)" % (
-            label, off, " ".join("%.0f" % t for t in first), on, s1["calls_planned"] - s0["calls_planned"], s1["fingerprints"] - s0["fingerprints"],
+        print("  %-24s switch off %.1f us | on: calls 1-4 %s us, then %.1f us per call (planned %d of them %d without a synchronisation, fingerprints read back %d, plans %d)" % (
+            label, off, " ".join("%.0f" % t for t in first), on, s1["calls_planned"] - s0["calls_planned"], s1["calls_async"] - s0["calls_async"], s1["fingerprints"] - s0["fingerprints"],
             s1["plans_created"] - s0["plans_created"]), flush=True)
     _lib.set_auto_plan(0)
     del g, rp, ci, val, B, C
