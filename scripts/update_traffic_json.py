@@ -28,7 +28,7 @@ for arg in sys.argv[1:]:
         "csrc_sha16": csrc_fingerprint(),
         "source": "%s (2*FETCH_SIZE + WRITE_SIZE, KiB->B; separate --pmc passes of `%s`; memory-side requests include Infinity-Cache hits)"
                   % (os.path.relpath(f, ROOT),
-                     ("python profiles/r03/experiments/narrow_rows_sbm.py %s" % key.split("/N")[1].split("/")[0]) if key.startswith("products-sbm")
+                     ("python scripts/kernel_pmc_case.py products-sbm %s auto 3" % key.split("/N")[1].split("/")[0]) if key.startswith("products-sbm")
                      else "python bench.py --no-extra --no-cpu-baseline --steps 50 --warmup 5 ..."),
     }
     data[key] = entry
