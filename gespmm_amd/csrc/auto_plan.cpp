@@ -201,7 +201,7 @@ hipError_t fingerprint(int dev, const int32_t* rowptr, const int32_t* colind, co
 // knows — the device decides every launch.
 constexpr int kFpCheckBlocks = 256;
 constexpr int kFpCheckSlots = 32;
-unsigned long long* g_fp_async[kAutoDevices] = {nullptr};  // [kFpCheckSlots][4] partial sums + ticket; zero between launches
+constexpr size_t kGuardBytes = 256;  // the guard word's share of an entry's device block; behind it: [kFpCheckSlots][4] partial sums + ticket
 
 __global__ void __launch_bounds__(256) k_fingerprint_check(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                            const float* __restrict__ val, long long M, unsigned long long* __restrict__ slots,
@@ -262,21 +262,19 @@ __global__ void __launch_bounds__(256) k_fingerprint_check(const int32_t* __rest
 
 hipError_t async_setup(AutoEntry& en, int dev) {
     if (dev < 0 || dev >= kAutoDevices) return hipErrorInvalidDevice;
-    constexpr size_t kBytes = ((size_t)kFpCheckSlots * 4 + 1) * 8;
-    if (!g_fp_async[dev]) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_fp_async[dev]), kBytes);
-        if (e == hipSuccess) e = hipMemset(g_fp_async[dev], 0, kBytes);
-        if (e != hipSuccess) return e;
-    }
+    // per ENTRY: guard word + the check's partial sums and ticket (zero between launches: the last workgroup clears them) — two keys on
+    // two streams may have their checks in flight together
+    constexpr size_t kBytes = kGuardBytes + ((size_t)kFpCheckSlots * 4 + 1) * 8;
     if (!en.guard_word) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&en.guard_word), 256);
-        if (e == hipSuccess) e = hipMemset(en.guard_word, 0, 256);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&en.guard_word), kBytes);
+        if (e == hipSuccess) e = hipMemset(en.guard_word, 0, kBytes);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&en.rec), 64, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&en.rec_dev), en.rec, 0);
         if (e != hipSuccess) return e;
         std::memset(en.rec, 0, 64);
     }
-    en.seq_launched = en.seq_seen = 0;
+    // records of checks launched for an earlier plan of this key are history (drop_plan has waited for them): sequence numbers go on
+    en.seq_seen = en.seq_launched;
     return hipSuccess;
 }
 
@@ -376,8 +374,8 @@ bool auto_plan_try(const int32_t* rowptr, const int32_t* colind, const float* va
         }
         if (en->plan && en->async_ok) {
             const unsigned long long seq = ++en->seq_launched;
-            hipLaunchKernelGGL(k_fingerprint_check, dim3(kFpCheckBlocks), dim3(256), 0, st, rowptr, colind, val, (long long)M, g_fp_async[dev],
-                               en->fp_pattern, en->fp_values, (long long)en->nnz, en->guard_word, en->rec_dev, seq);
+            hipLaunchKernelGGL(k_fingerprint_check, dim3(kFpCheckBlocks), dim3(256), 0, st, rowptr, colind, val, (long long)M,
+                               reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(en->guard_word) + kGuardBytes), en->fp_pattern, en->fp_values, (long long)en->nnz, en->guard_word, en->rec_dev, seq);
             if (hipGetLastError() == hipSuccess) {
                 const LaunchGuard run_plan = {en->guard_word, 1}, run_plain = {en->guard_word, 0};
                 int r1 = plan_spmm_guarded(en->plan, B, C, N, reduce, empty, stream, &run_plan);

@@ -106,6 +106,14 @@ def test_planned_from_the_kth_call_same_bits_and_changes_in_place_are_noticed(au
         got = _call(_lib, rp, ci, val, B)
         assert torch.equal(got.view(torch.int32), want.view(torch.int32))
     assert _lib.auto_plan_stats()["cached_plans"] == 1
+    # the second plan of this key is not disturbed by what the checks of the first one left behind
+    made = _lib.auto_plan_stats()["plans_created"]
+    for _ in range(6):
+        got = _call(_lib, rp, ci, val, B)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        torch.cuda.synchronize()
+    st3 = _lib.auto_plan_stats()
+    assert st3["cached_plans"] == 1 and st3["plans_created"] == made and st3["invalidated"] == st2["invalidated"], st3
     _lib.auto_plan_clear()
     assert _lib.auto_plan_stats()["cached_plans"] == 0
 
