@@ -82,6 +82,7 @@ EXPORTS = [
     "gespmm_set_auto_plan",
     "gespmm_auto_plan_clear",
     "gespmm_auto_plan_get_stats",
+    "gespmm_cluster_rows_study",
 ]
 
 PLAN_REORDER_AUTO = 0

@@ -209,6 +209,20 @@ int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M,
     return 0;
 }
 
+// Study hook (scripts/cluster_chain_study.py): the host clustering with its options and the coarsest cluster of every row.
+int gespmm_cluster_rows_study(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int32_t max_levels, int32_t sweeps,
+                              int32_t* perm_out, int32_t* top_label_out, int32_t* clusters_out /* [16] */) {
+    if (M <= 0 || !rowptr || !perm_out) return GESPMM_EINVAL;
+    gespmm::ClusterOptions opt;
+    opt.max_levels = max_levels;
+    opt.sweeps = sweeps;
+    gespmm::ClusterStats st;
+    if (gespmm::cluster_rows(M, K, rowptr, colind, opt, perm_out, &st, top_label_out) != 0) return GESPMM_EINVAL;
+    if (clusters_out)
+        for (int i = 0; i < 16; ++i) clusters_out[i] = st.clusters[i];
+    return st.levels;
+}
+
 double gespmm_simulate_l2_hits(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, const int32_t* perm,
                                int32_t slices, int64_t window_rows) {
     if (M <= 0 || K <= 0 || !rowptr || slices < 1 || window_rows < 1) return 0.0;

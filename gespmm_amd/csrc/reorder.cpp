@@ -164,7 +164,7 @@ inline int32_t heaviest_label(const Adj& a, int64_t node, const int32_t* nbr_lab
 }  // namespace
 
 int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* colind, const ClusterOptions& opt,
-                 int32_t* perm, ClusterStats* stats) {
+                 int32_t* perm, ClusterStats* stats, int32_t* top_labels) {
     if (M < 0 || K < 0 || (M > 0 && (!rowptr || !perm))) return -1;
     if (stats) *stats = ClusterStats{};
     if (M == 0) return 0;
@@ -369,6 +369,10 @@ int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* col
         order.swap(tmp);
     }
     std::memcpy(perm, order.data(), (size_t)M * sizeof(int32_t));
+    if (top_labels) {
+        if (level_labels.empty()) std::iota(top_labels, top_labels + M, 0);
+        else std::memcpy(top_labels, level_labels.back().data(), (size_t)M * sizeof(int32_t));
+    }
     return 0;
 }
 

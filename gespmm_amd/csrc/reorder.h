@@ -20,7 +20,7 @@ struct ClusterStats {
 
 // perm[i] = original row processed at position i. Returns 0, or -1 on bad arguments. All HOST pointers.
 int cluster_rows(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* colind, const ClusterOptions& opt,
-                 int32_t* perm, ClusterStats* stats);
+                 int32_t* perm, ClusterStats* stats, int32_t* top_labels = nullptr /* [M]: coarsest cluster of every row (studies) */);
 
 // Model of the per-XCD L2: rows processed in `perm` order (NULL = storage order), cut into `slices`
 // contiguous parts of equal non-zero count, each with an LRU of `window` B rows. Returns the share of

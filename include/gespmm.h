@@ -393,6 +393,10 @@ int gespmm_auto_plan_get_stats(gespmm_auto_plan_stats* out);
  */
 int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int32_t threads,
                         int32_t* perm_out, int32_t* levels_out, int32_t* clusters_out);
+/* Study hook (scripts/cluster_chain_study.py; HOST pointers): the same clustering with its depth / sweeps given, plus the coarsest
+ * cluster of every row (top_label_out[M], may be NULL). Returns the number of levels built or a negative error. */
+int gespmm_cluster_rows_study(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int32_t max_levels, int32_t sweeps,
+                              int32_t* perm_out, int32_t* top_label_out, int32_t* clusters_out);
 /*
  * Model of the per-XCD L2 used to judge an order (HOST pointers): rows processed in `perm` order (NULL = storage
  * order) in `slices` contiguous parts of equal non-zero count, each with an LRU of `window_rows` B rows; returns
