@@ -23,6 +23,9 @@
  *   gespmm_coo_to_csr        <- inline COO->CSR               spmm_test.cu:557-581
  *   gespmm_row_partition     <- (new; north_star multi-GPU)   no reference counterpart
  *   gespmm_plan_*            <- (new) analysis stage in front of repeated launches; no reference counterpart
+ *   gespmm_init              <- the 200 empty warm-up launches spmm_test.cu:720-721 (same role: start-up cost outside the timed loop)
+ *   gespmm_set_auto_plan / gespmm_auto_plan_* <- (new) plans for callers that keep no state: spmmWrapper spmm_test.cu:456-492,
+ *                               spmm_cuda spmm_kernel.cu:425-458, CustomCsrmm dgl-custom/binary_reduce_sum.cu:338-360
  *   gespmm_cluster_rows / gespmm_simulate_l2_hits <- (new) the plan's host-side row clustering and its L2 model
  *   gespmm_baseline_atomic_scatter_f32 <- Gunrock app's edge map  gunrock-test/app/spmm/spmm_enactor.cuh:92-105
  *   gespmm_baseline_copy_f32 <- (new) streaming-copy yardstick for the roofline record; no reference counterpart
