@@ -83,6 +83,7 @@ EXPORTS = [
     "gespmm_auto_plan_clear",
     "gespmm_auto_plan_get_stats",
     "gespmm_cluster_rows_study",
+    "gespmm_plan_wants_warmup",
 ]
 
 PLAN_REORDER_AUTO = 0
@@ -235,6 +236,8 @@ def _load():
     lib.gespmm_row_partition.argtypes = [p, c_int64, c_int32, p]
     lib.gespmm_init.restype = c_int
     lib.gespmm_init.argtypes = [c_int64, c_int64, p]
+    lib.gespmm_plan_wants_warmup.restype = c_int
+    lib.gespmm_plan_wants_warmup.argtypes = [c_int64, c_int64, c_int64, c_int64, c_int32]
     lib.gespmm_set_auto_plan.restype = c_int
     lib.gespmm_set_auto_plan.argtypes = [c_int32]
     lib.gespmm_auto_plan_clear.restype = None
@@ -276,12 +279,18 @@ def init(rows_hint=0, nnz_hint=0, stream=None):
 _initialised = set()
 
 
-def ensure_init(device_index, stream=None):
-    """gespmm_init once per process and device: the Python layer never builds a plan cold (the ~29 ms of kernel loading and arena
-    allocation belong to start-up, not to the first plan's analysis time — and not to its cost rule)."""
-    if device_index not in _initialised:
-        init(0, 0, stream)
-        _initialised.add(device_index)
+def ensure_init(device_index, stream=None, shape=None, expected_launches=0, forced=False):
+    """gespmm_init once per process and device, before the first plan that could use it: the Python layer never builds such a plan cold
+    (the ~29 ms of kernel loading and arena allocation belong to start-up, not to the first plan's analysis time — and not to its cost
+    rule). `shape` = (M, K, nnz, N) of the plan about to be made: a matrix whose analysis could not pay even when warm (pubmed-sized
+    graphs) keeps its storage order either way, so nothing is warmed up for it (the reference's GCN run on pubmed would otherwise pay
+    ~0.5 ms per epoch for it: profiles/r06/gcn_epochs.log)."""
+    if device_index in _initialised:
+        return
+    if shape is not None and not forced and lib.gespmm_plan_wants_warmup(int(shape[0]), int(shape[1]), int(shape[2]), int(shape[3]), int(expected_launches)) != 1:
+        return
+    init(0, 0, stream)
+    _initialised.add(device_index)
 
 
 def set_auto_plan(kth_call):

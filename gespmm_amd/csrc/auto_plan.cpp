@@ -420,7 +420,7 @@ bool auto_plan_try(const int32_t* rowptr, const int32_t* colind, const float* va
     if (!en->plan) {
         // the caller asked for plans: the first one of the process does not start cold (the analysis kernels are loaded and the arena is
         // made now, once; a cold AUTO plan would price that into its cost rule and decline)
-        if (!analysis_is_warm()) (void)gespmm_init(M, nnz, stream);
+        if (!analysis_is_warm() && gespmm_plan_wants_warmup(M, K > 0 && K < 0x7fffffffLL ? K : M, nnz, N, 0) == 1) (void)gespmm_init(M, nnz, stream);
         // columns: the caller's K where it is a real bound, else what the arrays hold (the DGL entry points do not know K)
         int64_t Kp = K;
         if (Kp <= 0 || Kp >= 0x7fffffffLL) Kp = (int64_t)fp[3] > M ? (int64_t)fp[3] : M;

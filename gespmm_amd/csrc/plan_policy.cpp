@@ -72,6 +72,21 @@ CostEstimate estimate_analysis_cost(const PlanFacts& f) {
     return c;
 }
 
+bool analysis_could_pay(int64_t M, int64_t K, int64_t nnz, int64_t N, int expected_launches) {
+    if (M <= 0 || nnz <= 0 || N <= 0) return false;
+    PlanFacts f;
+    f.M = M;
+    f.K = K;
+    f.nnz = nnz;
+    f.N = N;
+    f.expected_launches = expected_launches;
+    f.wedge_probe = 1.0;  // the most structure a probe can report (hits gain capped at 0.85)
+    f.cold_start = false;
+    const CostEstimate c = estimate_analysis_cost(f);
+    const int launches = expected_launches > 0 ? expected_launches : kDefaultExpectedLaunches;
+    return c.gain_us * (double)launches >= c.cost_us;
+}
+
 AnalysisDecision decide_analysis(const PlanFacts& f) {
     AnalysisDecision a;
     a.launch_flags = long_row_flags(f.M, f.nnz, f.max_degree, f.user_flags);
@@ -321,7 +336,12 @@ constexpr int64_t kQueryBytesV1 = (int64_t)offsetof(gespmm_plan_policy_query, ex
 constexpr int64_t kAnswerBytesV1 = (int64_t)offsetof(gespmm_plan_policy_answer, cost_skipped);
 }  // namespace
 
-extern "C" int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a) {
+extern "C" int gespmm_plan_wants_warmup(int64_t M, int64_t K, int64_t nnz, int64_t N, int32_t expected_launches) {
+    if (M < 0 || K < 0 || nnz < 0 || N < 0 || expected_launches < 0) return GESPMM_EINVAL;
+    return gespmm::analysis_could_pay(M, K, nnz, N, expected_launches) ? 1 : 0;
+}
+
+int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a) {
     return gespmm_plan_policy_v2(q, kQueryBytesV1, a, kAnswerBytesV1);
 }
 

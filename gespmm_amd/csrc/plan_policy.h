@@ -62,6 +62,10 @@ struct AnalysisDecision {
     int64_t model_sample = 0;  // entries per slice the model looks at (0 = all)
 };
 AnalysisDecision decide_analysis(const PlanFacts& f);
+// Could an analysis of a matrix of this shape pay for itself inside `expected_launches` (0 = 200) once the library is warm — with the most
+// structure the probe could report? If not, there is nothing to warm up for: gespmm_init (~60 ms) would be pure cost (pubmed-sized graphs:
+// the reference's GCN run would pay 0.3-0.6 ms per epoch for it).
+bool analysis_could_pay(int64_t M, int64_t K, int64_t nnz, int64_t N, int expected_launches);
 
 // Clustering depth (0 = the library's default of 6 levels). Levels 4-6 merge little and cost ~2 ms of launch latency on a
 // com-Amazon-sized graph; they are worth 4.5 % per launch on the structureless stand-in and nothing on graphs with communities

@@ -127,7 +127,8 @@ class SpmmPlan:
         self._handle = ctypes.c_void_p()
         M, K_, N_, nnz, var = self.shape
         with _on_device(dev):
-            _lib.ensure_init(dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+            _lib.ensure_init(dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev), shape=(M, K_, nnz, N_),
+                             expected_launches=expected_launches, forced=(reorder is True))
             rc = lib.gespmm_plan_create_v2(ctypes.byref(self._handle), _ptr(rowptr), _ptr(colind),
                                            _ptr(values) if values is not None else None, M, K_, nnz, N_, var,
                                            ctypes.byref(opt), ctypes.sizeof(opt), _stream(dev))

@@ -360,6 +360,10 @@ void gespmm_release_cached_memory(void);
  * with reorder = AUTO adds the cold cost to its cost rule (gespmm_plan_policy_query.cold_start).
  */
 int gespmm_init(int64_t rows_hint, int64_t nnz_hint, void* stream);
+/* 1 if an analysis of a matrix of this shape could pay for itself inside `expected_launches` (0 = 200) products once the library is warm
+ * (the cost rule with the most structure a probe can report), else 0: for such a matrix there is nothing to warm up for — a plan keeps
+ * its storage order either way. Host only. The Python layer asks this before it spends gespmm_init's ~60 ms on a pubmed-sized graph. */
+int gespmm_plan_wants_warmup(int64_t M, int64_t K, int64_t nnz, int64_t N, int32_t expected_launches);
 
 /*
  * Plan reuse behind the STATELESS entry points (since 0.3; off by default). The reference's callers keep no state between products

@@ -196,3 +196,15 @@ def test_policy_rejects_bad_queries():
         _lib.plan_policy(-1, 1, 1, 1, 1)
     with pytest.raises(_lib.GespmmError):
         _lib.plan_policy(10, 10, 10, 8, 1, variant=99)
+
+
+def test_warm_up_only_where_an_analysis_could_pay():
+    """gespmm_plan_wants_warmup: the cost rule with the most structure a probe could report. pubmed- and cora-sized graphs cannot pay for
+    an analysis inside 200 launches even when the library is warm — the Python layer then does not spend gespmm_init's ~60 ms on them
+    (profiles/r06/gcn_epochs.log: the reference's GCN run on pubmed regressed by 0.5 ms per epoch while it did) — the headline graph and
+    everything larger can; a long-lived plan changes the answer."""
+    w = lambda M, nnz, N, launches=0: _lib.lib.gespmm_plan_wants_warmup(M, M, nnz, N, launches)
+    assert w(19717, 108365, 128) == 0 and w(2708, 10556, 128) == 0 and w(19717, 108365, 128, 10000) == 1
+    assert w(334863, 1851744, 128) == 1 and w(334863, 1851744, 32) == 0 and w(232965, 114615892, 32) == 1
+    assert _lib.lib.gespmm_plan_wants_warmup(-1, 1, 1, 1, 0) < 0
+
