@@ -213,7 +213,7 @@ int gespmm_cluster_rows(const int32_t* rowptr, const int32_t* colind, int64_t M,
 int gespmm_cluster_rows_study(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K, int32_t max_levels, int32_t sweeps,
                               int32_t* perm_out, int32_t* top_label_out, int32_t* clusters_out /* [16] */) {
     if (M <= 0 || !rowptr || !perm_out) return GESPMM_EINVAL;
-    gespmm::ClusterOptions opt;
+    gespmm::ClusterOptions opt = cluster_options_from_env();
     opt.max_levels = max_levels;
     opt.sweeps = sweeps;
     gespmm::ClusterStats st;

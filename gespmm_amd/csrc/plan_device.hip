@@ -487,14 +487,14 @@ __device__ inline void best_of_group(long long& bt, uint32_t& bh, int& bL) {
     }
 }
 
-// degree <= G: one entry per lane, every lane sums the weights of the lanes that carry its label
+// degree <= G: one entry per lane, every lane sums the weights of the lanes that carry its label. `block` = the workgroup's index
+// inside its degree class (k_lp_small: the four classes of 1..64 entries share ONE launch).
 template <int G, bool ROWS>
-__global__ void __launch_bounds__(256) k_lp_small(LpArgs a) {
-    if (*a.done) return;
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (count * G may exceed 2^31 on forced huge plans)
+__device__ __forceinline__ void lp_small_body(const LpArgs& a, const int32_t* __restrict__ list, int count, long long block) {
+    const long long tid = block * 256 + threadIdx.x;  // (count * G may exceed 2^31 on forced huge plans)
     const int g = (int)(tid / G), l = (int)(tid % G);
-    const bool active = g < *a.count;
-    const int node = active ? a.list[g] : 0;
+    const bool active = g < count;
+    const int node = active ? list[g] : 0;
     const int beg = active ? a.adj.ptr[node] : 0, end = active ? a.adj.ptr[node + 1] : 0;
     const int e = beg + l;
     int L = -1, wt = 0;
@@ -520,6 +520,25 @@ __global__ void __launch_bounds__(256) k_lp_small(LpArgs a) {
     int bL = L;
     best_of_group<G>(bt, bh, bL);
     if (active && l == 0) a.next[node] = (ROWS && sits_out(a, node)) ? own : (bt >= 0 ? bL : own);
+}
+
+// The classes of 1..8, 9..16, 17..32 and 33..64 entries in one launch: workgroups [blk_end[k - 1], blk_end[k]) serve class k.
+// (Round 6: four launches of 5-11 us each per half-sweep, 30 half-sweeps per plan — most of each was its own ramp:
+//  profiles/r06/plan_kernels_before.log. A node's result does not depend on which workgroup computes it.)
+struct LpSmallClasses {
+    const int32_t* lists;   // [kBins][n_side]
+    const int32_t* counts;  // [kBins] (device)
+    int n_side;
+    int blk_end[4];
+};
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_lp_small(LpArgs a, LpSmallClasses c) {
+    if (*a.done) return;
+    const int b = (int)blockIdx.x;
+    if (b < c.blk_end[0]) lp_small_body<8, ROWS>(a, c.lists, c.counts[0], b);
+    else if (b < c.blk_end[1]) lp_small_body<16, ROWS>(a, c.lists + (int64_t)c.n_side, c.counts[1], b - c.blk_end[0]);
+    else if (b < c.blk_end[2]) lp_small_body<32, ROWS>(a, c.lists + 2 * (int64_t)c.n_side, c.counts[2], b - c.blk_end[1]);
+    else lp_small_body<64, ROWS>(a, c.lists + 3 * (int64_t)c.n_side, c.counts[3], b - c.blk_end[2]);
 }
 
 // 64 < degree <= 2048: one wavefront per node, label -> weight in an LDS hash table
@@ -1173,6 +1192,9 @@ struct DLevel {
 };
 
 // transposed adjacency: stable sort of the entries by column node keeps the row nodes ascending inside a column
+// (round 6: counts + one atomic per entry instead of the sort — the order inside a column is free — measured 0.15 ms less per plan
+//  on the headline graph, 39 + 52 us of atomics per level against three radix passes; not kept: a hub column serialises its atomics,
+//  the sort does not care. profiles/r06/plan_kernels_fused.log)
 hipError_t build_cols(Scratch& sc, DLevel& lv, const int32_t* n_of /* nullptr: rows.ptr decides (level 0) */,
                       hipStream_t st) {
     const int64_t E = lv.E;
@@ -1210,16 +1232,25 @@ hipError_t launch_half_sweep(const LpArgs& base, const int32_t* lists, const int
                              const int32_t* counts_host, int n_side, unsigned long long* acc, int acc_wgs,
                              int64_t nlabels, hipStream_t st) {
     LpArgs a = base;
-    for (int b = 0; b < kBins; ++b) {
+    {
+        LpSmallClasses c;
+        c.lists = lists;
+        c.counts = counts_dev;
+        c.n_side = n_side;
+        int64_t blocks = 0;
+        for (int b = 0; b < 4; ++b) {
+            blocks += ((int64_t)counts_host[b] * (8 << b) + 255) / 256;
+            if (blocks > 0x7fffffff) return hipErrorInvalidValue;  // (2^31 workgroups of 256 lanes: no matrix with 32-bit positions gets there)
+            c.blk_end[b] = (int)blocks;
+        }
+        if (blocks > 0) hipLaunchKernelGGL((k_lp_small<ROWS>), dim3((unsigned)blocks), dim3(256), 0, st, a, c);
+    }
+    for (int b = 4; b < kBins; ++b) {
         const int cnt = counts_host[b];
         if (cnt == 0) continue;
         a.list = lists + (int64_t)b * n_side;
         a.count = counts_dev + b;
-        if (b == 0) hipLaunchKernelGGL((k_lp_small<8, ROWS>), dim3(grid_for((int64_t)cnt * 8)), dim3(256), 0, st, a);
-        else if (b == 1) hipLaunchKernelGGL((k_lp_small<16, ROWS>), dim3(grid_for((int64_t)cnt * 16)), dim3(256), 0, st, a);
-        else if (b == 2) hipLaunchKernelGGL((k_lp_small<32, ROWS>), dim3(grid_for((int64_t)cnt * 32)), dim3(256), 0, st, a);
-        else if (b == 3) hipLaunchKernelGGL((k_lp_small<64, ROWS>), dim3(grid_for((int64_t)cnt * 64)), dim3(256), 0, st, a);
-        else if (b == 4) hipLaunchKernelGGL((k_lp_wave<ROWS>), dim3((unsigned)cnt), dim3(64), 0, st, a);
+        if (b == 4) hipLaunchKernelGGL((k_lp_wave<ROWS>), dim3((unsigned)cnt), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_lp_dense<ROWS>), dim3((unsigned)std::min(cnt, acc_wgs)), dim3(256), 0, st, a, acc, nlabels);
     }
     return hipGetLastError();
