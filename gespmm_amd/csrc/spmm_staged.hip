@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
         uint32_t t;
         const uint32_t r0 = (uint32_t)(cv[0] >> 32), r1 = (uint32_t)(cv[1] >> 32), r2 = (uint32_t)(cv[2] >> 32), r3 = (uint32_t)(cv[3] >> 32);
         if constexpr (VEC == 2) {
-#define GESPMM_END2(R) "v_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1\n\tv_mov_b64 %[a], 0\n\t"
+#define GESPMM_END2(R) "v_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1 nt\n\tv_mov_b64 %[a], 0\n\t"
             asm volatile(
                 "s_bitcmp1_b32 %[e], 0\n\ts_cbranch_scc1 10f\n\t" GESPMM_FMA2("%[a]", "%[c0]", "%[b0]") "\n11:\n\t"
                 "s_bitcmp1_b32 %[e], 1\n\ts_cbranch_scc1 20f\n\t" GESPMM_FMA2("%[a]", "%[c1]", "%[b1]") "\n21:\n\t"
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
                 bh[j] = __builtin_shufflevector(b[j], b[j], 2, 3);
             }
             // (one 16-byte store per lane; TWO wait states before the stored registers are overwritten — a store wider than 8 bytes reads its data late, gfx940+: a single one let the zeros through now and then, cora at N = 1024)
-#define GESPMM_STORE4(BASE) "global_store_dwordx4 %[t], v[60:63], " BASE " sc1\n\ts_nop 1\n\tv_mov_b64 v[60:61], 0\n\tv_mov_b64 v[62:63], 0\n\t"
+#define GESPMM_STORE4(BASE) "global_store_dwordx4 %[t], v[60:63], " BASE " sc1 nt\n\ts_nop 1\n\tv_mov_b64 v[60:61], 0\n\tv_mov_b64 v[62:63], 0\n\t"
 #define GESPMM_ROWS4(END)                                                                                                                  \
     "s_bitcmp1_b32 %[e], 0\n\ts_cbranch_scc1 10f\n\t" GESPMM_FMA2("v[60:61]", "%[c0]", "%[b0]") GESPMM_FMA2("v[62:63]", "%[c0]", "%[h0]") "\n11:\n\t" \
     "s_bitcmp1_b32 %[e], 1\n\ts_cbranch_scc1 20f\n\t" GESPMM_FMA2("v[60:61]", "%[c1]", "%[b1]") GESPMM_FMA2("v[62:63]", "%[c1]", "%[h1]") "\n21:\n\t" \

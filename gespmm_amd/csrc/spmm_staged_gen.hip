@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kGenWaves * 64, 8) void spmm_staged_gen_kernel(Stag
         const uint32_t r0 = h0 * n4, r1 = h1 * n4, r2 = h2 * n4, r3 = h3 * n4;
         uint32_t t;
         if constexpr (VEC == 1) {
-#define GESPMM_G_END1(R) "v_add_u32 %[t], " R ", %[lo]\n\ts_mov_b64 exec, %[am]\n\tglobal_store_dword %[t], %[a], %[C] sc1\n\ts_mov_b64 exec, -1\n\tv_mov_b32 %[a], 0\n\t"
+#define GESPMM_G_END1(R) "v_add_u32 %[t], " R ", %[lo]\n\ts_mov_b64 exec, %[am]\n\tglobal_store_dword %[t], %[a], %[C] sc1 nt\n\ts_mov_b64 exec, -1\n\tv_mov_b32 %[a], 0\n\t"
             asm volatile(GESPMM_G_ROWS4("v_fma_f32 %[a], %[h0], %[b0], %[a]\n\t", "v_fma_f32 %[a], %[h1], %[b1], %[a]\n\t",
                                         "v_fma_f32 %[a], %[h2], %[b2], %[a]\n\t", "v_fma_f32 %[a], %[h3], %[b3], %[a]\n\t", GESPMM_G_END1)
                          : [a] "+v"(acc), [t] "=&v"(t)
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kGenWaves * 64, 8) void spmm_staged_gen_kernel(Stag
                          : "memory", "scc");
 #undef GESPMM_G_END1
         } else if constexpr (VEC == 2) {
-#define GESPMM_G_END2(R) "v_add_u32 %[t], " R ", %[lo]\n\ts_mov_b64 exec, %[am]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1\n\ts_mov_b64 exec, -1\n\tv_mov_b64 %[a], 0\n\t"
+#define GESPMM_G_END2(R) "v_add_u32 %[t], " R ", %[lo]\n\ts_mov_b64 exec, %[am]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1 nt\n\ts_mov_b64 exec, -1\n\tv_mov_b64 %[a], 0\n\t"
             asm volatile(GESPMM_G_ROWS4(GESPMM_G_FMA2("%[a]", "%[c0]", "%[b0]"), GESPMM_G_FMA2("%[a]", "%[c1]", "%[b1]"),
                                         GESPMM_G_FMA2("%[a]", "%[c2]", "%[b2]"), GESPMM_G_FMA2("%[a]", "%[c3]", "%[b3]"), GESPMM_G_END2)
                          : [a] "+v"(acc), [t] "=&v"(t)
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kGenWaves * 64, 8) void spmm_staged_gen_kernel(Stag
             }
             // (one 16-byte store per lane; a store wider than 8 bytes reads its data late: two wait states before the registers are zeroed)
 #define GESPMM_G_END4(R)                                                                                                              \
-    "v_add_u32 %[t], " R ", %[lo]\n\ts_mov_b64 exec, %[am]\n\tglobal_store_dwordx4 %[t], v[60:63], %[C] sc1\n\ts_mov_b64 exec, -1\n\t" \
+    "v_add_u32 %[t], " R ", %[lo]\n\ts_mov_b64 exec, %[am]\n\tglobal_store_dwordx4 %[t], v[60:63], %[C] sc1 nt\n\ts_mov_b64 exec, -1\n\t" \
     "s_nop 1\n\tv_mov_b64 v[60:61], 0\n\tv_mov_b64 v[62:63], 0\n\t"
             asm volatile(GESPMM_G_ROWS4(GESPMM_G_FMA2("v[60:61]", "%[c0]", "%[b0]") GESPMM_G_FMA2("v[62:63]", "%[c0]", "%[g0]"),
                                         GESPMM_G_FMA2("v[60:61]", "%[c1]", "%[b1]") GESPMM_G_FMA2("v[62:63]", "%[c1]", "%[g1]"),
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kGenWaves * 64, 8) void spmm_staged_gen_kernel(Stag
         for (int j = 0; j < U; ++j) {
             if ((ends >> j) & 1u) {
                 const uint32_t crow = (uint32_t)(cv[j] >> 32);
-                if (active) *reinterpret_cast<vec_t*>(reinterpret_cast<char*>(Cp) + (size_t)crow * n4 + loff_g) = acc;
+                if (active) __builtin_nontemporal_store(acc, reinterpret_cast<vec_t*>(reinterpret_cast<char*>(Cp) + (size_t)crow * n4 + loff_g));
                 arm();
             } else {
                 fma_row(cv[j], b[j]);

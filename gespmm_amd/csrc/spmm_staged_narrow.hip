@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void spmm_staged_narrow_kernel(Stage
                 "s_mov_b64 exec, %[em]\n\t"
                 "s_cbranch_execz 1f\n\t"
                 "v_lshl_add_u32 %[t], %[v], %[sh], %[lo]\n\t"
-                "global_store_dwordx4 %[t], v[60:63], %[C]\n\t"
+                "global_store_dwordx4 %[t], v[60:63], %[C] sc1 nt\n\t"
                 "s_nop 1\n\t"
                 "v_mov_b32 v60, 0\n\tv_mov_b32 v61, 0\n\tv_mov_b32 v62, 0\n\tv_mov_b32 v63, 0\n"
                 "1:\n\t"
