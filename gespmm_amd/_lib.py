@@ -95,6 +95,7 @@ PLAN_KERNEL_AUTO = 0
 PLAN_KERNEL_STREAM = 1
 PLAN_KERNEL_SEG_STREAM = 3
 PLAN_KERNEL_STAGED = 5
+PLAN_KERNEL_RECORDS = 6
 
 
 class LaunchCfg(Structure):

@@ -83,6 +83,9 @@ struct gespmm_plan {
     // staged-rows kernel (spmm_staged.hip): tables for width N (plan_device.hip: device_build_staging)
     gespmm::StagingTables stg;
     double staging_seconds = 0.0;
+    // padded-record kernel (spmm_records.hip): tables for width N (narrow widths, short rows)
+    gespmm::RecordTables rec;
+    double records_seconds = 0.0;
     // gespmm_plan_tune: measured kernel times on the caller's operands (us; < 0: candidate not available)
     // The measurement is valid for the plan's own width only: launches at p->N take tuned_kernel / tuned_vec, every other width keeps
     // the per-launch rules of plan_policy.cpp (kernel_choice stays what the creator asked for).
@@ -90,7 +93,8 @@ struct gespmm_plan {
     int tuned_kernel = 0;  // GESPMM_PLAN_KERNEL_* that won (valid while `tuned`)
     int tuned_vec = 0;     // 1: the winner is the batch-stream kernel with 4 floats per lane (N <= 64)
     bool staging_kept_by_policy = false;  // keep_staged_tables() said yes at creation (else the tables exist only while tune measures them / if they won)
-    double tune_us[4] = {-1.0, -1.0, -1.0, -1.0};  // batch-stream, segmented-stream, staged-rows, batch-stream with 4 floats per lane (N <= 64)
+    double tune_us[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};  // batch-stream, segmented-stream, staged-rows, batch-stream with 4 floats per lane (N <= 64), padded records
+    bool records_kept_by_policy = false;  // want_record_tables() / keep_record_tables() said yes at creation (else the tables exist only while tune measures them / if they won)
 };
 
 namespace {
@@ -143,6 +147,7 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 
 void free_device(gespmm_plan* p) {
     gespmm::free_staging(&p->stg);
+    gespmm::free_records(&p->rec);
     if (p->gtasks_shared) p->d_gtasks = nullptr;
     if (p->d_block) {  // the permuted copy is one block
         (void)hipFree(p->d_block);
@@ -330,6 +335,24 @@ static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
     return e;
 }
 
+static double record_slot_fill(const gespmm_plan* p) {  // share of the entry slots of the batches that carry an entry
+    if (!p->rec.batches || p->rec.nbatches <= 0) return 0.0;
+    return (double)p->nnz / ((double)p->rec.nbatches * (64 / p->rec.group) * gespmm::kRecordPiece);
+}
+
+// Tables of the padded-record kernel (spmm_records.hip) for the plan's width: the matrix in the order the plan processes it (its
+// clustered copy, or the caller's arrays when the storage order was kept).
+static hipError_t build_record_tables(gespmm_plan* p, hipStream_t st) {
+    const auto ts = std::chrono::steady_clock::now();
+    static const int env_rows = getenv("GESPMM_REC_ROWS") ? atoi(getenv("GESPMM_REC_ROWS")) : 0;
+    const int rows = env_rows > 0 ? env_rows : gespmm::records_rows_per_task(p->facts);
+    const hipError_t e = gespmm::device_build_records(p->M, p->reordered ? p->d_rowptr : p->rowptr, p->reordered ? p->d_colind : p->colind,
+                                                      p->valued ? (p->reordered ? p->d_val : p->val) : nullptr,
+                                                      p->reordered ? p->d_perm : nullptr, rows, p->N, &p->rec, st);
+    p->records_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+    return e;
+}
+
 // gespmm_plan_create_v2: `opt_bytes` = sizeof(gespmm_plan_options) as the CALLER was compiled with; fields beyond it take
 // their defaults, bytes beyond what this library knows are ignored (gespmm.h, "Plan options and versions").
 static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int32_t* colind, const float* val, int64_t M,
@@ -345,7 +368,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
     if (reorder_mode < 0 || reorder_mode > 2) return GESPMM_EINVAL;
     const int kernel_mode = opt ? opt->kernel : GESPMM_PLAN_KERNEL_AUTO;
     if (kernel_mode != GESPMM_PLAN_KERNEL_AUTO && kernel_mode != GESPMM_PLAN_KERNEL_STREAM && kernel_mode != GESPMM_PLAN_KERNEL_SEG_STREAM &&
-        kernel_mode != GESPMM_PLAN_KERNEL_STAGED)
+        kernel_mode != GESPMM_PLAN_KERNEL_STAGED && kernel_mode != GESPMM_PLAN_KERNEL_RECORDS)
         return GESPMM_EINVAL;
     if (opt && opt->expected_launches < 0) return GESPMM_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -661,6 +684,24 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         delete p;
         return GESPMM_ENOMEM;
     }
+    // ---- padded-record kernel (narrow widths, short rows): when asked for, or when the policy says so (plan_policy.cpp)
+    if (gespmm::records_serves(M, K, N, p->max_degree) && nnz > 0 && gespmm::want_record_tables(p->facts, p->reordered, p->hits_after) &&
+        !(p->stg.ev && p->staging_kept_by_policy)) {
+        e = build_record_tables(p, st);
+        if (e == hipErrorOutOfMemory) {  // (padding beyond the cap, or no memory: the other kernels serve the plan)
+            gespmm::free_records(&p->rec);
+            (void)hipGetLastError();
+            e = hipSuccess;
+        }
+        if (e == hipSuccess && p->rec.batches && !gespmm::keep_record_tables(p->facts, record_slot_fill(p)))
+            gespmm::free_records(&p->rec);  // too much padding (rows of very different lengths share tasks): the other kernels stay
+        p->records_kept_by_policy = p->rec.batches != nullptr;
+        if (e != hipSuccess) {
+            free_device(p);
+            delete p;
+            return (int)e;
+        }
+    }
     p->analysis_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (p->reordered || p->hits_after >= 0.0) gespmm::mark_analysis_warm();  // (the analysis passes ran: their kernels are loaded now)
     *out = p;
@@ -719,6 +760,13 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
                                    : ((kchoice == GESPMM_PLAN_KERNEL_AUTO && p->staging_kept_by_policy) || kchoice == GESPMM_PLAN_KERNEL_STAGED)) &&
                         (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    // padded-record kernel: the tables exist (plan's width), sum reducer, 16-byte operands
+    if (p->rec.batches && N == p->N && reduce == gespmm::kReduceSum && variant_v4 && !(use_tuned && kchoice != GESPMM_PLAN_KERNEL_RECORDS) &&
+        (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !(staged && kchoice == GESPMM_PLAN_KERNEL_STAGED)) {
+        if (!B || !C) return GESPMM_EINVAL;
+        if (guard && guard->word == nullptr) return 0;  // (dry run: one kernel, guardable)
+        return (int)gespmm::launch_spmm_records(p->rec, B, C, N, p->launch_flags, guard, reinterpret_cast<hipStream_t>(stream));
+    }
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
@@ -794,22 +842,33 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
             return (int)e;
         }
     }
+    if (!p->rec.batches && v4 && p->nnz > 0 && gespmm::records_serves(p->M, p->K, p->N, p->max_degree)) {
+        e = build_record_tables(p, st);  // (built for the occasion too)
+        if (e != hipSuccess) {
+            gespmm::free_records(&p->rec);
+            (void)hipGetLastError();
+            e = hipSuccess;
+        }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e != hipSuccess) {
         if (e0) (void)hipEventDestroy(e0);
         if (!p->staging_kept_by_policy) gespmm::free_staging(&p->stg);
+        if (!p->records_kept_by_policy) gespmm::free_records(&p->rec);
         return (int)e;
     }
-    const int cand[4] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STREAM};
+    const int cand[5] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STREAM,
+                         GESPMM_PLAN_KERNEL_RECORDS};
     const bool was_tuned = p->tuned;
     const int was_kernel = p->tuned_kernel, was_vec = p->tuned_vec;
     int best = -1, rc = 0;
     p->tuned = true;  // (plan_run below launches the candidate through the tuned path)
-    for (int c = 0; c < 4 && rc == 0; ++c) {
+    for (int c = 0; c < 5 && rc == 0; ++c) {
         p->tune_us[c] = -1.0;
         if (c == 1 && !p->d_gtasks) continue;
+        if (c == 4 && !(p->rec.batches && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0)) continue;
         if (c == 2 && !(p->stg.ev && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && v4)) continue;
         if (c == 3 && !(p->variant == GESPMM_VARIANT_AUTO && N <= 64 && N % 4 == 0)) continue;
         p->tuned_kernel = cand[c];
@@ -834,6 +893,7 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
         p->tuned_kernel = was_kernel;
         p->tuned_vec = was_vec;
         if (!p->staging_kept_by_policy && !(was_tuned && was_kernel == GESPMM_PLAN_KERNEL_STAGED)) gespmm::free_staging(&p->stg);
+        if (!p->records_kept_by_policy && !(was_tuned && was_kernel == GESPMM_PLAN_KERNEL_RECORDS)) gespmm::free_records(&p->rec);
         return rc;
     }
     p->tuned_kernel = cand[best];
@@ -843,6 +903,10 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     if (best != 2 && p->stg.ev) {
         gespmm::free_staging(&p->stg);
         p->staging_kept_by_policy = false;
+    }
+    if (best != 4 && p->rec.batches) {
+        gespmm::free_records(&p->rec);
+        p->records_kept_by_policy = false;
     }
     if (best != 2) rc = plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);  // (C is the winner's product either way: same bits)
     return rc;
@@ -916,10 +980,15 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     if (!p->reordered) {
         p->val = val;
         p->valued = val != nullptr;
+        if (p->rec.batches) return (int)gespmm::device_records_set_values(p->rec, p->M, p->rowptr, p->colind, val, st);
         return 0;
     }
     if (!val) {
         p->valued = false;
+        if (p->rec.batches) {
+            const hipError_t er = gespmm::device_records_set_values(p->rec, p->M, p->d_rowptr, p->d_colind, nullptr, st);
+            if (er != hipSuccess) return (int)er;
+        }
         if (p->stg.ev) return (int)gespmm::device_staging_set_values(p->stg, nullptr, p->d_rowptr, p->M, p->nnz, st);  // the stream carries 1.0f
         return 0;
     }
@@ -934,6 +1003,10 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
     if (p->stg.ev) {
         const hipError_t es = gespmm::device_staging_set_values(p->stg, p->d_val, p->d_rowptr, p->M, p->nnz, st);
         if (es != hipSuccess) return (int)es;
+    }
+    if (p->rec.batches) {
+        const hipError_t er = gespmm::device_records_set_values(p->rec, p->M, p->d_rowptr, p->d_colind, p->d_val, st);
+        if (er != hipSuccess) return (int)er;
     }
     return (int)hipGetLastError();
 }
@@ -971,10 +1044,14 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
                      p->stg.nblocks, gespmm::staged_shape_any(p->N).slots, p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
+        if (p->rec.batches && !(p->tuned && p->tuned_kernel != GESPMM_PLAN_KERNEL_RECORDS) && !(staged_d && p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED))
+            snprintf(kern, sizeof kern, "kernel=padded-records tasks=%d rows_per_task=%d batches=%d slot_fill=%.3f tables=%.4fs (max / other widths: %s)",
+                     p->rec.ntasks, p->rec.rows_per_task, p->rec.nbatches,
+                     record_slot_fill(p), p->records_seconds, what);
         char tuned[200] = "";
         if (p->tuned)
-            snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f batch-stream-V4=%.1f]", p->tune_us[0],
-                     p->tune_us[1], p->tune_us[2], p->tune_us[3]);
+            snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f batch-stream-V4=%.1f padded-records=%.1f]",
+                     p->tune_us[0], p->tune_us[1], p->tune_us[2], p->tune_us[3], p->tune_us[4]);
         n = snprintf(out, (size_t)capacity,
                      "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d probe=%.3f l2_model=%.3f->%.3f "
                      "analysis=%.4fs on the %s (clustering %.4fs)%s | %s",
@@ -986,8 +1063,13 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             snprintf(why, sizeof why, " (analysis skipped: est. gain %.1f us x %d launches < est. cost %.0f us; wedge probe %.4f)", p->est_gain_us,
                      p->facts.expected_launches > 0 ? p->facts.expected_launches : gespmm::kDefaultExpectedLaunches, p->est_cost_us,
                      p->facts.wedge_probe);
+        char kern[420];
+        if (p->rec.batches)
+            snprintf(kern, sizeof kern, "kernel=padded-records tasks=%d rows_per_task=%d batches=%d tables=%.4fs (max / other widths: %s)", p->rec.ntasks,
+                     p->rec.rows_per_task, p->rec.nbatches, p->records_seconds, what);
+        else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.4fs%s | %s",
-                     p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, why, what);
+                     p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, why, kern);
     }
     if (n < 0) return GESPMM_EINVAL;
     return n < capacity ? n : (int)capacity - 1;

@@ -271,6 +271,35 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
 // 91.8 / 91.3 / 88.0 / 88.6, LFR mu = 0.1 (16) 177.7 / 176.5 / 170.1 / 168.9, geometric and small-world (11-12) flat, products-shaped
 // (50) 2792 / 2789 / 2880 / 2901; 256-column tiles at 48 / 64 / 80 rows: com-Amazon-shaped 180.8 / 175.3 / 176.5, geometric 341.9 /
 // 335.6 / 341.8, products-shaped 5271 / 5502 / 5600. Short rows want more of them per block, long rows fewer.
+// Padded-record kernel (spmm_records.hip): asked for by name, or (AUTO) where it was measured ahead of the streaming kernels and the
+// lane-group staged kernel — profiles/r06/records_audit_before_rule.log, time AUTO-before / records on the clustered order:
+//   com-Amazon-shaped communities (mean degree 5.5, modelled hits 0.67-0.69): N = 16 x1.23, N = 32 x1.25, N = 64 x1.08
+//   N = 16 at any mean degree: products-shaped communities (mean 50) x1.20, geometric (12) x1.87, small-world (11) x1.67
+//   N = 32 / 64 with rows of 10+ entries: level with or behind the lane-group staged kernel (x0.99 / x0.83 products-shaped, x0.99 / x0.76
+//     geometric, x0.92 / x0.71 small-world) — its tables are kept there, and these are not built
+//   LFR (mean degree 16, longest row 306: rows of very different lengths share a task, 28-46 % of the slots filled): x0.86 / x0.96 / x0.95
+//     at mu = 0.1, x0.78 / x0.94 / x0.86 at mu = 0.3 — keep_record_tables drops them by their slot fill
+//   an order that does not hit L2 (structureless graph, modelled 0.19-0.28): x0.66-0.84; the storage order of a scrambled graph: level
+//     with the plain call. Hence: clustered order kept and modelled at >= 0.60 hits.
+bool want_record_tables(const PlanFacts& f, bool reordered, double hits_after) {
+    if (f.kernel_choice == GESPMM_PLAN_KERNEL_RECORDS) return true;
+    if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO || f.variant != GESPMM_VARIANT_AUTO) return false;
+    if (!reordered || hits_after < 0.60 || f.nnz < (1 << 20) || f.M <= 0) return false;
+    return f.N <= 16 || (double)f.nnz / (double)f.M <= 8.0;
+}
+
+// ... and kept when enough of their slots carry an entry: com-Amazon-shaped 0.41 (N = 16) / 0.50 (32) / 0.58 (64) win, LFR 0.28 / 0.46
+// lose (the same log). N <= 16 deals rows to 16 chains and wins from a lower fill.
+bool keep_record_tables(const PlanFacts& f, double slot_fill) {
+    if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return true;
+    return slot_fill >= (f.N <= 16 ? 0.38 : 0.48);
+}
+
+int records_rows_per_task(const PlanFacts& f) {
+    (void)f;
+    return 16;
+}
+
 int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves) {
     const int sclass = staged_kernel_class(f.M, f.K, f.N);
     if (shape_waves != kStagedMaxWaves || (sclass != kStagedTuned && sclass != kStagedGeneral)) return shape_rows;  // (narrow widths, experiment shapes)
@@ -363,7 +392,7 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     if (q->variant < GESPMM_VARIANT_AUTO || q->variant >= GESPMM_NUM_VARIANTS || q->reorder < 0 || q->reorder > 2) return GESPMM_EINVAL;
     // the kernel values gespmm_plan_create accepts (2 and 4 belonged to the removed opt-in kernels)
     if (q->kernel != GESPMM_PLAN_KERNEL_AUTO && q->kernel != GESPMM_PLAN_KERNEL_STREAM && q->kernel != GESPMM_PLAN_KERNEL_SEG_STREAM &&
-        q->kernel != GESPMM_PLAN_KERNEL_STAGED)
+        q->kernel != GESPMM_PLAN_KERNEL_STAGED && q->kernel != GESPMM_PLAN_KERNEL_RECORDS)
         return GESPMM_EINVAL;
     if (q->analysis != GESPMM_PLAN_ANALYSIS_DEVICE && q->analysis != GESPMM_PLAN_ANALYSIS_HOST) return GESPMM_EINVAL;
     gespmm::PlanFacts f;

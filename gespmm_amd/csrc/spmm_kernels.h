@@ -198,6 +198,46 @@ inline int staged_tasks_per_block(int64_t N) {
 }
 inline bool staged_serves_any(int64_t M, int64_t K, int64_t N) { return staged_kernel_class(M, K, N) != kStagedNone; }
 
+// spmm_records.hip — the padded-record kernel (round 6): narrow widths (N <= 64, N % 4 == 0), short rows, sum reducer, plans only. A row
+// is cut into pieces of kRecordPiece padded entry slots; a wavefront is 64 / W chains (W = records_group(N) lanes each) and consumes one
+// BATCH = one piece per chain per step (headers + entries: one coalesced load per lane), a task = `rows_per_task` consecutive rows dealt
+// to the chains. Offsets into B / C are pre-multiplied 32-bit byte offsets.
+constexpr int kRecordPiece = 8;
+constexpr int kRecordMaxRow = 1024;                // longer rows would pad the other chains of their task for too long
+constexpr int64_t kRecordMaxBytes = 1ll << 34;     // of batches
+struct RecordTables {
+    void* block = nullptr;     // tasks + batches
+    void* side = nullptr;      // slot + first (kept for gespmm_plan_set_values)
+    int32_t* tasks = nullptr;  // ntasks int2 {first batch, #batches}
+    char* batches = nullptr;
+    int32_t* slot = nullptr;   // per row: first piece position inside its task * 16 + chain
+    int32_t* first = nullptr;  // per task: first batch (ntasks + 1)
+    int32_t ntasks = 0;
+    int32_t nbatches = 0;
+    int32_t rows_per_task = 0;
+    int32_t group = 0;         // W
+    int64_t N = 0;
+};
+struct RecordArgs {
+    const int32_t* tasks;
+    const char* batches;
+    const float* B;
+    float* C;
+    int32_t ntasks;
+    int32_t n;
+    const int32_t* guard;  // launch guard, as in SpmmArgs (NULL: no check)
+    int32_t guard_want;
+};
+int records_group(int64_t N);  // lanes per chain at width N (0: width not served)
+bool records_serves(int64_t M, int64_t K, int64_t N, int32_t max_degree);
+// rowptr / colind / val: the matrix in the order its rows are processed (val NULL: 1.0f); perm: C row of row i (NULL: i)
+hipError_t device_build_records(int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val, const int32_t* perm,
+                                int rows_per_task, int64_t N, RecordTables* out, hipStream_t st);
+hipError_t device_records_set_values(const RecordTables& t, int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val,
+                                     hipStream_t st);
+void free_records(RecordTables* t);
+hipError_t launch_spmm_records(const RecordTables& t, const float* B, float* C, int64_t N, int flags, const LaunchGuard* guard, hipStream_t st);
+
 // sddmm_kernels.hip
 constexpr int kSddmmNoSlab = 1;  // launch_sddmm flag: never take the cache-blocked CSR form
 hipError_t launch_sddmm(const int32_t* rowind_or_rowptr, bool csr, const int32_t* colind,

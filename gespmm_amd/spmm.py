@@ -121,7 +121,7 @@ class SpmmPlan:
         self.device = dev
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
         kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM,
-                "staged": _lib.PLAN_KERNEL_STAGED}[kernel]
+                "staged": _lib.PLAN_KERNEL_STAGED, "records": _lib.PLAN_KERNEL_RECORDS}[kernel]
         where = {"device": _lib.PLAN_ANALYSIS_DEVICE, "host": _lib.PLAN_ANALYSIS_HOST}[analysis]
         opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where, int(expected_launches))
         self._handle = ctypes.c_void_p()

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Padded-record kernel (spmm_records.hip) against the plan's AUTO choice at narrow widths: rows per task, nt stores, clustered / storage
+order; bits compared with the plain call.
+    GESPMM_REC_ROWS is read once per process: this script re-executes itself per value.
+    python profiles/r06/scripts/records_sweep.py [graph ...]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+if "GESPMM_REC_ROWS" not in os.environ:
+    for rows in os.environ.get("ROWS", "8,16,32,64").split(","):
+        env = dict(os.environ, GESPMM_REC_ROWS=rows)
+        subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, check=False)
+    sys.exit(0)
+
+import torch  # noqa: E402
+
+from gespmm_amd import _lib, graphs, spmm  # noqa: E402
+from kernel_ab import timeit  # noqa: E402
+
+dev = torch.device("cuda")
+rows = int(os.environ["GESPMM_REC_ROWS"])
+first = rows == int(os.environ.get("ROWS", "8,16,32,64").split(",")[0])
+widths = [int(x) for x in os.environ.get("WIDTHS", "32,16,64").split(",")]
+for name in sys.argv[1:] or ["com-amazon-sbm", "com-amazon-like"]:
+    g = graphs.synthetic_graph(name, seed=42, device=dev)
+    M, K, nnz, rp, ci = g["M"], g["K"], g["nnz"], g["rowptr"], g["colind"]
+    val = torch.rand(nnz, device=dev) - 0.5
+    for N in widths:
+        B = torch.rand(K, N, device=dev) - 0.5
+        C = torch.empty((M, N), device=dev)
+        alg = 4.0 * (M + 1) + 8.0 * nnz + 4.0 * (M + K) * N
+        spmm.csr_spmm(rp, ci, val, B, out=C)
+        ref = C.clone()
+        if first:
+            t = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C), 50)
+            print("%s N=%d plain call %.1f us (%.3f)" % (name, N, t, alg / t / 8e6), flush=True)
+            p = spmm.SpmmPlan(rp, ci, K, N, values=val, expected_launches=1000000)
+            t = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p), 50)
+            print("%s N=%d AUTO plan %.1f us (%.3f) | %s" % (name, N, t, alg / t / 8e6, p.describe().split("|")[-1].strip()[:90]), flush=True)
+            del p
+        for reorder in (True, False):
+            for fl in (0, _lib.FLAG_NT_STORE):
+                try:
+                    p = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=reorder, kernel="records", flags=fl, expected_launches=1000000)
+                except Exception as ex:  # noqa: BLE001
+                    print("  records: %s" % str(ex)[:80])
+                    continue
+                C.zero_()
+                t = timeit(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=p), 50)
+                ok = torch.equal(C.view(torch.int32), ref.view(torch.int32))
+                print("  %s N=%d records rows/task=%-2d %-9s nt=%d: %.1f us (%.3f)%s" % (
+                    name, N, rows, "clustered" if reorder else "storage", 1 if fl else 0, t, alg / t / 8e6, "" if ok else " BITS-DIFFER"), flush=True)
+                del p

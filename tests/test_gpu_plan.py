@@ -270,9 +270,10 @@ def test_tune_measures_the_candidates_and_keeps_the_bits(pkg, oracle, bundled):
         d = plan.describe()
         assert "tuned[us: batch-stream=" in d, d
         times = [float(x.split("=")[1]) for x in d.split("tuned[us: ")[1].split("]")[0].split()]
-        assert len(times) == 4 and times[0] > 0 and times[1] > 0, d
+        assert len(times) == 5 and times[0] > 0 and times[1] > 0, d
         assert times[2] > 0, d  # staged-rows is a candidate at every width since round 6 (96: the general kernel; 32: the lane-group form)
         assert (times[3] > 0) == (N == 32), d          # 4 floats per lane is a candidate at N <= 64
+        assert (times[4] > 0) == (N == 32), d          # ... and so is the padded-record kernel (spmm_records.hip)
         assert np.array_equal(bits(got), bits(ref)), (N, d)
         again = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()  # launches after the tune: the kept kernel
         assert np.array_equal(bits(again), bits(ref)), (N, d)

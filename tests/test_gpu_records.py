@@ -1,0 +1,131 @@
+"""The plan's padded-record kernel (csrc/spmm_records.hip): narrow widths (N <= 64, N % 4 == 0), rows of <= 1024 entries, sum reducer.
+A row is cut into pieces of 8 padded entry slots that stay in ONE lane group's chain, in order — every output element is still one
+fp32 accumulator over the row's entries in ascending CSR position with one fused multiply-add per entry (the reference's kernels:
+spmm_test.cu:182-203) — so the bits must equal the oracle's `fma` arithmetic and the plain call's, whatever the padding."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import bits, edge_case_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("N", (4, 8, 12, 16, 20, 32, 36, 48, 64))  # lane groups of 4 (N <= 16), 8 (N <= 32), 16 (N <= 64)
+@pytest.mark.parametrize("reorder", (True, False))
+@pytest.mark.parametrize("graph", ("cora", "pubmed"))
+def test_bits_equal_oracle_valued_unweighted_and_new_values(pkg, oracle, bundled, graph, reorder, N):
+    from gespmm_amd import spmm
+
+    g = bundled[graph]
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=7)
+    val = _dev(val_h)
+    plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=reorder, kernel="records")
+    assert "kernel=padded-records" in plan.describe(), plan.describe()
+    assert plan.clustered == reorder
+    B_h = oracle.hash_B(g["K"], N, seed=N)
+    B = _dev(B_h)
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma"))), (graph, N)
+    # the same plan without values: the records carry 1.0f (fma(1, b, acc) == acc + b), against the golden loop
+    got_u = spmm.csr_spmm_no_edge_value(rp, ci, B, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got_u), bits(oracle.spmm(g["rowptr"], g["colind"], None, B_h, "golden"))), (graph, N)
+    # with other values (the records are refilled on the device)
+    val2_h = oracle.hash_val(g["nnz"], seed=8)
+    val2 = _dev(val2_h)
+    got2 = spmm.csr_spmm(rp, ci, val2, B, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got2), bits(oracle.spmm(g["rowptr"], g["colind"], val2_h, B_h, "fma")))
+    # what the record kernel does not serve goes to the streaming kernels of the same plan: another width, the max reducer
+    B2_h = oracle.hash_B(g["K"], 128, seed=5)
+    got128 = spmm.csr_spmm(rp, ci, val2, _dev(B2_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got128), bits(oracle.spmm(g["rowptr"], g["colind"], val2_h, B2_h, "fma")))
+    plan_u = spmm.SpmmPlan(rp, ci, g["K"], N, reorder=reorder, kernel="records")  # (the max reducer takes plans without values)
+    got_max = plan_u.run(None, B, reduce_max=-10000.0).cpu().numpy()
+    assert np.array_equal(bits(got_max), bits(oracle.spmm_max(g["rowptr"], g["colind"], B_h, -10000.0))), (graph, N)
+
+
+@pytest.mark.parametrize("N", (16, 32, 64))
+def test_edge_shapes(pkg, oracle, N):
+    """Empty rows (leading, trailing, runs of them), rows of 1..200 entries (1 to 25 pieces in one chain), repeated and unsorted
+    columns, K != M, M smaller than one task and not a multiple of the rows per task."""
+    from gespmm_amd import spmm
+
+    g = edge_case_csr(seed=4)
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=3)
+    B_h = oracle.hash_B(g["K"], N, seed=N + 1)
+    plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=_dev(val_h), reorder=True, kernel="records")
+    assert "kernel=padded-records" in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp, ci, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(g["rowptr"], g["colind"], val_h, B_h, "fma")))
+    # many tasks, ragged last task: the same rows tiled 37 times with shifted columns
+    reps = 37
+    degs = np.tile(np.diff(g["rowptr"]), reps)
+    rowptr = np.zeros(degs.size + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    colind = np.concatenate([(g["colind"] + 7 * r) % g["K"] for r in range(reps)]).astype(np.int32)
+    val_h = oracle.hash_val(colind.size, seed=5)
+    rp2, ci2 = _dev(rowptr), _dev(colind)
+    for reorder in (True, False):
+        plan = spmm.SpmmPlan(rp2, ci2, g["K"], N, values=_dev(val_h), reorder=reorder, kernel="records")
+        assert "kernel=padded-records" in plan.describe(), plan.describe()
+        got = spmm.csr_spmm(rp2, ci2, _dev(val_h), _dev(B_h), plan=plan).cpu().numpy()
+        assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma"))), reorder
+
+
+def test_special_values_do_not_leak_through_the_padding(pkg, oracle):
+    """Padded slots repeat the address of the piece's last entry and are predicated off: an inf / nan in B must reach exactly the rows
+    that reference it, as in the plain call (a multiply by a padded 0 would turn inf into nan)."""
+    from gespmm_amd import spmm
+
+    g = edge_case_csr(seed=9)
+    N = 32
+    rp, ci = _dev(g["rowptr"]), _dev(g["colind"])
+    val_h = oracle.hash_val(g["nnz"], seed=1)
+    B_h = oracle.hash_B(g["K"], N, seed=2).copy()
+    B_h[0, :] = np.inf       # column 0 is also what an empty slot points at
+    B_h[g["colind"][-1], 3] = -np.inf
+    B_h[g["colind"][5], 7] = np.nan
+    val, B = _dev(val_h), _dev(B_h)
+    plan = spmm.SpmmPlan(rp, ci, g["K"], N, values=val, reorder=True, kernel="records")
+    assert "kernel=padded-records" in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan).cpu().numpy()
+    ref = spmm.csr_spmm(rp, ci, val, B).cpu().numpy()
+    assert np.array_equal(bits(got), bits(ref))
+
+
+def test_rows_beyond_the_limit_and_unaligned_operands_fall_back(pkg, oracle):
+    from gespmm_amd import spmm
+
+    rng = np.random.RandomState(3)
+    M, K, N = 300, 5000, 32
+    degs = rng.randint(0, 12, size=M)
+    degs[17] = 1500  # beyond kRecordMaxRow = 1024: the tables are not built, the streaming kernels serve the plan
+    rowptr = np.zeros(M + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    colind = rng.randint(0, K, size=int(rowptr[-1])).astype(np.int32)
+    val_h = oracle.hash_val(colind.size, seed=2)
+    B_h = oracle.hash_B(K, N, seed=4)
+    rp, ci, val = _dev(rowptr), _dev(colind), _dev(val_h)
+    plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="records")
+    assert "kernel=padded-records" not in plan.describe(), plan.describe()
+    got = spmm.csr_spmm(rp, ci, val, _dev(B_h), plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
+    # a B that starts 4 bytes into an allocation: the record kernel wants 16-byte rows, the plan launches a streaming kernel
+    degs[17] = 9
+    rowptr[1:] = np.cumsum(degs)
+    colind = colind[: int(rowptr[-1])]
+    val_h = val_h[: colind.size]
+    rp, ci, val = _dev(rowptr), _dev(colind), _dev(val_h)
+    plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=True, kernel="records")
+    assert "kernel=padded-records" in plan.describe(), plan.describe()
+    flat = torch.empty(K * N + 1, device="cuda")
+    Bu = flat[1:].view(K, N)
+    Bu.copy_(_dev(B_h))
+    got = spmm.csr_spmm(rp, ci, val, Bu, plan=plan).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
