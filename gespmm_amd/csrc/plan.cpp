@@ -344,8 +344,8 @@ static double record_slot_fill(const gespmm_plan* p) {  // share of the entry sl
 // clustered copy, or the caller's arrays when the storage order was kept).
 static hipError_t build_record_tables(gespmm_plan* p, hipStream_t st) {
     const auto ts = std::chrono::steady_clock::now();
-    static const int env_rows = getenv("GESPMM_REC_ROWS") ? atoi(getenv("GESPMM_REC_ROWS")) : 0;
-    const int rows = env_rows > 0 ? env_rows : gespmm::records_rows_per_task(p->facts);
+    static const int env_rows = getenv("GESPMM_REC_BATCHES") ? atoi(getenv("GESPMM_REC_BATCHES")) : 0;  // experiments
+    const int rows = env_rows > 0 ? env_rows : gespmm::records_batches_per_task(p->facts);
     const hipError_t e = gespmm::device_build_records(p->M, p->reordered ? p->d_rowptr : p->rowptr, p->reordered ? p->d_colind : p->colind,
                                                       p->valued ? (p->reordered ? p->d_val : p->val) : nullptr,
                                                       p->reordered ? p->d_perm : nullptr, rows, p->N, &p->rec, st);
@@ -1045,8 +1045,8 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
                      p->stg.nblocks, gespmm::staged_shape_any(p->N).slots, p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
         if (p->rec.batches && !(p->tuned && p->tuned_kernel != GESPMM_PLAN_KERNEL_RECORDS) && !(staged_d && p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED))
-            snprintf(kern, sizeof kern, "kernel=padded-records tasks=%d rows_per_task=%d batches=%d slot_fill=%.3f tables=%.4fs (max / other widths: %s)",
-                     p->rec.ntasks, p->rec.rows_per_task, p->rec.nbatches,
+            snprintf(kern, sizeof kern, "kernel=padded-records tasks=%d batches_per_task>=%d batches=%d slot_fill=%.3f tables=%.4fs (max / other widths: %s)",
+                     p->rec.ntasks, p->rec.target_batches, p->rec.nbatches,
                      record_slot_fill(p), p->records_seconds, what);
         char tuned[200] = "";
         if (p->tuned)
@@ -1065,8 +1065,8 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
                      p->facts.wedge_probe);
         char kern[420];
         if (p->rec.batches)
-            snprintf(kern, sizeof kern, "kernel=padded-records tasks=%d rows_per_task=%d batches=%d tables=%.4fs (max / other widths: %s)", p->rec.ntasks,
-                     p->rec.rows_per_task, p->rec.nbatches, p->records_seconds, what);
+            snprintf(kern, sizeof kern, "kernel=padded-records tasks=%d batches_per_task>=%d batches=%d slot_fill=%.3f tables=%.4fs (max / other widths: %s)", p->rec.ntasks,
+                     p->rec.target_batches, p->rec.nbatches, record_slot_fill(p), p->records_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);
         n = snprintf(out, (size_t)capacity, "order=storage max_degree=%d l2_model=%.3f->%.3f analysis=%.4fs%s | %s",
                      p->max_degree, p->hits_before, p->hits_after, p->analysis_seconds, why, kern);

@@ -288,16 +288,23 @@ bool want_record_tables(const PlanFacts& f, bool reordered, double hits_after) {
     return f.N <= 16 || (double)f.nnz / (double)f.M <= 8.0;
 }
 
-// ... and kept when enough of their slots carry an entry: com-Amazon-shaped 0.41 (N = 16) / 0.50 (32) / 0.58 (64) win, LFR 0.28 / 0.46
-// lose (the same log). N <= 16 deals rows to 16 chains and wins from a lower fill.
+// ... and kept when enough of their slots carry an entry (tasks cut by work, profiles/r06/records_audit.log): N <= 16 com-Amazon-shaped 0.53,
+// geometric 0.57, products-shaped 0.62, small-world 0.69 win, LFR 0.42 loses; N = 32 / 64 com-Amazon-shaped 0.59 / 0.62 win.
 bool keep_record_tables(const PlanFacts& f, double slot_fill) {
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO) return true;
-    return slot_fill >= (f.N <= 16 ? 0.38 : 0.48);
+    return slot_fill >= (f.N <= 16 ? 0.48 : 0.50);
 }
 
-int records_rows_per_task(const PlanFacts& f) {
-    (void)f;
-    return 16;
+// Batches a task is cut at: a multiple of the mean number of 8-entry pieces per row — short tasks keep the grid several generations deep,
+// longer ones pack rows of different lengths better (a chain ends within one row of the task's longest). Measured, best T by graph
+// (profiles/r06/records_sweep2.log, records_sweep3.log; mean pieces per row in brackets):
+//   N = 32 / 64   com-Amazon-shaped [1.2] 3-4 / 3 · small-world, geometric [1.9-2.0] 8 / 5-12 · LFR [2.5] 8-24 / 8-16 · products-shaped [6.8] 16-24 / 16
+//   N = 16        com-Amazon-shaped 4 · small-world 3 (5: +12 %) · geometric 3-5 · products-shaped 16 (12: +4 %) · LFR flat
+int records_batches_per_task(const PlanFacts& f) {
+    double mp = f.M > 0 ? (double)f.nnz / (8.0 * (double)f.M) + 0.5 : 1.0;
+    if (mp < 1.0) mp = 1.0;
+    int t = (int)((f.N <= 16 ? 1.6 : 3.0) * mp + 0.5);
+    return t < 3 ? 3 : (t > 24 ? 24 : t);
 }
 
 int staged_rows_for(const PlanFacts& f, int shape_rows, int shape_waves) {

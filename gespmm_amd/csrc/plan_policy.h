@@ -91,9 +91,9 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after);
 // ---- the staged tables exist: does enough of the matrix find its B row staged?
 bool keep_staged_tables(const PlanFacts& f, double staged_fraction);
 // Padded-record kernel (spmm_records.hip): are its tables built for this plan (reordered: the clustered order was kept; hits_after: its
-// modelled L2 hits, < 0 unknown), and how many consecutive rows make one wavefront's task.
+// modelled L2 hits, < 0 unknown), and the batches a wavefront task is cut at.
 bool want_record_tables(const PlanFacts& f, bool reordered, double hits_after);
-int records_rows_per_task(const PlanFacts& f);
+int records_batches_per_task(const PlanFacts& f);
 bool keep_record_tables(const PlanFacts& f, double slot_fill);  // slot_fill: share of the batches' entry slots that carry an entry
 
 // ---- per launch (width N_launch may differ from the plan's): segmented-stream instead of batch-stream?

@@ -200,8 +200,8 @@ inline bool staged_serves_any(int64_t M, int64_t K, int64_t N) { return staged_k
 
 // spmm_records.hip — the padded-record kernel (round 6): narrow widths (N <= 64, N % 4 == 0), short rows, sum reducer, plans only. A row
 // is cut into pieces of kRecordPiece padded entry slots; a wavefront is 64 / W chains (W = records_group(N) lanes each) and consumes one
-// BATCH = one piece per chain per step (headers + entries: one coalesced load per lane), a task = `rows_per_task` consecutive rows dealt
-// to the chains. Offsets into B / C are pre-multiplied 32-bit byte offsets.
+// BATCH = one piece per chain per step (headers + entries: one coalesced load per lane), a task = consecutive rows dealt to the chains,
+// cut at `target_batches` batches. Offsets into B / C are pre-multiplied 32-bit byte offsets.
 constexpr int kRecordPiece = 8;
 constexpr int kRecordMaxRow = 1024;                // longer rows would pad the other chains of their task for too long
 constexpr int64_t kRecordMaxBytes = 1ll << 34;     // of batches
@@ -211,10 +211,11 @@ struct RecordTables {
     int32_t* tasks = nullptr;  // ntasks int2 {first batch, #batches}
     char* batches = nullptr;
     int32_t* slot = nullptr;   // per row: first piece position inside its task * 16 + chain
+    int32_t* row_task = nullptr;  // per row: its task
     int32_t* first = nullptr;  // per task: first batch (ntasks + 1)
     int32_t ntasks = 0;
     int32_t nbatches = 0;
-    int32_t rows_per_task = 0;
+    int32_t target_batches = 0;  // T: batches a task is cut at (longer when a row needs more)
     int32_t group = 0;         // W
     int64_t N = 0;
 };
@@ -232,7 +233,7 @@ int records_group(int64_t N);  // lanes per chain at width N (0: width not serve
 bool records_serves(int64_t M, int64_t K, int64_t N, int32_t max_degree);
 // rowptr / colind / val: the matrix in the order its rows are processed (val NULL: 1.0f); perm: C row of row i (NULL: i)
 hipError_t device_build_records(int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val, const int32_t* perm,
-                                int rows_per_task, int64_t N, RecordTables* out, hipStream_t st);
+                                int target_batches, int64_t N, RecordTables* out, hipStream_t st);
 hipError_t device_records_set_values(const RecordTables& t, int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val,
                                      hipStream_t st);
 void free_records(RecordTables* t);

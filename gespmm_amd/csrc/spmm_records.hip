@@ -15,8 +15,9 @@
 //     16 B per lane back to back (8 KB per wavefront in flight), then the 8 multiply-adds — those past the piece's length are
 //     predicated off (their gathers repeat the piece's last address: same cache line) —, then stores the row if the piece
 //     was its last;
-//   * a TASK = R consecutive rows of the plan's order dealt greedily to the chain with the fewest pieces so far; wavefront w
-//     reads task w = {first batch, #batches}: one scalar load, then the pipeline above. No row pointers, no LDS, no barrier.
+//   * a TASK = consecutive rows of the plan's order dealt greedily to the chain with the fewest pieces so far, cut by WORK (a task
+//     takes rows while the least loaded chain can hold the next one within max(T, its longest chain) batches); wavefront w reads
+//     task w = {first batch, #batches}: one scalar load, then the pipeline above. No row pointers, no LDS, no barrier.
 //
 // Offsets are pre-multiplied 32-bit byte offsets from B / C (the plan knows N): served when max(M, K) * N * 4 < 4 GB.
 #include <hip/hip_runtime.h>
@@ -150,22 +151,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
 
 // ----------------------------------------------------------------------------- tables (plan time, on the device)
 
-// One thread per task: rows [t * R, t * R + R) dealt in order to the chain with the fewest pieces so far (ties: lowest chain).
-// slot[i] = first piece position of row i inside its task * 16 + chain; nb[t] = batches of the task.
+// Tasks are cut by WORK, one thread per span of kRecordSpan consecutive rows (tasks do not cross spans): rows are dealt in order to
+// the chain with the fewest pieces so far (ties: lowest chain), and a task takes the next row while that chain can hold it without
+// raising the task's length beyond max(T, its longest chain) — so every chain ends within one row of the longest, whatever the row
+// lengths (a long row opens a task that the following short rows fill up beside it). write == false: tasks per span -> count[span];
+// write == true: base[span] = first task id of the span: slot[i] = first piece position of row i inside its task * 16 + chain,
+// row_task[i], nb[task] = batches of the task.
+constexpr int kRecordSpan = 256;
 template <int G>
-__global__ void rec_assign_kernel(const int32_t* __restrict__ rowptr, int M, int R, int ntasks, int32_t* __restrict__ slot,
+__global__ void rec_assign_kernel(const int32_t* __restrict__ rowptr, int M, int T, int nspans, bool write, const int32_t* __restrict__ base,
+                                  int32_t* __restrict__ count, int32_t* __restrict__ slot, int32_t* __restrict__ row_task,
                                   int32_t* __restrict__ nb) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > ntasks) return;
-    if (t == ntasks) {  // (the scan runs over ntasks + 1 counts: its last output is the total)
-        nb[t] = 0;
-        return;
-    }
+    const int sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sp >= nspans) return;
     int lens[G];
 #pragma unroll
     for (int c = 0; c < G; ++c) lens[c] = 0;
-    const int r0 = t * R;
-    const int r1 = (M - r0 < R) ? M : r0 + R;
+    const int r0 = sp * kRecordSpan;
+    const int r1 = (M - r0 < kRecordSpan) ? M : r0 + kRecordSpan;
+    int task = write ? base[sp] : 0;
+    int ntasks = 0, mx = 0, rows_in_task = 0;
     int prev = rowptr[r0];
     for (int i = r0; i < r1; ++i) {
         const int next = rowptr[i + 1];
@@ -180,15 +185,33 @@ __global__ void rec_assign_kernel(const int32_t* __restrict__ rowptr, int M, int
                 best = c;
             }
         }
-        slot[i] = bl * 16 + best;
+        const int cap = mx > T ? mx : T;
+        if (rows_in_task > 0 && bl + pieces > cap) {  // the task is full: close it, the row opens the next one
+            if (write) nb[task] = mx;
+            ++task;
+            ++ntasks;
+#pragma unroll
+            for (int c = 0; c < G; ++c) lens[c] = 0;
+            best = 0;
+            bl = 0;
+            mx = 0;
+            rows_in_task = 0;
+        }
+        if (write) {
+            slot[i] = bl * 16 + best;
+            row_task[i] = task;
+        }
 #pragma unroll
         for (int c = 0; c < G; ++c)
             if (c == best) lens[c] = bl + pieces;
+        mx = bl + pieces > mx ? bl + pieces : mx;
+        ++rows_in_task;
     }
-    int mx = 0;
-#pragma unroll
-    for (int c = 0; c < G; ++c) mx = lens[c] > mx ? lens[c] : mx;
-    nb[t] = mx;
+    if (rows_in_task > 0) {
+        if (write) nb[task] = mx;
+        ++ntasks;
+    }
+    if (!write) count[sp] = ntasks;
 }
 
 __global__ void rec_tasks_kernel(const int32_t* __restrict__ first, int ntasks, int2* __restrict__ tasks) {
@@ -200,8 +223,8 @@ __global__ void rec_tasks_kernel(const int32_t* __restrict__ first, int ntasks, 
 // an untouched slot is {offset 0, value 0, 0 entries, not last}.
 template <int G>
 __global__ void rec_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const float* __restrict__ val,
-                                const int32_t* __restrict__ perm, const int32_t* __restrict__ slot, const int32_t* __restrict__ first,
-                                int M, int R, uint32_t rowbytes, char* __restrict__ batches, bool values_only) {
+                                const int32_t* __restrict__ perm, const int32_t* __restrict__ slot, const int32_t* __restrict__ row_task,
+                                const int32_t* __restrict__ first, int M, uint32_t rowbytes, char* __restrict__ batches, bool values_only) {
     constexpr int BB = G * 8 * (1 + P);
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / P;
     const int j = threadIdx.x % P;
@@ -212,7 +235,7 @@ __global__ void rec_fill_kernel(const int32_t* __restrict__ rowptr, const int32_
     const int pieces = d > 0 ? (d + P - 1) / P : 1;
     const int s = slot[i];
     const int c = s & 15;
-    char* b = batches + (size_t)(first[i / R] + (s >> 4)) * BB;
+    char* b = batches + (size_t)(first[row_task[i]] + (s >> 4)) * BB;
     const uint32_t crow = (uint32_t)(perm ? perm[i] : i) * rowbytes;
     for (int k = 0; k < pieces; ++k, b += BB) {
         const int plen = (d - k * P < P) ? d - k * P : P;
@@ -228,42 +251,63 @@ __global__ void rec_fill_kernel(const int32_t* __restrict__ rowptr, const int32_
 }
 
 template <int G>
-hipError_t build_g(int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val, const int32_t* perm, int R, int64_t N,
+hipError_t build_g(int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val, const int32_t* perm, int T, int64_t N,
                    RecordTables* out, hipStream_t st) {
     constexpr int BB = G * 8 * (1 + P);
-    const int64_t ntasks = (M + R - 1) / R;
+    const int64_t nspans = (M + kRecordSpan - 1) / kRecordSpan;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    // side block: slot[M], counts / first[ntasks + 1] (kept: gespmm_plan_set_values refills the stream), scan scratch
-    size_t scan_bytes = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)ntasks + 1,
+    // side block (kept: gespmm_plan_set_values refills the stream): slot[M], row_task[M], first[M + 1]; scratch behind it: nb[M + 1],
+    // per-span counts and bases, the scans' temporary storage
+    size_t scan_a = 0, scan_b = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, scan_a, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)nspans + 1,
                                            rocprim::plus<int32_t>(), st);
+    if (e == hipSuccess)
+        e = rocprim::exclusive_scan(nullptr, scan_b, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)M + 1, rocprim::plus<int32_t>(), st);
     if (e != hipSuccess) return e;
-    const size_t b_slot = up((size_t)M * 4), b_cnt = up(((size_t)ntasks + 1) * 4);
+    const size_t scan_bytes = scan_a > scan_b ? scan_a : scan_b;
+    const size_t b_row = up((size_t)M * 4), b_row1 = up(((size_t)M + 1) * 4), b_span = up(((size_t)nspans + 1) * 4);
     char* side = nullptr;
-    e = hipMalloc(reinterpret_cast<void**>(&side), b_slot + 2 * b_cnt + up(scan_bytes) + 256);
+    e = hipMalloc(reinterpret_cast<void**>(&side), 2 * b_row + 2 * b_row1 + 2 * b_span + up(scan_bytes) + 256);
     if (e != hipSuccess) return e;
     int32_t* slot = reinterpret_cast<int32_t*>(side);
-    int32_t* first = reinterpret_cast<int32_t*>(side + b_slot);
-    int32_t* cnt = reinterpret_cast<int32_t*>(side + b_slot + b_cnt);
-    void* scan_tmp = side + b_slot + 2 * b_cnt;
-    hipLaunchKernelGGL((rec_assign_kernel<G>), dim3((unsigned)((ntasks + 1 + 255) / 256)), dim3(256), 0, st, rowptr, (int)M, R, (int)ntasks,
-                       slot, cnt);
-    e = hipGetLastError();
+    int32_t* row_task = reinterpret_cast<int32_t*>(side + b_row);
+    int32_t* first = reinterpret_cast<int32_t*>(side + 2 * b_row);
+    int32_t* nb = reinterpret_cast<int32_t*>(side + 2 * b_row + b_row1);
+    int32_t* count = reinterpret_cast<int32_t*>(side + 2 * b_row + 2 * b_row1);
+    int32_t* base = reinterpret_cast<int32_t*>(side + 2 * b_row + 2 * b_row1 + b_span);
+    void* scan_tmp = side + 2 * b_row + 2 * b_row1 + 2 * b_span;
+    const dim3 sgrid((unsigned)((nspans + 63) / 64)), sblock(64);
+    e = hipMemsetAsync(nb, 0, ((size_t)M + 1) * 4, st);  // (tasks beyond the last one: no batches — the scan below runs over M + 1 counts)
+    if (e == hipSuccess) e = hipMemsetAsync(count, 0, ((size_t)nspans + 1) * 4, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((rec_assign_kernel<G>), sgrid, sblock, 0, st, rowptr, (int)M, T, (int)nspans, false, (const int32_t*)nullptr, count,
+                           (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess)
-        e = rocprim::exclusive_scan(scan_tmp, scan_bytes, (const int32_t*)cnt, first, 0, (size_t)ntasks + 1, rocprim::plus<int32_t>(), st);
-    int32_t total = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&total, first + ntasks, 4, hipMemcpyDeviceToHost, st);
+        e = rocprim::exclusive_scan(scan_tmp, scan_a, (const int32_t*)count, base, 0, (size_t)nspans + 1, rocprim::plus<int32_t>(), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((rec_assign_kernel<G>), sgrid, sblock, 0, st, rowptr, (int)M, T, (int)nspans, true, (const int32_t*)base, count, slot,
+                           row_task, nb);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = rocprim::exclusive_scan(scan_tmp, scan_b, (const int32_t*)nb, first, 0, (size_t)M + 1, rocprim::plus<int32_t>(), st);
+    int32_t totals[2] = {0, 0};  // tasks, batches
+    if (e == hipSuccess) e = hipMemcpyAsync(&totals[0], base + nspans, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&totals[1], first + M, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && (total < 0 || (int64_t)total * BB > (int64_t)kRecordMaxBytes)) e = hipErrorOutOfMemory;  // (a hub row pads 7 chains)
+    const int64_t ntasks = totals[0], total = totals[1];
+    if (e == hipSuccess && (ntasks <= 0 || total < 0 || total * BB > (int64_t)kRecordMaxBytes)) e = hipErrorOutOfMemory;
     char* main_block = nullptr;
-    const size_t b_tasks = up((size_t)ntasks * 8);
+    const size_t b_tasks = up((size_t)(ntasks > 0 ? ntasks : 1) * 8);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&main_block), b_tasks + (size_t)total * BB + 256);
     if (e == hipSuccess) e = hipMemsetAsync(main_block + b_tasks, 0, (size_t)total * BB, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(rec_tasks_kernel, dim3((unsigned)((ntasks + 255) / 256)), dim3(256), 0, st, first, (int)ntasks,
                            reinterpret_cast<int2*>(main_block));
         hipLaunchKernelGGL((rec_fill_kernel<G>), dim3((unsigned)((M * P + 255) / 256)), dim3(256), 0, st, rowptr, colind, val, perm, slot,
-                           first, (int)M, R, (uint32_t)(N * 4), main_block + b_tasks, false);
+                           row_task, first, (int)M, (uint32_t)(N * 4), main_block + b_tasks, false);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -276,10 +320,11 @@ hipError_t build_g(int64_t M, const int32_t* rowptr, const int32_t* colind, cons
     out->tasks = reinterpret_cast<int32_t*>(main_block);
     out->batches = main_block + b_tasks;
     out->slot = slot;
+    out->row_task = row_task;
     out->first = first;
     out->ntasks = (int32_t)ntasks;
-    out->nbatches = total;
-    out->rows_per_task = R;
+    out->nbatches = (int32_t)total;
+    out->target_batches = T;
     out->group = 64 / G;
     out->N = N;
     return hipSuccess;
@@ -299,13 +344,13 @@ bool records_serves(int64_t M, int64_t K, int64_t N, int32_t max_degree) {
 }
 
 hipError_t device_build_records(int64_t M, const int32_t* rowptr, const int32_t* colind, const float* val, const int32_t* perm,
-                                int rows_per_task, int64_t N, RecordTables* out, hipStream_t st) {
+                                int target_batches, int64_t N, RecordTables* out, hipStream_t st) {
     const int W = records_group(N);
-    if (!W || M <= 0 || rows_per_task < 1) return hipErrorInvalidValue;
+    if (!W || M <= 0 || target_batches < 1) return hipErrorInvalidValue;
     switch (W) {
-        case 4: return build_g<16>(M, rowptr, colind, val, perm, rows_per_task, N, out, st);
-        case 8: return build_g<8>(M, rowptr, colind, val, perm, rows_per_task, N, out, st);
-        default: return build_g<4>(M, rowptr, colind, val, perm, rows_per_task, N, out, st);
+        case 4: return build_g<16>(M, rowptr, colind, val, perm, target_batches, N, out, st);
+        case 8: return build_g<8>(M, rowptr, colind, val, perm, target_batches, N, out, st);
+        default: return build_g<4>(M, rowptr, colind, val, perm, target_batches, N, out, st);
     }
 }
 
@@ -315,9 +360,9 @@ hipError_t device_records_set_values(const RecordTables& t, int64_t M, const int
     const dim3 grid((unsigned)((M * P + 255) / 256));
     const uint32_t rowbytes = (uint32_t)(t.N * 4);
     switch (t.group) {
-        case 4: hipLaunchKernelGGL((rec_fill_kernel<16>), grid, dim3(256), 0, st, rowptr, colind, val, (const int32_t*)nullptr, t.slot, t.first, (int)M, t.rows_per_task, rowbytes, t.batches, true); break;
-        case 8: hipLaunchKernelGGL((rec_fill_kernel<8>), grid, dim3(256), 0, st, rowptr, colind, val, (const int32_t*)nullptr, t.slot, t.first, (int)M, t.rows_per_task, rowbytes, t.batches, true); break;
-        default: hipLaunchKernelGGL((rec_fill_kernel<4>), grid, dim3(256), 0, st, rowptr, colind, val, (const int32_t*)nullptr, t.slot, t.first, (int)M, t.rows_per_task, rowbytes, t.batches, true); break;
+        case 4: hipLaunchKernelGGL((rec_fill_kernel<16>), grid, dim3(256), 0, st, rowptr, colind, val, (const int32_t*)nullptr, t.slot, t.row_task, t.first, (int)M, rowbytes, t.batches, true); break;
+        case 8: hipLaunchKernelGGL((rec_fill_kernel<8>), grid, dim3(256), 0, st, rowptr, colind, val, (const int32_t*)nullptr, t.slot, t.row_task, t.first, (int)M, rowbytes, t.batches, true); break;
+        default: hipLaunchKernelGGL((rec_fill_kernel<4>), grid, dim3(256), 0, st, rowptr, colind, val, (const int32_t*)nullptr, t.slot, t.row_task, t.first, (int)M, rowbytes, t.batches, true); break;
     }
     return hipGetLastError();
 }
