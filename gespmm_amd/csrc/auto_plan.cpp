@@ -522,9 +522,10 @@ int gespmm_init(int64_t rows_hint, int64_t nnz_hint, void* stream) {
         // every kernel family once: the plain call, a clustered plan on the streaming kernels (both), the staged-rows kernels (tuned,
         // general, lane groups) — building the plans runs every analysis pass
         if (rc == 0) rc = gespmm::run_spmm(rp, ci, nullptr, B, C, M, M, N, nnz, GESPMM_VARIANT_AUTO, nullptr, gespmm::kReduceSum, 0.0f, stream, nullptr, 0, nullptr);
-        const int kernels[4] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STAGED};
-        const int widths[4] = {N, N, N, 32};
-        for (int i = 0; i < 4 && rc == 0; ++i) {
+        const int kernels[5] = {GESPMM_PLAN_KERNEL_STREAM, GESPMM_PLAN_KERNEL_SEG_STREAM, GESPMM_PLAN_KERNEL_STAGED, GESPMM_PLAN_KERNEL_STAGED,
+                                GESPMM_PLAN_KERNEL_RECORDS};  // (... and the padded-record kernel with its table passes)
+        const int widths[5] = {N, N, N, 32, 32};
+        for (int i = 0; i < 5 && rc == 0; ++i) {
             gespmm_plan_options opt;
             std::memset(&opt, 0, sizeof opt);
             opt.reorder = GESPMM_PLAN_REORDER;

@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r06f; mkdir -p $O
 B="python bench.py --no-extra --no-cpu-baseline --steps 50 --warmup 5"
-K="spmm_(seg)?stream|spmm_staged|spmm_longrow|spmm_slab"
+K="spmm_(seg)?stream|spmm_staged|spmm_records|spmm_longrow|spmm_slab"
 scripts/gpu_pmc.sh bench_sbm_plan "$K" -- $B > $O/pmc_1.log 2>&1
 scripts/gpu_pmc.sh bench_sbm_plain "$K" -- $B --no-plan > $O/pmc_2.log 2>&1
 scripts/gpu_pmc.sh bench_like_plan "$K" -- $B --graph com-amazon-like --expected-launches 1000000 > $O/pmc_3.log 2>&1

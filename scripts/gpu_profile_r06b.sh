@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r06f; mkdir -p $O
-K="spmm_(seg)?stream|spmm_staged|spmm_longrow|spmm_slab"
+K="spmm_(seg)?stream|spmm_staged|spmm_records|spmm_longrow|spmm_slab"
 scripts/gpu_pmc.sh products_sbm_staged "spmm_staged" -- python scripts/kernel_pmc_case.py products-sbm 128 auto 3 > $O/pmc_7.log 2>&1
 scripts/gpu_pmc.sh products_sbm_staged_N512 "spmm_staged" -- python scripts/kernel_pmc_case.py products-sbm 512 auto 3 > $O/pmc_8.log 2>&1
 scripts/gpu_pmc.sh reddit_sbm_plan "$K" -- python scripts/kernel_pmc_case.py reddit-sbm 128 auto 3 > $O/pmc_9.log 2>&1
