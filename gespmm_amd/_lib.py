@@ -113,7 +113,7 @@ class PlanPolicyQuery(Structure):
                 ("max_degree", c_int32), ("reorder", c_int32), ("kernel", c_int32), ("analysis", c_int32), ("flags", c_int32),
                 ("task_entries", c_int32), ("row_floor", c_int32), ("hits_before", ctypes.c_double),
                 ("hits_after", ctypes.c_double), ("staged_fraction", ctypes.c_double), ("expected_launches", c_int32),
-                ("cold_start", c_int32), ("wedge_probe", ctypes.c_double)]
+                ("cold_start", c_int32), ("wedge_probe", ctypes.c_double), ("record_slot_fill", ctypes.c_double)]
 
 
 class PlanPolicyAnswer(Structure):
@@ -123,7 +123,9 @@ class PlanPolicyAnswer(Structure):
                                                                                        ("cost_skipped", c_int32), ("cluster_levels", c_int32),
                                                                                        ("est_gain_us", ctypes.c_double),
                                                                                        ("est_cost_us", ctypes.c_double), ("cluster_sweeps", c_int32),
-                                                                                       ("staged_rows", c_int32)]
+                                                                                       ("staged_rows", c_int32), ("build_records", c_int32),
+                                                                                       ("keep_records", c_int32), ("records_batches", c_int32),
+                                                                                       ("reserved0", c_int32)]
 
 
 class AutoPlanStats(Structure):
@@ -259,13 +261,13 @@ class GespmmError(RuntimeError):
 
 def plan_policy(M, K, nnz, N, max_degree, hits_before=0.0, hits_after=0.0, staged_fraction=0.0, N_launch=0, variant=VARIANT_AUTO,
                 reorder=PLAN_REORDER_AUTO, kernel=PLAN_KERNEL_AUTO, analysis=PLAN_ANALYSIS_DEVICE, flags=0, task_entries=0,
-                row_floor=0, expected_launches=0, wedge_probe=-1.0, cold_start=0):
+                row_floor=0, expected_launches=0, wedge_probe=-1.0, cold_start=0, record_slot_fill=-1.0):
     """What a plan would decide for a matrix of this shape (gespmm_plan_policy_v2: host only, no device) — a dict.
     `wedge_probe` is the plan's structure probe (share of sampled wedges that close; negative = unknown), `expected_launches` the
     number of products the analysis has to pay for itself in (0 = 200)."""
     q = PlanPolicyQuery(int(M), int(K), int(nnz), int(N), int(N_launch), int(variant), int(max_degree), int(reorder), int(kernel),
                         int(analysis), int(flags), int(task_entries), int(row_floor), float(hits_before), float(hits_after),
-                        float(staged_fraction), int(expected_launches), int(cold_start), float(wedge_probe))
+                        float(staged_fraction), int(expected_launches), int(cold_start), float(wedge_probe), float(record_slot_fill))
     a = PlanPolicyAnswer()
     check(lib.gespmm_plan_policy_v2(ctypes.byref(q), ctypes.sizeof(q), ctypes.byref(a), ctypes.sizeof(a)), "gespmm_plan_policy_v2")
     return {n: getattr(a, n) for n, _ in PlanPolicyAnswer._fields_ if not n.startswith("reserved")}

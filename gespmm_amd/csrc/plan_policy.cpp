@@ -386,7 +386,8 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     gespmm_plan_policy_query qq;
     std::memset(&qq, 0, sizeof qq);
     qq.wedge_probe = -1.0;
-    if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, cold_start) + 4) qq.cold_start = 0;  // (a 0.2 caller: unknown)
+    if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, cold_start) + 4) qq.cold_start = 0;
+    if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, record_slot_fill) + 8) qq.record_slot_fill = -1.0;  // (a 0.2 caller: unknown)
     std::memcpy(&qq, q_in, (size_t)(q_bytes < (int64_t)sizeof qq ? q_bytes : (int64_t)sizeof qq));
     if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, wedge_probe) + 8) qq.wedge_probe = -1.0;
     if (q_bytes < (int64_t)offsetof(gespmm_plan_policy_query, cold_start) + 4) qq.cold_start = 0;
@@ -469,6 +470,11 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
         const gespmm::StagedShape sh = gespmm::staged_shape_any(q->N);
         a->staged_rows = sh.waves ? gespmm::staged_rows_for(f, sh.rows, sh.waves) : 0;
     }
+    // the padded-record kernel (plan.cpp builds its tables after the staged ones: not beside tables that were kept)
+    a->build_records = gespmm::records_serves(q->M, q->K, q->N, q->max_degree) && q->nnz > 0 && gespmm::want_record_tables(f, keep, q->hits_after) &&
+                       !a->keep_staged;
+    a->keep_records = a->build_records && (q->record_slot_fill < 0.0 || gespmm::keep_record_tables(f, q->record_slot_fill));
+    a->records_batches = gespmm::records_batches_per_task(f);
     std::memcpy(a_out, &aa, (size_t)(a_bytes < (int64_t)sizeof aa ? a_bytes : (int64_t)sizeof aa));
     return 0;
 }

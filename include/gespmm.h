@@ -449,6 +449,8 @@ typedef struct gespmm_plan_policy_query {
                                   its kernels and makes its arena (~29 ms): the cost rule is asked with that on top */
     double wedge_probe;      /* share of sampled (row r; c1, c2 in r) wedges with c2 in row c1 — the plan's cheap structure probe on square
                                 matrices; negative = unknown (rectangular matrix, host analysis) */
+    double record_slot_fill; /* padded-record kernel (round 6, read when q_bytes covers it): share of the batches' entry slots that carry an
+                                entry once its tables are built; negative = not known yet (keep_records then repeats build_records) */
 } gespmm_plan_policy_query;
 typedef struct gespmm_plan_policy_answer {
     int32_t launch_flags;      /* user flags + GESPMM_FLAG_SPLIT_LONG_ROWS or _STRICT_ORDER */
@@ -469,6 +471,11 @@ typedef struct gespmm_plan_policy_answer {
     double est_cost_us;        /* estimated time of the analysis */
     int32_t cluster_sweeps;    /* label-propagation sweeps per level (0 = the clustering's own default: five) */
     int32_t staged_rows;       /* rows per block of the staged-rows tables at this width (0: the width is not served) */
+    /* round 6 (written when a_bytes covers them): the padded-record kernel (GESPMM_PLAN_KERNEL_RECORDS) */
+    int32_t build_records, keep_records; /* its tables are built (clustered order kept, narrow width, short rows, no staged tables kept) /
+                                            kept, given record_slot_fill */
+    int32_t records_batches;   /* batches a wavefront task of those tables is cut at */
+    int32_t reserved0;
 } gespmm_plan_policy_answer;
 int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);  /* the 0.2 layouts (up to staged_fraction / model_sample) */
 int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q, int64_t q_bytes, gespmm_plan_policy_answer* a, int64_t a_bytes);

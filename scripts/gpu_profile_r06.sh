@@ -15,6 +15,7 @@ scripts/gpu_pmc.sh bench_like_plan "$K" -- $B --graph com-amazon-like --expected
 scripts/gpu_pmc.sh bench_like_plain "$K" -- $B --graph com-amazon-like --no-plan > $O/pmc_4.log 2>&1
 scripts/gpu_pmc.sh bench_sbm_plan_N32 "$K" -- $B --ncols 32 --expected-launches 1000000 > $O/pmc_5.log 2>&1
 scripts/gpu_pmc.sh bench_sbm_plan_N512 "$K" -- $B --ncols 512 > $O/pmc_6.log 2>&1
+scripts/gpu_pmc.sh bench_sbm_plan_N64 "$K" -- $B --ncols 64 --expected-launches 1000000 > $O/pmc_6a.log 2>&1
 scripts/gpu_pmc.sh bench_sbm_plan_N100 "$K" -- $B --ncols 100 --expected-launches 1000000 > $O/pmc_6b.log 2>&1
 scripts/gpu_pmc.sh bench_sbm_plan_N200 "$K" -- $B --ncols 200 --expected-launches 1000000 > $O/pmc_6c.log 2>&1
 scripts/gpu_pmc.sh products_sbm_staged "spmm_staged" -- python scripts/kernel_pmc_case.py products-sbm 128 auto 3 > $O/pmc_7.log 2>&1
@@ -29,7 +30,7 @@ python scripts/update_traffic_json.py \
   products-sbm/N128/valued/plan=gpurun_out/pmc_products_sbm_staged/summary.csv products-sbm/N512/valued/plan=gpurun_out/pmc_products_sbm_staged_N512/summary.csv \
   > $O/update_traffic.log 2>&1
 sed -i "s#gpurun_out/pmc_#profiles/r06/pmc_#g" profiles/hbm_traffic.json; cp profiles/hbm_traffic.json $O/hbm_traffic.json
-for t in bench_sbm_plan bench_sbm_plain bench_like_plan bench_like_plain bench_sbm_plan_N32 bench_sbm_plan_N512 bench_sbm_plan_N100 bench_sbm_plan_N200 products_sbm_staged products_sbm_staged_N512 reddit_sbm_plan rmat24_plain_N256; do
+for t in bench_sbm_plan bench_sbm_plain bench_like_plan bench_like_plain bench_sbm_plan_N32 bench_sbm_plan_N64 bench_sbm_plan_N512 bench_sbm_plan_N100 bench_sbm_plan_N200 products_sbm_staged products_sbm_staged_N512 reddit_sbm_plan rmat24_plain_N256; do
   echo "== $t"; grep -E "FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum|TCC_MISS_sum|TCC_EA0_RDREQ_sum" gpurun_out/pmc_$t/summary.csv | cut -d, -f1,6- | cut -c1-200; grep -E "spmm_" gpurun_out/pmc_$t/kernel_stats.csv | cut -c1-200; done > $O/pmc_digest.log 2>&1
 P=/tmp/prof_bench; rm -rf $P; mkdir -p $P
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o b -- python bench.py > $O/bench_under_profiler.log 2>&1

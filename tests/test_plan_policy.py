@@ -208,3 +208,28 @@ def test_warm_up_only_where_an_analysis_could_pay():
     assert w(334863, 1851744, 128) == 1 and w(334863, 1851744, 32) == 0 and w(232965, 114615892, 32) == 1
     assert _lib.lib.gespmm_plan_wants_warmup(-1, 1, 1, 1, 0) < 0
 
+
+
+def test_padded_record_kernel_rules():
+    """plan_policy.cpp want_record_tables / keep_record_tables / records_batches_per_task (profiles/r06/records_audit.log): short rows at
+    narrow widths in an order that hits L2; any mean degree at N <= 16; not beside staged tables that were kept; kept by slot fill."""
+    amazon = dict(M=334863, K=334863, nnz=1851744, max_degree=120, hits_before=0.054, expected_launches=1000000, wedge_probe=0.3)
+    q = lambda **kw: _lib.plan_policy(**{**amazon, **kw})
+    a = q(N=32, hits_after=0.675)
+    assert (a["keep_clustered"], a["build_records"], a["keep_records"], a["records_batches"]) == (1, 1, 1, 4)
+    assert q(N=32, hits_after=0.675, record_slot_fill=0.59)["keep_records"] == 1
+    assert q(N=32, hits_after=0.675, record_slot_fill=0.46)["keep_records"] == 0  # (LFR with 16-row tasks: behind the streaming kernel)
+    assert q(N=16, hits_after=0.686, record_slot_fill=0.42)["keep_records"] == 0 and q(N=16, hits_after=0.686, record_slot_fill=0.53)["keep_records"] == 1
+    assert q(N=64, hits_after=0.668)["build_records"] == 1
+    for kw in (dict(N=128, hits_after=0.66), dict(N=30, hits_after=0.675), dict(N=32, hits_after=0.222),
+               dict(N=32, hits_after=0.675, max_degree=2726), dict(N=32, hits_after=0.675, variant=_lib.VARIANT_CRC)):
+        assert q(**kw)["build_records"] == 0, kw
+    # rows of 50 entries (products-shaped, a quarter of the size): the lane-group staged kernel keeps N = 32 / 64, records take N = 16
+    prod = dict(M=612257, K=612257, nnz=30929570, max_degree=1009, hits_before=0.04, hits_after=0.85, expected_launches=1000000, wedge_probe=0.3)
+    p32 = _lib.plan_policy(N=32, staged_fraction=0.70, **prod)
+    assert (p32["keep_staged"], p32["build_records"]) == (1, 0)
+    p16 = _lib.plan_policy(N=16, **prod)
+    assert (p16["build_records"], p16["records_batches"]) == (1, 11)
+    # asked for by name: any order, any mean degree (still N <= 64, N % 4 == 0, rows <= 1024)
+    assert _lib.plan_policy(N=32, kernel=_lib.PLAN_KERNEL_RECORDS, reorder=_lib.PLAN_NO_REORDER, **{**prod, "hits_after": 0.04})["build_records"] == 1
+    assert _lib.plan_policy(N=32, kernel=_lib.PLAN_KERNEL_RECORDS, **{**prod, "max_degree": 1500})["build_records"] == 0
