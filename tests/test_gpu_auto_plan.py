@@ -198,3 +198,30 @@ def test_init_is_idempotent_and_warms_the_analysis(pkg):
     cold = _lib.plan_policy(334863, 334863, 1851744, 128, 100, wedge_probe=0.42, cold_start=1)
     assert cold["est_cost_us"] - warm["est_cost_us"] == pytest.approx(29000.0)
     assert warm["analyse"] == 1 and cold["analyse"] == 0
+
+
+def test_narrow_width_through_the_record_kernel(auto, oracle):
+    """N = 32 on the headline graph: a cached plan launches the padded-record kernel (spmm_records.hip) behind the device-side guard; same
+    bits as the plain call, values changed in place are noticed and the records refilled."""
+    _lib = auto
+    from gespmm_amd import graphs
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    rp, ci, K, nnz = g["rowptr"], g["colind"], g["K"], g["nnz"]
+    val = torch.from_numpy(oracle.hash_val(nnz, seed=3)).cuda()
+    B = torch.from_numpy(oracle.hash_B(K, 32, seed=4)).cuda()
+    ref = _plain(_lib, rp, ci, val, B)
+    before = _lib.auto_plan_stats()
+    _lib.set_auto_plan(2)
+    for _ in range(5):
+        assert torch.equal(_call(_lib, rp, ci, val, B).view(torch.int32), ref.view(torch.int32))
+    val.mul_(-0.25)
+    want = _plain(_lib, rp, ci, val, B)
+    for _ in range(4):
+        assert torch.equal(_call(_lib, rp, ci, val, B).view(torch.int32), want.view(torch.int32))
+        torch.cuda.synchronize()
+    st = _lib.auto_plan_stats()
+    if st["cached_plans"] == 1:  # (the cost rule may keep the storage order inside 200 launches at this width: then nothing was planned)
+        assert st["calls_planned"] - before["calls_planned"] >= 3, st
+        assert st["values_refreshed"] - before["values_refreshed"] == 1, st
+    _lib.auto_plan_clear()

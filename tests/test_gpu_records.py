@@ -129,3 +129,16 @@ def test_rows_beyond_the_limit_and_unaligned_operands_fall_back(pkg, oracle):
     Bu.copy_(_dev(B_h))
     got = spmm.csr_spmm(rp, ci, val, Bu, plan=plan).cpu().numpy()
     assert np.array_equal(bits(got), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma")))
+
+
+def test_reduced_soak_of_the_record_kernel(pkg):
+    """120 seeds of scripts/records_soak.py (random shapes, widths 4 .. 64, both orders, rows at and beyond the 1024-entry limit,
+    valued / unweighted / new values) against the plain call's strict-order bits."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import records_soak
+
+    checked, served = records_soak.soak(71000, 120, verbose=False)
+    assert checked >= 900 and served >= 250, (checked, served)
