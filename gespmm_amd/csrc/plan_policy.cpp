@@ -4,6 +4,7 @@
 // this repository did not write: profiles/r04/holdout_audit.log, scripts/holdout_audit.py) is the check that they are not
 // fitted to the stand-ins of gespmm_amd/graphs.py.
 
+#include <cstdlib>
 #include "plan_policy.h"
 
 #include <cstddef>
@@ -281,6 +282,9 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
 //     at mu = 0.1, x0.78 / x0.94 / x0.86 at mu = 0.3 — keep_record_tables drops them by their slot fill
 //   an order that does not hit L2 (structureless graph, modelled 0.19-0.28): x0.66-0.84; the storage order of a scrambled graph: level
 //     with the plain call. Hence: clustered order kept and modelled at >= 0.60 hits.
+//   Widths that are not multiples of 4 (4-byte-aligned vectors; the streaming kernels fall to one float per lane there) under the same
+//     rule, profiles/r06/records_anywidth.log: com-Amazon-shaped N = 7 / 30 / 41 / 47 / 62 x1.15 / x1.19 / x1.32 / x1.35 / x1.20;
+//     products-shaped N = 7 / 10 / 15 x1.50 / x1.55 / x1.42 (N = 20 ... 62 level: mean degree 50, not taken).
 bool want_record_tables(const PlanFacts& f, bool reordered, double hits_after) {
     if (f.kernel_choice == GESPMM_PLAN_KERNEL_RECORDS) return true;
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO || f.variant != GESPMM_VARIANT_AUTO) return false;

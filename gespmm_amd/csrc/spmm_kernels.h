@@ -198,7 +198,7 @@ inline int staged_tasks_per_block(int64_t N) {
 }
 inline bool staged_serves_any(int64_t M, int64_t K, int64_t N) { return staged_kernel_class(M, K, N) != kStagedNone; }
 
-// spmm_records.hip — the padded-record kernel (round 6): narrow widths (N <= 64, N % 4 == 0), short rows, sum reducer, plans only. A row
+// spmm_records.hip — the padded-record kernel (round 6): narrow widths (4 <= N <= 64), short rows, sum reducer, plans only. A row
 // is cut into pieces of kRecordPiece padded entry slots; a wavefront is 64 / W chains (W = records_group(N) lanes each) and consumes one
 // BATCH = one piece per chain per step (headers + entries: one coalesced load per lane), a task = consecutive rows dealt to the chains,
 // cut at `target_batches` batches. Offsets into B / C are pre-multiplied 32-bit byte offsets.

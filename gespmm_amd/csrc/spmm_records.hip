@@ -1,4 +1,4 @@
-// spmm_records.hip — the padded-record kernel: narrow widths (N <= 64), short rows, plans only (round 6).
+// spmm_records.hip — the padded-record kernel: narrow widths (4 <= N <= 64), short rows, plans only (round 6).
 //
 // What bounds the streaming kernels at N = 32 on a graph of 5.5 entries per row is not bandwidth (150 MB at 4.4 TB/s) but the
 // chain of dependent round trips a wavefront walks per task — task, then row pointers / C rows / CSR tile, then LDS, then U = 4
@@ -45,7 +45,14 @@ struct RecGeom {
 
 __device__ __forceinline__ int bperm(int byte_addr, int x) { return __builtin_amdgcn_ds_bpermute(byte_addr, x); }
 
-template <int W, int STORE>  // STORE: 0 plain, 1 nt, 2 sc1 nt (written through the XCD's L2 and not kept: what the staged kernels do)
+// A vector of four floats at ANY 4-byte boundary (widths that are not multiples of 4: rows of B and C start where they start).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// STORE: 0 plain, 1 nt, 2 sc1 nt (written through the XCD's L2 and not kept: what the staged kernels do).
+// ANYN: the width is not a multiple of 4 — the lane that would reach past the row's end takes the row's LAST four columns instead
+// (it recomputes up to three columns of its neighbour: same inputs, same order, same bits — the two stores overlap with equal values),
+// and every vector access is 4-byte aligned only (gfx950 serves unaligned global accesses; the compiler is told through the type).
+template <int W, int STORE, bool ANYN>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))) void spmm_records_kernel(RecordArgs a) {
     constexpr int G = 64 / W;
     constexpr int BB = RecGeom<W>::kBatchBytes;
@@ -63,7 +70,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
     const int nb = __builtin_amdgcn_readfirstlane(t.y);
     const char* bp = a.batches + (size_t)first * BB;
     const bool colok = l * 4 < a.n;
-    const uint32_t lbytes = colok ? (uint32_t)l * 16u : 0u;
+    uint32_t lbytes = colok ? (uint32_t)l * 16u : 0u;
+    if constexpr (ANYN) {
+        if (colok && l * 4 + 4 > a.n) lbytes = (uint32_t)(a.n - 4) * 4u;  // (n >= 4)
+    }
     const char* Bb = reinterpret_cast<const char*>(a.B);
     char* Cb = reinterpret_cast<char*>(a.C);
     const bool loader = l * EPL < P;                       // (W = 16: half the lanes carry an entry)
@@ -113,7 +123,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
         }
         float bv[P][4];
 #pragma unroll
-        for (int j = 0; j < P; ++j) load_vec<4>(bv[j], Bb + (size_t)(off[j] + lbytes));
+        for (int j = 0; j < P; ++j) {
+            if constexpr (ANYN) {
+                const f4u t4 = *reinterpret_cast<const f4u*>(Bb + (size_t)(off[j] + lbytes));
+                bv[j][0] = t4[0];
+                bv[j][1] = t4[1];
+                bv[j][2] = t4[2];
+                bv[j][3] = t4[3];
+            } else {
+                load_vec<4>(bv[j], Bb + (size_t)(off[j] + lbytes));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const bool live = j < len;  // (a select, not a branch: a branch lets the compiler sink the gather under it)
@@ -125,7 +145,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
         }
         if (hdr.y & 0x100) {  // the row's last piece
             if (colok) {
-                if constexpr (STORE == 2) {
+                if constexpr (ANYN) {
+                    f4u o;
+                    o[0] = acc[0];
+                    o[1] = acc[1];
+                    o[2] = acc[2];
+                    o[3] = acc[3];
+                    *reinterpret_cast<f4u*>(Cb + (size_t)((uint32_t)hdr.x + lbytes)) = o;
+                } else if constexpr (STORE == 2) {
                     using f4 = typename VecT<4>::type;
                     f4 o;
                     o[0] = acc[0];
@@ -333,7 +360,7 @@ hipError_t build_g(int64_t M, const int32_t* rowptr, const int32_t* colind, cons
 }  // namespace
 
 int records_group(int64_t N) {
-    if (N < 4 || N > 64 || (N % 4) != 0) return 0;
+    if (N < 4 || N > 64) return 0;
     return N <= 16 ? 4 : (N <= 32 ? 8 : 16);
 }
 
@@ -389,11 +416,12 @@ hipError_t launch_spmm_records(const RecordTables& t, const float* B, float* C, 
     if (nwg == 0) return hipSuccess;
     static const int env_store = getenv("GESPMM_REC_STORE") ? atoi(getenv("GESPMM_REC_STORE")) : -1;  // experiments
     const int store = env_store >= 0 ? env_store : ((flags & kFlagNtStore) ? 1 : 2);
-#define GESPMM_REC_LAUNCH(W_)                                                                                        \
-    do {                                                                                                             \
-        if (store == 2) hipLaunchKernelGGL((spmm_records_kernel<W_, 2>), dim3(nwg), dim3(kThreads), 0, st, a);       \
-        else if (store == 1) hipLaunchKernelGGL((spmm_records_kernel<W_, 1>), dim3(nwg), dim3(kThreads), 0, st, a);  \
-        else hipLaunchKernelGGL((spmm_records_kernel<W_, 0>), dim3(nwg), dim3(kThreads), 0, st, a);                  \
+#define GESPMM_REC_LAUNCH(W_)                                                                                               \
+    do {                                                                                                                    \
+        if (N % 4 != 0) hipLaunchKernelGGL((spmm_records_kernel<W_, 0, true>), dim3(nwg), dim3(kThreads), 0, st, a);        \
+        else if (store == 2) hipLaunchKernelGGL((spmm_records_kernel<W_, 2, false>), dim3(nwg), dim3(kThreads), 0, st, a);  \
+        else if (store == 1) hipLaunchKernelGGL((spmm_records_kernel<W_, 1, false>), dim3(nwg), dim3(kThreads), 0, st, a);  \
+        else hipLaunchKernelGGL((spmm_records_kernel<W_, 0, false>), dim3(nwg), dim3(kThreads), 0, st, a);                  \
     } while (0)
     switch (t.group) {
         case 4: GESPMM_REC_LAUNCH(4); break;

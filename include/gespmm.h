@@ -313,7 +313,7 @@ typedef struct gespmm_plan_options {
                                           analysis; rows beyond 2048 entries go to the long-row pass). AUTO takes it for clustered
                                           matrices with mean degree >= 12 (N = 128) / >= 5 (wider) when >= 60 % (N = 128) / 42 % of
                                           the entries find their B row staged (csrc/plan_policy.cpp: hold-out audit) */
-#define GESPMM_PLAN_KERNEL_RECORDS 6    /* padded-record kernel (since 0.3, round 6): N <= 64 and a multiple of 4, rows of <= 1024 entries, sum reducer,
+#define GESPMM_PLAN_KERNEL_RECORDS 6    /* padded-record kernel (since 0.3, round 6): 4 <= N <= 64, rows of <= 1024 entries, sum reducer,
                                           max(M, K) * N * 4 < 4 GB — the plan lays its copy of the matrix out as batches of 8-slot row pieces
                                           (one coalesced load per lane, all 8 gathers of a piece in flight at once); AUTO takes it for short
                                           rows at narrow widths; other launches of the plan fall back to the streaming kernels */

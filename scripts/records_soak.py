@@ -1,6 +1,6 @@
 """Soak of the padded-record kernel (csrc/spmm_records.hip): seeded random matrices (the generator of scripts/staged_soak.py: empty rows,
 rows of 1 .. 300 entries, local and scattered columns, K != M, now and then one row of 700 .. 1024 entries — and one beyond the limit, which
-must fall back) through a forced records plan at random widths 4 .. 64 (lane groups of 4 / 8 / 16, masked tail lanes), clustered and storage
+must fall back) through a forced records plan at random widths 4 .. 64 (lane groups of 4 / 8 / 16; multiples of 4 and not), clustered and storage
 order, random task lengths, against the plain call's strict-order bits — valued, unweighted, and after new values.
     python scripts/records_soak.py [first_seed] [count]"""
 import os, sys, time
@@ -35,7 +35,7 @@ def soak(first, count, verbose=True):
         rp, ci = torch.from_numpy(rowptr).cuda(), torch.from_numpy(colind).cuda()
         val = torch.from_numpy((rng.rand(colind.size).astype(np.float32) - 0.5)).cuda()
         val2 = torch.from_numpy((rng.rand(colind.size).astype(np.float32) - 0.5)).cuda()
-        for N in (4 * int(rng.randint(1, 5)), 4 * int(rng.randint(5, 9)), 4 * int(rng.randint(9, 17))):
+        for N in (4 * int(rng.randint(1, 5)), 4 * int(rng.randint(5, 9)), 4 * int(rng.randint(9, 17)), int(rng.randint(4, 65))):
             B = torch.from_numpy((rng.rand(K, N).astype(np.float32) - 0.5)).cuda()
             reorder = bool(rng.rand() < 0.7)
             plan = spmm.SpmmPlan(rp, ci, K, N, values=val, reorder=reorder, kernel="records", flags=0x100)

@@ -1,4 +1,4 @@
-"""The plan's padded-record kernel (csrc/spmm_records.hip): narrow widths (N <= 64, N % 4 == 0), rows of <= 1024 entries, sum reducer.
+"""The plan's padded-record kernel (csrc/spmm_records.hip): narrow widths (4 <= N <= 64), rows of <= 1024 entries, sum reducer.
 A row is cut into pieces of 8 padded entry slots that stay in ONE lane group's chain, in order — every output element is still one
 fp32 accumulator over the row's entries in ascending CSR position with one fused multiply-add per entry (the reference's kernels:
 spmm_test.cu:182-203) — so the bits must equal the oracle's `fma` arithmetic and the plain call's, whatever the padding."""
@@ -15,7 +15,8 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("N", (4, 8, 12, 16, 20, 32, 36, 48, 64))  # lane groups of 4 (N <= 16), 8 (N <= 32), 16 (N <= 64)
+@pytest.mark.parametrize("N", (4, 5, 7, 8, 12, 16, 17, 20, 30, 32, 36, 41, 47, 48, 63, 64))  # lane groups of 4 (N <= 16), 8 (N <= 32), 16 (N <= 64); widths that are
+# not multiples of 4: 4-byte-aligned vectors, the lane at the row's end takes the last four columns
 @pytest.mark.parametrize("reorder", (True, False))
 @pytest.mark.parametrize("graph", ("cora", "pubmed"))
 def test_bits_equal_oracle_valued_unweighted_and_new_values(pkg, oracle, bundled, graph, reorder, N):
@@ -49,7 +50,7 @@ def test_bits_equal_oracle_valued_unweighted_and_new_values(pkg, oracle, bundled
     assert np.array_equal(bits(got_max), bits(oracle.spmm_max(g["rowptr"], g["colind"], B_h, -10000.0))), (graph, N)
 
 
-@pytest.mark.parametrize("N", (16, 32, 64))
+@pytest.mark.parametrize("N", (16, 32, 47, 64))
 def test_edge_shapes(pkg, oracle, N):
     """Empty rows (leading, trailing, runs of them), rows of 1..200 entries (1 to 25 pieces in one chain), repeated and unsorted
     columns, K != M, M smaller than one task and not a multiple of the rows per task."""
@@ -141,4 +142,4 @@ def test_reduced_soak_of_the_record_kernel(pkg):
     import records_soak
 
     checked, served = records_soak.soak(71000, 120, verbose=False)
-    assert checked >= 900 and served >= 250, (checked, served)
+    assert checked >= 1200 and served >= 330, (checked, served)

@@ -221,7 +221,8 @@ def test_padded_record_kernel_rules():
     assert q(N=32, hits_after=0.675, record_slot_fill=0.46)["keep_records"] == 0  # (LFR with 16-row tasks: behind the streaming kernel)
     assert q(N=16, hits_after=0.686, record_slot_fill=0.42)["keep_records"] == 0 and q(N=16, hits_after=0.686, record_slot_fill=0.53)["keep_records"] == 1
     assert q(N=64, hits_after=0.668)["build_records"] == 1
-    for kw in (dict(N=128, hits_after=0.66), dict(N=30, hits_after=0.675), dict(N=32, hits_after=0.222),
+    assert q(N=47, hits_after=0.67)["build_records"] == 1  # (41 / 47 classes: 4-byte-aligned vectors, records_anywidth.log)
+    for kw in (dict(N=128, hits_after=0.66), dict(N=3, hits_after=0.675), dict(N=66, hits_after=0.675), dict(N=32, hits_after=0.222),
                dict(N=32, hits_after=0.675, max_degree=2726), dict(N=32, hits_after=0.675, variant=_lib.VARIANT_CRC)):
         assert q(**kw)["build_records"] == 0, kw
     # rows of 50 entries (products-shaped, a quarter of the size): the lane-group staged kernel keeps N = 32 / 64, records take N = 16
@@ -230,6 +231,6 @@ def test_padded_record_kernel_rules():
     assert (p32["keep_staged"], p32["build_records"]) == (1, 0)
     p16 = _lib.plan_policy(N=16, **prod)
     assert (p16["build_records"], p16["records_batches"]) == (1, 11)
-    # asked for by name: any order, any mean degree (still N <= 64, N % 4 == 0, rows <= 1024)
+    # asked for by name: any order, any mean degree (still 4 <= N <= 64, rows <= 1024)
     assert _lib.plan_policy(N=32, kernel=_lib.PLAN_KERNEL_RECORDS, reorder=_lib.PLAN_NO_REORDER, **{**prod, "hits_after": 0.04})["build_records"] == 1
     assert _lib.plan_policy(N=32, kernel=_lib.PLAN_KERNEL_RECORDS, **{**prod, "max_degree": 1500})["build_records"] == 0
