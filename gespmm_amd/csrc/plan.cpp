@@ -47,6 +47,7 @@ struct gespmm_plan {
     bool valued = false;
     int32_t max_degree = 0;
     bool reordered = false;
+    bool identity_order = false;  // reordered, but the plan's copy is in the caller's order (a matrix that arrived clustered: the staged-rows kernel needs the plan's tables)
     void* d_block = nullptr;  // device analysis: perm / rowptr / colind / src_begin (/ val) are parts of this ONE allocation
     bool val_in_block = false;
     int32_t* d_rowptr = nullptr;
@@ -98,6 +99,11 @@ struct gespmm_plan {
 };
 
 namespace {
+
+__global__ void iota_kernel(int32_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
 
 __global__ void permute_values_kernel(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ src_begin,
                                       const float* __restrict__ val, float* __restrict__ val_p, int M, int nnz) {
@@ -526,7 +532,22 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
                 delete p;
                 return (int)e;
             }
-            if (!gespmm::keep_clustered_order(f, ad, p->hits_before, p->hits_after)) {
+            if (!gespmm::keep_clustered_order(f, ad, p->hits_before, p->hits_after) && !dense_try && gespmm::storage_order_wants_plan_copy(f, p->hits_before)) {
+                // The matrix ARRIVED in an order as good as the clustering's (a caller who keeps the graph by community): the staged-rows
+                // kernel still needs the plan's own tables, so the plan copies the matrix in the IDENTITY order and goes on as if it had
+                // clustered it (dropped again below if the tables are not kept: then nothing is paid per launch, as before)
+                hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, p->d_perm, (int)M);
+                e = hipGetLastError();
+                if (e == hipSuccess)
+                    e = gespmm::device_permute_csr(M, nnz, rowptr, colind, p->d_perm, p->d_rowptr, p->d_colind, p->d_src_begin, st);
+                if (e != hipSuccess) {
+                    free_device(p);
+                    delete p;
+                    return (int)e;
+                }
+                p->hits_after = p->hits_before;
+                p->identity_order = true;
+            } else if (!gespmm::keep_clustered_order(f, ad, p->hits_before, p->hits_after)) {
                 reorder = false;  // the storage order (or the cache-blocked path) is as good: keep it and pay nothing per launch
                 (void)hipFree(p->d_block);
                 p->d_block = nullptr;
@@ -575,8 +596,23 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
                 delete p;
                 return (int)e;
             }
-            p->reordered = true;
-            if (kd.shallow_unroll) p->launch_flags |= GESPMM_FLAG_SHALLOW_UNROLL;
+            if (p->identity_order && !p->staging_kept_by_policy) {
+                // the copy in storage order was made for the staged-rows kernel alone: without its tables the caller's arrays serve
+                gespmm::free_staging(&p->stg);
+                if (p->d_tasks) (void)hipFree(p->d_tasks);
+                p->d_tasks = p->d_gtasks = nullptr;
+                p->ntasks = p->ngtasks = 0;
+                p->gtasks_shared = false;
+                (void)hipFree(p->d_block);
+                p->d_block = nullptr;
+                p->d_perm = p->d_rowptr = p->d_colind = p->d_src_begin = nullptr;
+                p->d_val = nullptr;
+                p->val_in_block = false;
+                p->identity_order = false;
+            } else {
+                p->reordered = true;
+                if (kd.shallow_unroll) p->launch_flags |= GESPMM_FLAG_SHALLOW_UNROLL;
+            }
             reorder = false;  // done: skip the host branch
         }
 
@@ -685,7 +721,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
         return GESPMM_ENOMEM;
     }
     // ---- padded-record kernel (narrow widths, short rows): when asked for, or when the policy says so (plan_policy.cpp)
-    if (gespmm::records_serves(M, K, N, p->max_degree) && nnz > 0 && gespmm::want_record_tables(p->facts, p->reordered, p->hits_after) &&
+    if (gespmm::records_serves(M, K, N, p->max_degree) && nnz > 0 && gespmm::want_record_tables(p->facts, p->reordered ? p->hits_after : p->hits_before) &&
         !(p->stg.ev && p->staging_kept_by_policy)) {
         e = build_record_tables(p, st);
         if (e == hipErrorOutOfMemory) {  // (padding beyond the cap, or no memory: the other kernels serve the plan)
@@ -1053,9 +1089,10 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
             snprintf(tuned, sizeof tuned, " tuned[us: batch-stream=%.1f segmented-stream=%.1f staged-rows=%.1f batch-stream-V4=%.1f padded-records=%.1f]",
                      p->tune_us[0], p->tune_us[1], p->tune_us[2], p->tune_us[3], p->tune_us[4]);
         n = snprintf(out, (size_t)capacity,
-                     "order=clustered levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d probe=%.3f l2_model=%.3f->%.3f "
+                     "order=%s levels=%d clusters=%s tasks=%d task_entries=%d group_tasks=%d max_degree=%d probe=%.3f l2_model=%.3f->%.3f "
                      "analysis=%.4fs on the %s (clustering %.4fs)%s | %s",
-                     p->stats.levels, lv, p->ntasks, p->task_entries, p->ngtasks, p->max_degree, p->facts.wedge_probe, p->hits_before,
+                     p->identity_order ? "storage(plan copy: as local as the clustering)" : "clustered", p->stats.levels, lv, p->ntasks, p->task_entries,
+                     p->ngtasks, p->max_degree, p->facts.wedge_probe, p->hits_before,
                      p->hits_after, p->analysis_seconds, p->analysis == GESPMM_PLAN_ANALYSIS_HOST ? "host" : "device", p->cluster_seconds, tuned, kern);
     } else {
         char why[200] = "";

@@ -234,6 +234,15 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after) {
     return d;
 }
 
+// A matrix that arrives in an order as local as the clustering's (the headline graph relabelled in its planted order models 0.70 in storage
+// order, 0.66 clustered): until round 6 it kept its storage order AND the streaming kernels — N = 128 122 us where the same graph shuffled
+// runs 82 through the staged-rows kernel (profiles/r06/records_preordered.log). Same rule as for a clustered order: choose_plan_kernel on the
+// storage order's modelled hits.
+bool storage_order_wants_plan_copy(const PlanFacts& f, double hits_before) {
+    if (f.reorder_mode != GESPMM_PLAN_REORDER_AUTO || f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO || f.host_analysis || hits_before < 0.0) return false;
+    return choose_plan_kernel(f, hits_before).build_staged;
+}
+
 bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     // Not enough reuse inside the blocks: the streaming kernels stay. The share of entries that find their B row staged is what
     // separates the graphs where the kernel wins from those where it loses — on the repository's stand-ins AND on the hold-out
@@ -285,10 +294,12 @@ bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
 //   Widths that are not multiples of 4 (4-byte-aligned vectors; the streaming kernels fall to one float per lane there) under the same
 //     rule, profiles/r06/records_anywidth.log: com-Amazon-shaped N = 7 / 30 / 41 / 47 / 62 x1.15 / x1.19 / x1.32 / x1.35 / x1.20;
 //     products-shaped N = 7 / 10 / 15 x1.50 / x1.55 / x1.42 (N = 20 ... 62 level: mean degree 50, not taken).
-bool want_record_tables(const PlanFacts& f, bool reordered, double hits_after) {
+//   `order_hits`: the modelled L2 hits of the order the plan PROCESSES the rows in — the clustered order if it was kept, the storage order
+//   if the model judged it as good (a matrix that arrives clustered: profiles/r06/records_preordered.log); negative = never modelled.
+bool want_record_tables(const PlanFacts& f, double order_hits) {
     if (f.kernel_choice == GESPMM_PLAN_KERNEL_RECORDS) return true;
     if (f.kernel_choice != GESPMM_PLAN_KERNEL_AUTO || f.variant != GESPMM_VARIANT_AUTO) return false;
-    if (!reordered || hits_after < 0.60 || f.nnz < (1 << 20) || f.M <= 0) return false;
+    if (order_hits < 0.60 || f.nnz < (1 << 20) || f.M <= 0) return false;
     return f.N <= 16 || (double)f.nnz / (double)f.M <= 8.0;
 }
 
@@ -475,7 +486,7 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
         a->staged_rows = sh.waves ? gespmm::staged_rows_for(f, sh.rows, sh.waves) : 0;
     }
     // the padded-record kernel (plan.cpp builds its tables after the staged ones: not beside tables that were kept)
-    a->build_records = gespmm::records_serves(q->M, q->K, q->N, q->max_degree) && q->nnz > 0 && gespmm::want_record_tables(f, keep, q->hits_after) &&
+    a->build_records = gespmm::records_serves(q->M, q->K, q->N, q->max_degree) && q->nnz > 0 && gespmm::want_record_tables(f, !ad.analyse ? -1.0 : (keep ? q->hits_after : q->hits_before)) &&
                        !a->keep_staged;
     a->keep_records = a->build_records && (q->record_slot_fill < 0.0 || gespmm::keep_record_tables(f, q->record_slot_fill));
     a->records_batches = gespmm::records_batches_per_task(f);

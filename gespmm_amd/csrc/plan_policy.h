@@ -90,9 +90,12 @@ PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after);
 
 // ---- the staged tables exist: does enough of the matrix find its B row staged?
 bool keep_staged_tables(const PlanFacts& f, double staged_fraction);
-// Padded-record kernel (spmm_records.hip): are its tables built for this plan (reordered: the clustered order was kept; hits_after: its
-// modelled L2 hits, < 0 unknown), and the batches a wavefront task is cut at.
-bool want_record_tables(const PlanFacts& f, bool reordered, double hits_after);
+// The clustering was judged no better than the storage order (keep_clustered_order == false): does the plan still make its own copy
+// of the matrix, in the storage order, because the staged-rows kernel — which walks the plan's tables — would be built for it?
+bool storage_order_wants_plan_copy(const PlanFacts& f, double hits_before);
+// Padded-record kernel (spmm_records.hip): are its tables built for this plan (order_hits: modelled L2 hits of the order the plan
+// processes the rows in, < 0 unknown), and the batches a wavefront task is cut at.
+bool want_record_tables(const PlanFacts& f, double order_hits);
 int records_batches_per_task(const PlanFacts& f);
 bool keep_record_tables(const PlanFacts& f, double slot_fill);  // slot_fill: share of the batches' entry slots that carry an entry
 

@@ -419,6 +419,24 @@ def add_self_loops(rowptr, colind):
     return newptr.to(torch.int32), c.to(torch.int32)
 
 
+def relabel_by_order(rowptr, colind, order):
+    """The square matrix with vertex order[i] renamed to i (rows AND columns), columns sorted inside every row: what a caller who keeps
+    the graph in a community order hands over. ``order`` is a permutation of range(M) (e.g. argsort of the planted labels)."""
+    M = rowptr.numel() - 1
+    dev = rowptr.device
+    order = order.to(dev).long()
+    new_id = torch.empty(M, dtype=torch.int64, device=dev)
+    new_id[order] = torch.arange(M, device=dev)
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    rows_old = torch.repeat_interleave(torch.arange(M, device=dev), deg)
+    r, c = new_id[rows_old], new_id[colind.long()]
+    idx = torch.argsort(r * M + c)
+    r, c = r[idx], c[idx]
+    rp = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+    rp[1:] = torch.cumsum(torch.bincount(r, minlength=M), 0)
+    return rp.to(torch.int32), c.to(torch.int32)
+
+
 def transpose_csr(rowptr, colind, K=None, val=None):
     """CSC arrays (colptr, rowind[, cscval]) of a CSR pattern, rows ascending inside a
     column — host-side helper for callers that build both orders once, like

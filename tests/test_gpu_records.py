@@ -143,3 +143,46 @@ def test_reduced_soak_of_the_record_kernel(pkg):
 
     checked, served = records_soak.soak(71000, 120, verbose=False)
     assert checked >= 1200 and served >= 330, (checked, served)
+
+
+def test_a_matrix_that_arrives_clustered_keeps_its_order_and_takes_the_record_kernel(pkg, oracle):
+    """The headline graph relabelled in its planted order: the plan judges the storage order as good as its own clustering, keeps it
+    (no permuted copy) — and AUTO still launches the padded-record kernel at N = 32, by the modelled hits of the storage order."""
+    from gespmm_amd import graphs, spmm
+    from helpers import sampled_rows_equal_oracle
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    rp, ci = graphs.relabel_by_order(g["rowptr"], g["colind"], torch.argsort(g["truth"]))
+    val = torch.from_numpy(oracle.hash_val(g["nnz"], seed=7)).cuda()
+    B = torch.from_numpy(oracle.hash_B(g["K"], 32, seed=3)).cuda()
+    plan = spmm.SpmmPlan(rp, ci, g["K"], 32, values=val, expected_launches=1000000)
+    d = plan.describe()
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    assert torch.equal(got.view(torch.int32), spmm.csr_spmm(rp, ci, val, B).view(torch.int32)), d
+    assert sampled_rows_equal_oracle(oracle, rp, ci, val, B, got, nrows=256, seed=1), d
+    if not plan.clustered:  # (the model may also prefer its own order by a few points: then the rule is the one the audit covers)
+        assert "kernel=padded-records" in d, d
+
+
+def test_a_matrix_that_arrives_clustered_gets_the_staged_kernel_at_wide_widths(pkg, oracle):
+    """Same matrix at N = 128: the plan keeps the caller's order but makes its own copy in it, because the staged-rows kernel walks the
+    plan's tables (until round 6 such a matrix kept the streaming kernels: 122 against 82 us)."""
+    from gespmm_amd import graphs, spmm
+    from helpers import sampled_rows_equal_oracle
+
+    g = graphs.synthetic_graph("com-amazon-sbm", seed=42, device="cuda")
+    rp, ci = graphs.relabel_by_order(g["rowptr"], g["colind"], torch.argsort(g["truth"]))
+    val = torch.from_numpy(oracle.hash_val(g["nnz"], seed=7)).cuda()
+    B = torch.from_numpy(oracle.hash_B(g["K"], 128, seed=3)).cuda()
+    plan = spmm.SpmmPlan(rp, ci, g["K"], 128, values=val, expected_launches=1000000)
+    d = plan.describe()
+    assert "kernel=staged-rows" in d, d
+    got = spmm.csr_spmm(rp, ci, val, B, plan=plan)
+    assert torch.equal(got.view(torch.int32), spmm.csr_spmm(rp, ci, val, B).view(torch.int32)), d
+    assert sampled_rows_equal_oracle(oracle, rp, ci, val, B, got, nrows=256, seed=2), d
+    if "order=storage(plan copy" in d:
+        assert plan.order().tolist()[:5] == [0, 1, 2, 3, 4]
+    # new values through the same plan
+    val2 = torch.from_numpy(oracle.hash_val(g["nnz"], seed=9)).cuda()
+    got2 = spmm.csr_spmm(rp, ci, val2, B, plan=plan)
+    assert torch.equal(got2.view(torch.int32), spmm.csr_spmm(rp, ci, val2, B).view(torch.int32))
