@@ -40,6 +40,7 @@ cp profiles/bench_extra_last.json $O/bench_extra_round6.json
 ( time python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --graph rmat --rmat-scale 24 --steps 5 --warmup 2 ) > $O/bench_rmat24_torchrun1.log 2>&1
 timeout 600 python scripts/plan_ms.py com-amazon-sbm com-amazon-like pubmed-like products-sbm 2>&1 | grep -v amdgpu | cut -c1-400 > $O/plan_ms.log
 timeout 2400 python -m pytest tests -m gpu -q -rs > $O/pytest_gpu_final.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu_final.log
+timeout 900 python scripts/records_soak.py 9000 300 2>&1 | grep -v amdgpu > $O/records_soak.log
 grep "^{" $O/bench_round6.log | cut -c1-4000; cat $O/bench_round6.time; grep "^{" $O/bench_rmat24_torchrun1.log | cut -c1-1500
 cat $O/pmc_digest.log | head -120
 tail -4 $O/pytest_gpu_final.log | cut -c1-300
