@@ -688,6 +688,25 @@ def main():
                                                            "order": (rdef.get("plan") or "")[:13]}}
             series[other].update({k: v for k, v in ceiling_for(gs, N, r["frac"]).items() if k != "ceiling_note"})
             del gs
+            # ---- round 6: the planted-community graph ARRIVING in its community order (rows and columns relabelled by the planted labels:
+            #      a caller who keeps the graph that way). The plan keeps the caller's order; the fast kernels still apply
+            try:
+                torch.cuda.empty_cache()
+                gp = graphs.synthetic_graph("com-amazon-sbm", seed=42, device=dev)
+                rpp, cip = graphs.relabel_by_order(gp["rowptr"], gp["colind"], torch.argsort(gp["truth"]))
+                gpo = {"M": gp["M"], "K": gp["K"], "nnz": gp["nnz"], "rowptr": rpp, "colind": cip}
+                del gp
+                arr = {}
+                for n3 in (N, 32):
+                    r3 = measure_graph(gpo, val, n3, True, expected_launches=STEADY_STATE)
+                    p3 = measure_graph(gpo, val, n3, True, use_plan=False)
+                    extra["com-amazon-sbm_planted_order_N%d_valued" % n3] = r3
+                    arr["N%d" % n3] = {"kernel_us": r3["kernel_us"], "frac": r3["frac"], "plain_call_kernel_us": p3["kernel_us"],
+                                       "plan": (r3.get("plan") or "")[:28] + " | " + (r3.get("plan") or "").split("|")[-1].strip()[:22]}
+                series["com-amazon-sbm_arriving_in_planted_order"] = arr
+                del gpo, rpp, cip
+            except Exception as ex:  # noqa: BLE001
+                series["com-amazon-sbm_arriving_in_planted_order"] = {"skipped": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
 
             # ---- the second graph of BASELINE configs[1]: reddit-shaped x N=128 (cache-blocked path), sampled rows verified
             torch.cuda.empty_cache()
