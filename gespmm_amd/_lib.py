@@ -96,6 +96,7 @@ PLAN_KERNEL_STREAM = 1
 PLAN_KERNEL_SEG_STREAM = 3
 PLAN_KERNEL_STAGED = 5
 PLAN_KERNEL_RECORDS = 6
+PLAN_KERNEL_STAGED_SLABS = 7
 
 
 class LaunchCfg(Structure):

@@ -84,6 +84,10 @@ struct gespmm_plan {
     // staged-rows kernel (spmm_staged.hip): tables for width N (plan_device.hip: device_build_staging)
     gespmm::StagingTables stg;
     double staging_seconds = 0.0;
+    // column-slab tables (round 6; dense clustered matrices at N = 128): staged tables of the slab view, one launch per slab (plan_run)
+    gespmm::StagingTables slab;
+    gespmm::SlabView slab_view;
+    double slab_seconds = 0.0;
     // padded-record kernel (spmm_records.hip): tables for width N (narrow widths, short rows)
     gespmm::RecordTables rec;
     double records_seconds = 0.0;
@@ -153,6 +157,8 @@ __global__ void scatter_by_index_kernel(const float* __restrict__ src, const int
 
 void free_device(gespmm_plan* p) {
     gespmm::free_staging(&p->stg);
+    gespmm::free_staging(&p->slab);
+    gespmm::free_slab_view(&p->slab_view, false);
     gespmm::free_records(&p->rec);
     if (p->gtasks_shared) p->d_gtasks = nullptr;
     if (p->d_block) {  // the permuted copy is one block
@@ -341,6 +347,33 @@ static hipError_t build_staging_tables(gespmm_plan* p, hipStream_t st) {
     return e;
 }
 
+// Column-slab tables (plan_device.hip: device_build_slab_view): the clustered matrix as P ascending column ranges, staged tables per
+// (block of rows, slab). Leaves p->slab empty when the matrix does not qualify (a row with descending columns: slab order would not be
+// CSR order; a slab of some row beyond the staged kernel's row limit) — the plan's other kernels stay.
+static hipError_t build_slab_tables(gespmm_plan* p, int P, hipStream_t st) {
+    const auto ts = std::chrono::steady_clock::now();
+    const int64_t M = p->M, K = p->K, nnz = p->nnz, N = p->N;
+    gespmm::StagedShape shape = gespmm::staged_shape(N);
+    static const int rows_env = getenv("GESPMM_SLAB_ROWS") ? atoi(getenv("GESPMM_SLAB_ROWS")) : 0;  // experiments
+    if (rows_env > 0) shape.rows = rows_env;
+    if (N != 128 || shape.waves != 16 || shape.slots != 160 || P < 2 || nnz <= 0 || !gespmm::staged_serves(M, K, N) ||
+        !gespmm::staged_stream_fits(M * P, nnz) || M * P >= (1ll << 30))
+        return hipSuccess;
+    hipError_t e = gespmm::device_build_slab_view(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, p->d_perm, P,
+                                                  &p->slab_view, st);
+    if (e == hipSuccess && (!p->slab_view.sorted || p->slab_view.max_row > gespmm::kStagedMaxRow)) {
+        gespmm::free_slab_view(&p->slab_view, false);
+        return hipSuccess;
+    }
+    if (e == hipSuccess)
+        e = gespmm::device_build_staging(M * P, K, nnz, p->slab_view.rowptr_v, p->slab_view.colind_v, p->slab_view.val_v, p->slab_view.perm_v,
+                                         shape.rows, shape.slots, shape.waves, shape.waves, &p->slab, st, M, true);
+    gespmm::free_slab_view(&p->slab_view, e == hipSuccess);  // (the view's column indices / values / row map are in the tables now)
+    if (e != hipSuccess) gespmm::free_staging(&p->slab);
+    p->slab_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+    return e;
+}
+
 static double record_slot_fill(const gespmm_plan* p) {  // share of the entry slots of the batches that carry an entry
     if (!p->rec.batches || p->rec.nbatches <= 0) return 0.0;
     return (double)p->nnz / ((double)p->rec.nbatches * (64 / p->rec.group) * gespmm::kRecordPiece);
@@ -374,7 +407,7 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
     if (reorder_mode < 0 || reorder_mode > 2) return GESPMM_EINVAL;
     const int kernel_mode = opt ? opt->kernel : GESPMM_PLAN_KERNEL_AUTO;
     if (kernel_mode != GESPMM_PLAN_KERNEL_AUTO && kernel_mode != GESPMM_PLAN_KERNEL_STREAM && kernel_mode != GESPMM_PLAN_KERNEL_SEG_STREAM &&
-        kernel_mode != GESPMM_PLAN_KERNEL_STAGED && kernel_mode != GESPMM_PLAN_KERNEL_RECORDS)
+        kernel_mode != GESPMM_PLAN_KERNEL_STAGED && kernel_mode != GESPMM_PLAN_KERNEL_RECORDS && kernel_mode != GESPMM_PLAN_KERNEL_STAGED_SLABS)
         return GESPMM_EINVAL;
     if (opt && opt->expected_launches < 0) return GESPMM_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -591,6 +624,18 @@ static int plan_create_impl(gespmm_plan** out, const int32_t* rowptr, const int3
                 p->staging_kept_by_policy = p->stg.ev != nullptr;
                 lap("staging tables");
             }
+            // ---- column-slab tables (dense clustered matrices at N = 128: plan_policy.cpp slab_count_for / keep_slab_tables)
+            if (e == hipSuccess && !p->identity_order) {
+                const int P = gespmm::slab_count_for(f);
+                if (P >= 2) {
+                    e = build_slab_tables(p, P, st);
+                    if (e == hipSuccess && p->slab.ev && !gespmm::keep_slab_tables(f, p->slab.staged_fraction)) {
+                        gespmm::free_staging(&p->slab);
+                        gespmm::free_slab_view(&p->slab_view, false);
+                    }
+                    lap("slab tables");
+                }
+            }
             if (e != hipSuccess) {
                 free_device(p);
                 delete p;
@@ -803,6 +848,23 @@ static int plan_run(gespmm_plan* p, const float* B, float* C, int64_t N, int red
         if (guard && guard->word == nullptr) return 0;  // (dry run: one kernel, guardable)
         return (int)gespmm::launch_spmm_records(p->rec, B, C, N, p->launch_flags, guard, reinterpret_cast<hipStream_t>(stream));
     }
+    // column-slab tables: one launch of the staged-rows kernel per slab, the second and later ones continuing from C (sum reducer, the
+    // plan's width, 16-byte operands; an explicit other kernel or a tuned plan keeps its choice)
+    if (p->reordered && p->slab.ev && N == p->N && reduce == gespmm::kReduceSum && variant_v4 && !use_tuned &&
+        (kchoice == GESPMM_PLAN_KERNEL_AUTO || kchoice == GESPMM_PLAN_KERNEL_STAGED_SLABS) && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        if (!B || !C) return GESPMM_EINVAL;
+        if (guard) return gespmm::kNotGuardable;  // (several launches)
+        hipStream_t hst = reinterpret_cast<hipStream_t>(stream);
+        const int P = p->slab_view.slabs, nb = p->slab.nblocks / P;
+        for (int s = 0; s < P; ++s) {
+            gespmm::StagedArgs sa = {p->slab_view.rowptr_v, p->slab.ev, nullptr, p->slab.tasks, p->slab.hot_cols, p->slab.nhot, B, C, nb,
+                                     p->slab.waves, p->slab.slots, 0, nullptr, 0, 0, 0.0f, nullptr, 0, s * nb, s > 0 ? 1 : 0};
+            rc = (int)gespmm::launch_spmm_staged(sa, p->M, p->K, N, hst);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
     if (staged) {
         if (!B || !C) return GESPMM_EINVAL;
         gespmm::StagedArgs sa = {p->stg.rowptr_s ? p->stg.rowptr_s : p->d_rowptr, p->stg.ev, p->d_perm, p->stg.tasks, p->stg.hot_cols,
@@ -861,7 +923,9 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     if (!p || N <= 0 || !B || !C) return GESPMM_EINVAL;
     if (N != p->N) return GESPMM_EINVAL;  // the tables are made for one width
     // a storage-order plan has one launch path, and the caller's explicit choice stands: nothing to measure, but C = A * B as promised
-    if (!p->reordered || p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO)
+    // (... and so does a plan that kept column-slab tables: they are not one of the candidates below, and the rule that kept them —
+    //  half of the entries staged on a matrix of mean degree >= 192 — is far from the margin: 2.29 against 2.97 ms where it fires)
+    if (!p->reordered || p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO || p->slab.ev)
         return plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1025,6 +1089,10 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
             const hipError_t er = gespmm::device_records_set_values(p->rec, p->M, p->d_rowptr, p->d_colind, nullptr, st);
             if (er != hipSuccess) return (int)er;
         }
+        if (p->slab.ev) {
+            const hipError_t es = gespmm::device_slab_set_values(p->slab, p->slab_view, nullptr, p->M * p->slab_view.slabs, p->nnz, st);
+            if (es != hipSuccess) return (int)es;
+        }
         if (p->stg.ev) return (int)gespmm::device_staging_set_values(p->stg, nullptr, p->d_rowptr, p->M, p->nnz, st);  // the stream carries 1.0f
         return 0;
     }
@@ -1038,6 +1106,10 @@ int gespmm_plan_set_values(gespmm_plan* p, const float* val, void* stream) {
                        p->d_src_begin, val, p->d_val, (int)p->M, (int)p->nnz);
     if (p->stg.ev) {
         const hipError_t es = gespmm::device_staging_set_values(p->stg, p->d_val, p->d_rowptr, p->M, p->nnz, st);
+        if (es != hipSuccess) return (int)es;
+    }
+    if (p->slab.ev) {
+        const hipError_t es = gespmm::device_slab_set_values(p->slab, p->slab_view, p->d_val, p->M * p->slab_view.slabs, p->nnz, st);
         if (es != hipSuccess) return (int)es;
     }
     if (p->rec.batches) {
@@ -1076,7 +1148,12 @@ int gespmm_plan_describe(const gespmm_plan* p, char* out, int64_t capacity) {
         for (int i = 0; i < p->stats.levels && i < 16 && off < 100; ++i)
             off += snprintf(lv + off, sizeof lv - (size_t)off, "%s%d", i ? ">" : "", p->stats.clusters[i]);
         char kern[420];
-        if (staged_d && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
+        const bool slab_d = p->slab.ev && !p->tuned && (p->kernel_choice == GESPMM_PLAN_KERNEL_AUTO || p->kernel_choice == GESPMM_PLAN_KERNEL_STAGED_SLABS) &&
+                            (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4);
+        if (slab_d)
+            snprintf(kern, sizeof kern, "kernel=staged-slabs slabs=%d blocks=%d rows_in_lds<=%d staged_entries=%.3f tables=%.4fs (max / other widths: %s)",
+                     p->slab_view.slabs, p->slab.nblocks, p->slab.slots, p->slab.staged_fraction, p->slab_seconds, what);
+        else if (staged_d && (p->variant == GESPMM_VARIANT_AUTO || p->variant >= GESPMM_VARIANT_CRC_CWM4))
             snprintf(kern, sizeof kern, "kernel=staged-rows blocks=%d rows_in_lds<=%d staged_entries=%.3f hub_rows=%d tables=%.4fs (max / other widths: %s)",
                      p->stg.nblocks, gespmm::staged_shape_any(p->N).slots, p->stg.staged_fraction, p->stg.nlong, p->staging_seconds, what);
         else snprintf(kern, sizeof kern, "%s", what);

@@ -72,7 +72,27 @@ hipError_t device_split_long_rows(int64_t M, int64_t nnz, const int32_t* rowptr_
 // `parts`: tasks per block (the wide kernel: one per wavefront = waves; the narrow kernel: one per lane group = waves x G)
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
                                 const float* val_p, const int32_t* perm, int R, int H, int waves, int parts, StagingTables* out,
-                                hipStream_t st);
+                                hipStream_t st, int64_t seg_rows = 0, bool slab_tables = false);
+// (seg_rows > 0: blocks never straddle a segment of seg_rows rows, M a multiple of it; slab_tables: the tables of a column-slab view —
+//  task word 0 = C row of the task's first row, row-end codes carry the C row of the next row: spmm_staged.hip's continuing launches)
+
+// Column-slab view of the clustered matrix (plan_device.hip): P x M rows, slab-major. rowptr_v / src_v stay with the plan (value updates),
+// colind_v / val_v / perm_v are what device_build_staging reads and go once the tables exist. sorted == 0: some row has descending
+// columns — no view was made.
+struct SlabView {
+    int32_t* rowptr_v = nullptr;  // P * M + 1
+    int32_t* src_v = nullptr;     // nnz: entry of the clustered matrix behind each entry of the view
+    int32_t* colind_v = nullptr;  // nnz            (temporary)
+    float* val_v = nullptr;       // nnz or NULL    (temporary)
+    int32_t* perm_v = nullptr;    // P * M          (temporary)
+    int32_t slabs = 0;
+    int32_t max_row = 0;          // longest row of the view
+    int32_t sorted = 0;
+};
+hipError_t device_build_slab_view(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
+                                  const int32_t* perm, int P, SlabView* out, hipStream_t st);
+hipError_t device_slab_set_values(const StagingTables& t, const SlabView& v, const float* val_p, int64_t Mv, int64_t nnz, hipStream_t st);
+void free_slab_view(SlabView* v, bool temporaries_only);
 // val_p: values in the clustered matrix's entry order (NULL: 1.0f); rowptr_p: its row pointers (used when hub rows were split off)
 hipError_t device_staging_set_values(const StagingTables& t, const float* val_p, const int32_t* rowptr_p, int64_t M, int64_t nnz,
                                      hipStream_t st);

@@ -1752,11 +1752,21 @@ constexpr int kStageHistBins = 256;
 constexpr int kStageCounters = 64;  // partial sums of the staged-entry count (power of two)
 constexpr int kStageKeysLds = 8192;  // keys of a block kept in LDS by k_stage_select (32 KB)
 
-__global__ void k_stage_offsets(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int32_t* __restrict__ blkoff) {
+// First row of block `blk`: blocks of R rows that never straddle a SEGMENT of seg_rows rows (column-slab tables: one segment per slab —
+// a launch covers the blocks of one segment; every other table: one segment = the matrix). nb_seg = blocks per segment.
+__device__ __forceinline__ int64_t stage_block_begin(int64_t blk, int R, int64_t seg_rows, int64_t nb_seg, int64_t M) {
+    const int64_t seg = blk / nb_seg, b = blk - seg * nb_seg;
+    int64_t r = seg * seg_rows + b * R;
+    const int64_t lim = (seg + 1) * seg_rows;
+    if (r > lim) r = lim;
+    return r < M ? r : M;
+}
+
+__global__ void k_stage_offsets(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int64_t seg_rows, int64_t nb_seg,
+                                int32_t* __restrict__ blkoff) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nblk) return;
-    const int64_t r = i * R < M ? i * R : M;
-    blkoff[i] = rowptr_p[r];
+    blkoff[i] = rowptr_p[stage_block_begin(i, R, seg_rows, nb_seg, M)];
 }
 
 __global__ void k_stage_iota(int32_t* __restrict__ out, int64_t n) {
@@ -1862,14 +1872,14 @@ __global__ __launch_bounds__(256) void k_stage_select(const int32_t* __restrict_
     }
 }
 
-__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int kStagedWaves,
-                              int32_t* __restrict__ tasks) {
+__global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, int64_t nblk, int R, int64_t seg_rows, int64_t nb_seg,
+                              int kStagedWaves, const int32_t* __restrict__ first_crow, int32_t* __restrict__ tasks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk * kStagedWaves) return;
     const int64_t blk = i / kStagedWaves;
     const int w = (int)(i % kStagedWaves);
-    const int b0 = (int)(blk * R);
-    const int b1 = (int)(b0 + R < M ? b0 + R : M);
+    const int b0 = (int)stage_block_begin(blk, R, seg_rows, nb_seg, M);
+    const int b1 = (int)stage_block_begin(blk + 1, R, seg_rows, nb_seg, M);
     const int e0 = rowptr_p[b0], e1 = rowptr_p[b1];
     auto bound = [&](int ww) -> int {  // first row of part ww: the block's entries cut into kStagedWaves equal shares
         if (ww <= 0) return b0;
@@ -1885,7 +1895,9 @@ __global__ void k_stage_tasks(const int32_t* __restrict__ rowptr_p, int64_t M, i
     };
     const int r0 = bound(w), r1 = bound(w + 1);
     // stream positions: entry p of row r is record p + r (one row-end record behind every row)
-    reinterpret_cast<int4*>(tasks)[i] = make_int4(r0, r1 - r0, rowptr_p[r0] + r0, rowptr_p[r1] + r1);
+    // (word 0 — not read by the kernels since the stream carries the rows — holds the C row of the task's first row in column-slab tables)
+    const int w0 = first_crow ? first_crow[r0 < M ? r0 : (int)M - 1] : r0;
+    reinterpret_cast<int4*>(tasks)[i] = make_int4(w0, r1 - r0, rowptr_p[r0] + r0, rowptr_p[r1] + r1);
 }
 
 __device__ __forceinline__ int row_of_entry(const int32_t* __restrict__ rowptr, int M, int q) {
@@ -1909,10 +1921,16 @@ __global__ void k_stage_interleave(const int32_t* __restrict__ code, const float
 
 // ... row r's end record {kStagedRowEnd, C row of r} at rowptr_p[r + 1] + r, and the padding behind the last row: staged slot 0,
 // value +0 (an LDS read, no memory gather; never summed)
+// (with_next — column-slab tables: the code's low 30 bits carry the C row of the row BEHIND this one, where a continuing launch
+//  picks its accumulators up; the other kernels' address shifts never see such a table)
 __global__ void k_stage_rowends(const int32_t* __restrict__ rowptr_p, const int32_t* __restrict__ perm, int64_t M, int64_t nnz,
-                                int32_t* __restrict__ ev) {
+                                int with_next, int32_t* __restrict__ ev) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M) reinterpret_cast<int2*>(ev)[(int64_t)rowptr_p[t + 1] + t] = make_int2(kStagedRowEnd, perm ? perm[t] : (int)t);
+    if (t < M) {
+        const int64_t tn = t + 1 < M ? t + 1 : t;
+        const int next = with_next ? ((perm ? perm[tn] : (int)tn) & 0x3fffffff) : 0;
+        reinterpret_cast<int2*>(ev)[(int64_t)rowptr_p[t + 1] + t] = make_int2(kStagedRowEnd | next, perm ? perm[t] : (int)t);
+    }
     else if (t < M + kStagedPad) reinterpret_cast<int2*>(ev)[nnz + t] = make_int2((int)0x80000000u, 0);
 }
 
@@ -2020,13 +2038,16 @@ void free_staging(StagingTables* t) {
 
 hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p,
                                 const float* val_p, const int32_t* perm, int R, int H, int waves, int parts, StagingTables* out,
-                                hipStream_t st) {
+                                hipStream_t st, int64_t seg_rows, bool slab_tables) {
     // (rowptr_p / colind_p / val_p / nnz describe what the staged kernel walks: the clustered matrix, or its copy without hub rows —
     // `out` then already carries rowptr_s / ltasks / nlong / nnz_s from device_split_long_rows, which stay)
     if (M <= 0 || nnz <= 0 || K <= 0 || H <= 0 || R <= 0 || waves <= 0 || waves > kStagedMaxWaves || parts < waves || parts > 64 * waves)
         return hipErrorInvalidValue;
     const int kStagedWaves = parts;  // tasks per block
-    const int64_t nblk = (M + R - 1) / R;
+    if (seg_rows <= 0 || seg_rows > M) seg_rows = M;
+    if (M % seg_rows != 0 || (slab_tables && (!perm || M >= (1ll << 30)))) return hipErrorInvalidValue;
+    const int64_t nb_seg = (seg_rows + R - 1) / R;  // blocks per segment (column-slab tables: per slab)
+    const int64_t nblk = (M / seg_rows) * nb_seg;
     // (Round 3 marked columns whose own row sits far away in the clustered order and gathered them `nt`; level or harmful once the block
     // heights and the clustering depth had settled — profiles/r04/far_marks_by_graph.log — and removed in round 5.)
     if (!staged_stream_fits(M, nnz)) return hipErrorInvalidValue;
@@ -2054,7 +2075,7 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
     StagingTables t;  // the four tables built here; merged into *out on success
     auto body = [&]() -> hipError_t {
         GESPMM_TRY(hipMemsetAsync(staged, 0, 8 * kStageCounters, st));
-        hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, R, blkoff);
+        hipLaunchKernelGGL(k_stage_offsets, dim3(grid_for(nblk + 1)), dim3(256), 0, st, rowptr_p, M, nblk, R, seg_rows, nb_seg, blkoff);
         hipLaunchKernelGGL(k_stage_iota, dim3(grid_for(nnz)), dim3(256), 0, st, idx_in, nnz);
         GESPMM_TRY(rocprim::segmented_radix_sort_pairs(tmp, sort_bytes, colind_p, keys, (const int32_t*)idx_in, idx_out, (size_t)nnz,
                                                        (unsigned)nblk, (const int32_t*)blkoff, (const int32_t*)blkoff + 1, 0u,
@@ -2074,10 +2095,11 @@ hipError_t device_build_staging(int64_t M, int64_t K, int64_t nnz, const int32_t
         GESPMM_TRY(hipMemsetAsync(t.hot_cols, 0xFF, (size_t)nblk * H * 4, st));  // unused slots: -1 (the kernel copies nothing for them)
         hipLaunchKernelGGL(k_stage_select, dim3((unsigned)nblk), dim3(256), 0, st, (const int32_t*)blkoff, (const int32_t*)keys,
                            (const int32_t*)idx_out, H, code, t.hot_cols, t.nhot, staged);
-        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, R, kStagedWaves, t.tasks);
+        hipLaunchKernelGGL(k_stage_tasks, dim3(grid_for(nblk * kStagedWaves)), dim3(256), 0, st, rowptr_p, M, nblk, R, seg_rows, nb_seg,
+                           kStagedWaves, slab_tables ? perm : (const int32_t*)nullptr, t.tasks);
         hipLaunchKernelGGL(k_stage_interleave, dim3(grid_for(nnz)), dim3(256), 0, st, (const int32_t*)code, val_p, rowptr_p, (int)M, nnz,
                            t.ev);
-        hipLaunchKernelGGL(k_stage_rowends, dim3(grid_for(M + kStagedPad)), dim3(256), 0, st, rowptr_p, perm, M, nnz, t.ev);
+        hipLaunchKernelGGL(k_stage_rowends, dim3(grid_for(M + kStagedPad)), dim3(256), 0, st, rowptr_p, perm, M, nnz, slab_tables ? 1 : 0, t.ev);
         GESPMM_TRY(hipGetLastError());
         unsigned long long hs[kStageCounters], h = 0;
         GESPMM_TRY(fetch(hs, (const unsigned long long*)staged, kStageCounters, st));  // (synchronises: the temporaries may go)
@@ -2115,6 +2137,153 @@ hipError_t device_staging_set_values(const StagingTables& t, const float* val_p,
     } else if (nnz > 0) {
         hipLaunchKernelGGL(k_stage_values, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, rowptr_p, (int)M, nnz, t.ev);
     }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ column-slab view (round 6)
+//
+// Dense clustered matrices (a reddit-shaped community refers to ~100 000 distinct B rows: a block's 160 LDS slots cover a seventh of its
+// entries): the matrix is cut into P ascending COLUMN ranges, each range of each row becomes a row of a VIEW with P x M rows (slab-major:
+// view row p * M + r = the entries of clustered row r whose column falls in slab p), and the staged tables are built on the view with
+// blocks that never straddle a slab: per (block of rows, slab) its own list of staged columns. Slab p is one launch over its blocks; launch
+// p > 0 continues the rows from the partial sums in C. Needs rows with non-decreasing columns (slab order == CSR order in every row).
+
+namespace {
+
+__device__ __forceinline__ int row_lower_bound(const int32_t* __restrict__ colind, int b, int e, int64_t key) {  // first q in [b, e): col >= key
+    while (b < e) {
+        const int mid = (b + e) >> 1;
+        if ((int64_t)colind[mid] >= key) e = mid;
+        else b = mid + 1;
+    }
+    return b;
+}
+
+__global__ void k_slab_sorted(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int M, int64_t nnz,
+                              int32_t* __restrict__ unsorted) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (q >= nnz) return;
+    if (colind[q - 1] > colind[q]) {
+        const int r = row_of_entry(rowptr, M, (int)q);
+        if (rowptr[r] != (int)q) *unsorted = 1;  // a descent inside a row
+    }
+}
+
+__global__ void k_slab_counts(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, int64_t M, int64_t K, int P,
+                              int32_t* __restrict__ cnt_v, int32_t* __restrict__ max_row) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (i < M * P) {
+        const int64_t p = i / M, r = i - p * M;
+        const int b = rowptr[r], e = rowptr[r + 1];
+        const int lo = row_lower_bound(colind, b, e, (K * p) / P);
+        const int hi = row_lower_bound(colind, lo, e, (K * (p + 1)) / P);
+        c = hi - lo;
+        cnt_v[i] = c;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_down(c, o);
+        c = other > c ? other : c;
+    }
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(max_row, c);
+}
+
+__global__ void k_slab_scatter(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind, const float* __restrict__ val,
+                               const int32_t* __restrict__ rowptr_v, int64_t M, int64_t K, int P, int64_t nnz,
+                               int32_t* __restrict__ colind_v, float* __restrict__ val_v, int32_t* __restrict__ src_v) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz) return;
+    const int r = row_of_entry(rowptr, (int)M, (int)q);
+    const int64_t c = colind[q];
+    int64_t p = (c * P) / K;
+    while (p > 0 && c < (K * p) / P) --p;
+    while (p + 1 < P && c >= (K * (p + 1)) / P) ++p;
+    const int s = row_lower_bound(colind, rowptr[r], rowptr[r + 1], (K * p) / P);
+    const int64_t dest = (int64_t)rowptr_v[p * M + r] + (q - s);
+    colind_v[dest] = (int32_t)c;
+    if (val_v) val_v[dest] = val[q];
+    src_v[dest] = (int32_t)q;
+}
+
+__global__ void k_slab_perm(const int32_t* __restrict__ perm, int64_t M, int P, int32_t* __restrict__ perm_v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * P) return;
+    const int64_t r = i % M;
+    perm_v[i] = perm ? perm[r] : (int32_t)r;
+}
+
+__global__ void k_stage_values_view(const float* __restrict__ val_p, const int32_t* __restrict__ src_v, const int32_t* __restrict__ rowptr_v,
+                                    int Mv, int64_t nnz, int32_t* __restrict__ ev) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz) return;
+    const int r = row_of_entry(rowptr_v, Mv, (int)q);
+    ev[2 * (q + r) + 1] = val_p ? __float_as_int(val_p[src_v[q]]) : 0x3f800000;
+}
+
+}  // namespace
+
+void free_slab_view(SlabView* v, bool temporaries_only) {
+    if (!v) return;
+    for (void* q : {(void*)v->colind_v, (void*)v->val_v, (void*)v->perm_v})
+        if (q) (void)hipFree(q);
+    v->colind_v = nullptr;
+    v->val_v = nullptr;
+    v->perm_v = nullptr;
+    if (temporaries_only) return;
+    for (void* q : {(void*)v->rowptr_v, (void*)v->src_v})
+        if (q) (void)hipFree(q);
+    *v = SlabView();
+}
+
+hipError_t device_build_slab_view(int64_t M, int64_t K, int64_t nnz, const int32_t* rowptr_p, const int32_t* colind_p, const float* val_p,
+                                  const int32_t* perm, int P, SlabView* out, hipStream_t st) {
+    *out = SlabView();
+    if (M <= 0 || K <= 0 || nnz <= 0 || P < 2 || P > 64 || M * P >= (1ll << 30) || nnz >= (1ll << 31) - 64) return hipErrorInvalidValue;
+    const int64_t Mv = M * P;
+    Scratch sc(st);
+    GESPMM_TRY(sc.init(0, 0, 4 * (size_t)(Mv + 1) + (4 << 20)));
+    sc.use(Scratch::kTemp);
+    int32_t *cnt_v = nullptr, *flags = nullptr;
+    GESPMM_TRY(sc.get(&cnt_v, Mv + 1));
+    GESPMM_TRY(sc.get(&flags, 2));
+    SlabView v;
+    auto body = [&]() -> hipError_t {
+        GESPMM_TRY(hipMemsetAsync(flags, 0, 8, st));
+        GESPMM_TRY(hipMemsetAsync(cnt_v + Mv, 0, 4, st));
+        if (nnz > 1) hipLaunchKernelGGL(k_slab_sorted, dim3(grid_for(nnz)), dim3(256), 0, st, rowptr_p, colind_p, (int)M, nnz, flags);
+        hipLaunchKernelGGL(k_slab_counts, dim3(grid_for(Mv)), dim3(256), 0, st, rowptr_p, colind_p, M, K, P, cnt_v, flags + 1);
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&v.rowptr_v), (size_t)(Mv + 1) * 4));
+        GESPMM_TRY(exclusive_scan<int32_t>(sc, cnt_v, v.rowptr_v, Mv + 1, st));
+        int32_t h[2] = {0, 0};
+        GESPMM_TRY(fetch(h, (const int32_t*)flags, 2, st));
+        v.sorted = h[0] ? 0 : 1;
+        v.max_row = h[1];
+        v.slabs = P;
+        if (!v.sorted) return hipSuccess;  // (no view: the caller keeps its other kernels)
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&v.colind_v), (size_t)nnz * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&v.src_v), (size_t)nnz * 4));
+        GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&v.perm_v), (size_t)Mv * 4));
+        if (val_p) GESPMM_TRY(hipMalloc(reinterpret_cast<void**>(&v.val_v), (size_t)nnz * 4));
+        hipLaunchKernelGGL(k_slab_scatter, dim3(grid_for(nnz)), dim3(256), 0, st, rowptr_p, colind_p, val_p, (const int32_t*)v.rowptr_v, M, K,
+                           P, nnz, v.colind_v, v.val_v, v.src_v);
+        hipLaunchKernelGGL(k_slab_perm, dim3(grid_for(Mv)), dim3(256), 0, st, perm, M, P, v.perm_v);
+        GESPMM_TRY(hipGetLastError());
+        return hipStreamSynchronize(st);
+    };
+    const hipError_t e = body();
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        free_slab_view(&v, false);
+        return e;
+    }
+    *out = v;
+    return hipSuccess;
+}
+
+hipError_t device_slab_set_values(const StagingTables& t, const SlabView& v, const float* val_p, int64_t Mv, int64_t nnz, hipStream_t st) {
+    if (!t.ev || !v.src_v || nnz <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stage_values_view, dim3(grid_for(nnz)), dim3(256), 0, st, val_p, (const int32_t*)v.src_v, (const int32_t*)v.rowptr_v,
+                       (int)Mv, nnz, t.ev);
     return hipGetLastError();
 }
 

@@ -243,6 +243,28 @@ bool storage_order_wants_plan_copy(const PlanFacts& f, double hits_before) {
     return choose_plan_kernel(f, hits_before).build_staged;
 }
 
+// Column-slab tables (plan.cpp: build_slab_tables). A block of the staged-rows kernel stages 160 B rows; on a dense clustered matrix a
+// block of 96 rows refers to thousands of distinct columns and a seventh of its entries find their row in LDS (reddit-shaped communities,
+// mean degree 492: 0.15 staged, 3.98 ms — behind the segmented-stream kernel's 2.97). Cut into P ascending column ranges with one
+// staging list per (block, range), the same kernel stages 0.29 / 0.42 / 0.58 / 0.66 / 0.71 of the entries at P = 2 / 3 / 5 / 8 / 12
+// (profiles/r06/reddit_slab_staged.log: products of the P ranges 3.38 / 3.00 / 2.40 / 2.23 / 2.25 ms) at the price of one pass over C
+// per extra range. P ~ mean degree / 64. Explicit choice: always (GESPMM_SLABS overrides the count); AUTO: mean degree >= 192 at N = 128.
+int slab_count_for(const PlanFacts& f) {
+    static const int env = getenv("GESPMM_SLABS") ? atoi(getenv("GESPMM_SLABS")) : 0;
+    if (f.N != 128 || f.host_analysis) return 0;
+    const bool asked = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED_SLABS;
+    const bool auto_ok = f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && f.variant == GESPMM_VARIANT_AUTO && f.mean_floor() >= 192;
+    if (!asked && !auto_ok) return 0;
+    int P = env > 0 ? env : (int)((f.mean_floor() + 32) / 64);
+    if (P < 2) P = asked ? 2 : 0;
+    return P > 16 ? 16 : P;
+}
+
+bool keep_slab_tables(const PlanFacts& f, double staged_fraction) {
+    // (structureless dense graphs stage little whatever the cut: the streaming kernels / the cache-blocked path stay)
+    return f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED_SLABS || staged_fraction >= 0.50;
+}
+
 bool keep_staged_tables(const PlanFacts& f, double staged_fraction) {
     // Not enough reuse inside the blocks: the streaming kernels stay. The share of entries that find their B row staged is what
     // separates the graphs where the kernel wins from those where it loses — on the repository's stand-ins AND on the hold-out
@@ -415,7 +437,7 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
     if (q->variant < GESPMM_VARIANT_AUTO || q->variant >= GESPMM_NUM_VARIANTS || q->reorder < 0 || q->reorder > 2) return GESPMM_EINVAL;
     // the kernel values gespmm_plan_create accepts (2 and 4 belonged to the removed opt-in kernels)
     if (q->kernel != GESPMM_PLAN_KERNEL_AUTO && q->kernel != GESPMM_PLAN_KERNEL_STREAM && q->kernel != GESPMM_PLAN_KERNEL_SEG_STREAM &&
-        q->kernel != GESPMM_PLAN_KERNEL_STAGED && q->kernel != GESPMM_PLAN_KERNEL_RECORDS)
+        q->kernel != GESPMM_PLAN_KERNEL_STAGED && q->kernel != GESPMM_PLAN_KERNEL_RECORDS && q->kernel != GESPMM_PLAN_KERNEL_STAGED_SLABS)
         return GESPMM_EINVAL;
     if (q->analysis != GESPMM_PLAN_ANALYSIS_DEVICE && q->analysis != GESPMM_PLAN_ANALYSIS_HOST) return GESPMM_EINVAL;
     gespmm::PlanFacts f;

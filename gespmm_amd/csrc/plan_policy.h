@@ -89,6 +89,10 @@ struct PlanKernelDecision {
 PlanKernelDecision choose_plan_kernel(const PlanFacts& f, double hits_after);
 
 // ---- the staged tables exist: does enough of the matrix find its B row staged?
+// Column-slab tables (round 6): how many ascending column ranges the clustered matrix is cut into for the staged-rows kernel (0: no such
+// tables), and whether they stay once the share of entries that find their B row staged is known.
+int slab_count_for(const PlanFacts& f);
+bool keep_slab_tables(const PlanFacts& f, double staged_fraction);
 bool keep_staged_tables(const PlanFacts& f, double staged_fraction);
 // The clustering was judged no better than the storage order (keep_clustered_order == false): does the plan still make its own copy
 // of the matrix, in the storage order, because the staged-rows kernel — which walks the plan's tables — would be built for it?

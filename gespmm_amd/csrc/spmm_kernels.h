@@ -147,6 +147,10 @@ struct StagedArgs {
     float empty;
     const int32_t* guard;  // launch guard, as in SpmmArgs (NULL: no check)
     int32_t guard_want;
+    // column-slab tables (plan.cpp: build_slab_tables; spmm_staged.hip only): the launch covers blocks blk0 .. blk0 + nblocks - 1 of the
+    // tables; acc != 0: rows continue from the partial sums in C (task word 0 = C row of the task's first row, row-end codes carry the next)
+    int32_t blk0;
+    int32_t acc;
 };
 // Shape of a block at width N: `waves` wavefronts (0 = width not served) own `rows` consecutive rows of the clustered matrix and
 // stage up to `slots` B rows (waves x 4 KB of LDS). GESPMM_STAGED_WAVES / GESPMM_STAGED_ROWS override it for experiments.
@@ -228,6 +232,10 @@ struct RecordArgs {
     int32_t n;
     const int32_t* guard;  // launch guard, as in SpmmArgs (NULL: no check)
     int32_t guard_want;
+    // column-slab tables (plan.cpp: build_slab_tables; spmm_staged.hip only): the launch covers blocks blk0 .. blk0 + nblocks - 1 of the
+    // tables; acc != 0: rows continue from the partial sums in C (task word 0 = C row of the task's first row, row-end codes carry the next)
+    int32_t blk0;
+    int32_t acc;
 };
 int records_group(int64_t N);  // lanes per chain at width N (0: width not served)
 bool records_serves(int64_t M, int64_t K, int64_t N, int32_t max_degree);

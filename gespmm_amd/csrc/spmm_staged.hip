@@ -88,8 +88,13 @@ template <> struct LaneVec<4> { using type = float __attribute__((ext_vector_typ
 // PAGE2: B between 4 and 8 GB (products-shaped x 512 columns: 5.0 GB). The lane's 32-bit offset wraps modulo 4 GB by itself —
 // `code << log2(row bytes)` drops the bit that says which half — and the base pointer is chosen between B and B + 4 GB by
 // that bit of the (scalar) code: two scalar instructions on the memory path, none on the LDS path.
-template <int VEC, int U, int TSHIFT, bool PAGE2, int WAVES, int LK>
+// ACC (round 6, column-slab tables: plan.cpp build_slab_tables): the launch CONTINUES rows whose first column slabs an earlier launch
+// summed — a wavefront's accumulators start as the C row of its first row (task word 0), and a row-end record carries the C row of the
+// row behind it in its code's low 30 bits: store this row, load that one. A partial sum stored to C and loaded again is the same value,
+// and a row's entries are still added in CSR order (the slabs are ascending column ranges of rows with ascending columns): same bits.
+template <int VEC, int U, int TSHIFT, bool PAGE2, int WAVES, int LK, bool ACC = false>
 __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
+    static_assert(!ACC || (VEC == 2 && TSHIFT == 0 && !PAGE2), "the continuing form exists for the 128-column shape");
     constexpr int kStagedWaves = WAVES;
     constexpr int kStagedLdsBytes = WAVES * LK * 1024;  // LK KB of staged B rows per wavefront of the block (4: two blocks per CU; 8: one)
     constexpr int P = LK;                                // 16-byte pieces of the staging copy per thread
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int blk, tile = 0;
     if constexpr (TSHIFT == 0) {
-        blk = xcd_contiguous(blockIdx.x, a.nblocks);
+        blk = a.blk0 + xcd_contiguous(blockIdx.x, a.nblocks);  // (blk0: the slab's first block — 0 for every other table)
     } else {
         constexpr int NX = 8 >> TSHIFT;  // XCDs that serve one tile
         tile = (int)blockIdx.x & ((1 << TSHIFT) - 1);
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
 #pragma unroll
     for (int u = 0; u < P; ++u) hcol[u] = (dbg & 1) ? -1 : hc[(u * kStagedWaves * 64 + tid) / kRowF4];
     const int wb = tk[2], we = tk[3];  // the wavefront's range of the record stream (entries + one row-end record per row)
+    const int crow0 = ACC ? tk[0] : 0;  // (slab tables: C row of the task's first row)
     const float* Bp = a.B + (size_t)tile * (64 * VEC);
     const float* BpHi = Bp + (1ull << 30);  // + 4 GB (PAGE2)
     (void)BpHi;
@@ -150,6 +156,11 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     const i2v* evv = reinterpret_cast<const i2v*>(a.ev) + wb;
     i2v win = {0, 0};
     if (we > wb) win = __builtin_nontemporal_load(evv + lane);  // (the stream is padded: a whole window is always readable)
+    v2f acc_first = {0.0f, 0.0f};
+    if constexpr (ACC) {
+        if (we > wb)
+            acc_first = *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(a.C) + (((size_t)(uint32_t)crow0) << kGlobalShift) + loff);
+    }
 #pragma unroll
     for (int u = 0; u < P; ++u)
         if (hcol[u] >= 0) s_hot[u * kStagedWaves * 64 + tid] = stage[u];
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     // (256-column tiles: the four accumulators are pinned to v[60:63] — inline assembly cannot name the halves of a register
     //  quadruple, and a row end wants ONE 16-byte store per lane: two 8-byte stores write every line of C in two halves and cost
     //  the short-row graphs a third of their time, profiles/r05/kernel_ab_record_stream.log)
-    v2f acc[1] = {v2f{0.0f, 0.0f}};
+    v2f acc[1] = {acc_first};
     f4v acc4 = {0.0f, 0.0f, 0.0f, 0.0f};
     (void)acc;
     (void)acc4;
@@ -260,7 +271,30 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_staged_kernel(StagedArgs a) {
     auto consume4 = [&](uint32_t ends, const uint64_t* cv, const vec_t* b) {
         uint32_t t;
         const uint32_t r0 = (uint32_t)(cv[0] >> 32), r1 = (uint32_t)(cv[1] >> 32), r2 = (uint32_t)(cv[2] >> 32), r3 = (uint32_t)(cv[3] >> 32);
-        if constexpr (VEC == 2) {
+        if constexpr (VEC == 2 && ACC) {
+            const uint32_t n0 = (uint32_t)cv[0] & 0x3fffffffu, n1 = (uint32_t)cv[1] & 0x3fffffffu, n2 = (uint32_t)cv[2] & 0x3fffffffu,
+                           n3 = (uint32_t)cv[3] & 0x3fffffffu;  // C row of the row behind each (possible) row end
+            // (the store reads its 8 bytes of data at issue; the load's result arrives long after — and is waited for before the next multiply-add)
+#define GESPMM_END2A(R, NX)                                                                                                       \
+    "v_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1 nt\n\tv_lshl_add_u32 %[t], " NX ", %[sh], %[lo]\n\t" \
+    "global_load_dwordx2 %[a], %[t], %[C]\n\ts_waitcnt vmcnt(0)\n\t"
+            asm volatile(
+                "s_bitcmp1_b32 %[e], 0\n\ts_cbranch_scc1 10f\n\t" GESPMM_FMA2("%[a]", "%[c0]", "%[b0]") "\n11:\n\t"
+                "s_bitcmp1_b32 %[e], 1\n\ts_cbranch_scc1 20f\n\t" GESPMM_FMA2("%[a]", "%[c1]", "%[b1]") "\n21:\n\t"
+                "s_bitcmp1_b32 %[e], 2\n\ts_cbranch_scc1 30f\n\t" GESPMM_FMA2("%[a]", "%[c2]", "%[b2]") "\n31:\n\t"
+                "s_bitcmp1_b32 %[e], 3\n\ts_cbranch_scc1 40f\n\t" GESPMM_FMA2("%[a]", "%[c3]", "%[b3]")
+                "s_branch 99f\n"
+                "10:\n\t" GESPMM_END2A("%[r0]", "%[n0]") "s_branch 11b\n"
+                "20:\n\t" GESPMM_END2A("%[r1]", "%[n1]") "s_branch 21b\n"
+                "30:\n\t" GESPMM_END2A("%[r2]", "%[n2]") "s_branch 31b\n"
+                "40:\n\t" GESPMM_END2A("%[r3]", "%[n3]") "\n99:"
+                : [a] "+v"(acc[0]), [t] "=&v"(t)
+                : [e] "s"(ends), [c0] "s"(cv[0]), [c1] "s"(cv[1]), [c2] "s"(cv[2]), [c3] "s"(cv[3]), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]),
+                  [b3] "v"(b[3]), [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [n0] "s"(n0), [n1] "s"(n1), [n2] "s"(n2), [n3] "s"(n3),
+                  [sh] "n"(kGlobalShift), [lo] "v"(loff), [C] "s"(Cp)
+                : "memory", "scc");
+#undef GESPMM_END2A
+        } else if constexpr (VEC == 2) {
 #define GESPMM_END2(R) "v_lshl_add_u32 %[t], " R ", %[sh], %[lo]\n\tglobal_store_dwordx2 %[t], %[a], %[C] sc1 nt\n\tv_mov_b64 %[a], 0\n\t"
             asm volatile(
                 "s_bitcmp1_b32 %[e], 0\n\ts_cbranch_scc1 10f\n\t" GESPMM_FMA2("%[a]", "%[c0]", "%[b0]") "\n11:\n\t"
@@ -455,6 +489,11 @@ hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t M, int64_t K, int6
     //  graph, products-shaped 3.92 vs 2.79 ms, geometric 240 vs 193 us: two blocks per CU hide each other's staging round trips, one does
     //  not. profiles/r05/staged_lds_per_wave.log; the kernel stays generic in LK, only 4 is instantiated)
     if (lds_kb != 4 && !(lds_kb == 5 && a.waves == 16)) return hipErrorInvalidValue;
+    if (a.acc) {  // (column-slab tables, second and later slabs: the 128-column shape only)
+        if (!(tc == 128 && a.waves == 16 && lds_kb == 5)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((spmm_staged_kernel<2, 16, 0, false, 16, 5, true>), grid, block, 0, st, a);
+        return hipGetLastError();
+    }
 #define GESPMM_STAGED_LAUNCH(VEC, U, TS, PG)                                                                                   \
     do {                                                                                                                       \
         if (a.waves == 16 && lds_kb == 5) hipLaunchKernelGGL((spmm_staged_kernel<VEC, U, TS, PG, 16, 5>), grid, block, 0, st, a);   \

@@ -90,7 +90,7 @@ class SpmmPlan:
     next to each other and find the shared B rows in L2 (and, at N = 128 / 256 where blocks of 96 / 64 clustered rows
     reuse their B rows, the tables of the staged-rows kernel: those rows are read from LDS; made for THIS width
     only). Only the processing order changes: the result has the same bits as the plain call.
-    ``kernel``: "auto" | "stream" | "seg-stream" | "staged".
+    ``kernel``: "auto" | "stream" | "seg-stream" | "staged" | "records" | "staged-slabs" (dense clustered matrices, N = 128).
 
         plan = SpmmPlan(rowptr, colind, K, N, values=val)      # reorder="auto" | True | False
         out = csr_spmm(rowptr, colind, val, dense, plan=plan)
@@ -121,7 +121,7 @@ class SpmmPlan:
         self.device = dev
         mode = {"auto": _lib.PLAN_REORDER_AUTO, True: _lib.PLAN_REORDER, False: _lib.PLAN_NO_REORDER}[reorder]
         kern = {"auto": _lib.PLAN_KERNEL_AUTO, "stream": _lib.PLAN_KERNEL_STREAM, "seg-stream": _lib.PLAN_KERNEL_SEG_STREAM,
-                "staged": _lib.PLAN_KERNEL_STAGED, "records": _lib.PLAN_KERNEL_RECORDS}[kernel]
+                "staged": _lib.PLAN_KERNEL_STAGED, "records": _lib.PLAN_KERNEL_RECORDS, "staged-slabs": _lib.PLAN_KERNEL_STAGED_SLABS}[kernel]
         where = {"device": _lib.PLAN_ANALYSIS_DEVICE, "host": _lib.PLAN_ANALYSIS_HOST}[analysis]
         opt = _lib.PlanOptions(mode, int(task_entries), int(row_floor), int(threads), int(flags), kern, where, int(expected_launches))
         self._handle = ctypes.c_void_p()

@@ -318,6 +318,14 @@ typedef struct gespmm_plan_options {
                                           (one coalesced load per lane, all 8 gathers of a piece in flight at once); AUTO takes it for short
                                           rows at narrow widths; other launches of the plan fall back to the streaming kernels */
 
+#define GESPMM_PLAN_KERNEL_STAGED_SLABS 7 /* (since 0.3, round 6) the staged-rows kernel over P ascending COLUMN ranges of the clustered matrix, one
+                                          staging list per (block of rows, range) and one launch per range, the second and later ones continuing
+                                          from the partial sums in C — for dense clustered matrices (a reddit-shaped community refers to ~100 000
+                                          B rows; 160 LDS slots per block cover a seventh of its entries, per range two thirds). N = 128, sum
+                                          reducer, rows with non-decreasing columns (range order == CSR order: the same bits), no slab of a row
+                                          beyond 2048 entries — else the plan keeps its other kernels. AUTO takes it at mean degree >= 192 when
+                                          >= 50 % of the entries find their B row staged */
+
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,
                        int64_t M, int64_t K, int64_t nnz, int64_t N /* width the plan is tuned for */, int variant,
                        const gespmm_plan_options* opt /* may be NULL */, void* stream);
