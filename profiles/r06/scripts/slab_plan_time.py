@@ -25,7 +25,7 @@ val = torch.rand(nnz, device="cuda") - 0.5
 B = torch.rand(K, N, device="cuda") - 0.5
 C = torch.empty(M, N, device="cuda")
 ref = spmm.csr_spmm(rp, ci, val, B, cfg={"flags": _lib.FLAG_STRICT_ORDER})
-for kern in ("auto", "seg-stream", "staged-slabs"):
+for kern in (("staged-slabs",) if os.environ.get("SLAB_ONLY") else ("auto", "seg-stream", "staged-slabs")):
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
