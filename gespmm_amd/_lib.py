@@ -126,7 +126,7 @@ class PlanPolicyAnswer(Structure):
                                                                                        ("est_cost_us", ctypes.c_double), ("cluster_sweeps", c_int32),
                                                                                        ("staged_rows", c_int32), ("build_records", c_int32),
                                                                                        ("keep_records", c_int32), ("records_batches", c_int32),
-                                                                                       ("reserved0", c_int32)]
+                                                                                       ("slab_ranges", c_int32)]
 
 
 class AutoPlanStats(Structure):

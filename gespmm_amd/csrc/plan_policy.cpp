@@ -96,6 +96,11 @@ AnalysisDecision decide_analysis(const PlanFacts& f) {
     const bool big_enough = f.M >= (1 << 14) && f.nnz >= f.M && f.nnz <= (1ll << 28) && f.b_bytes() > (8ll << 20);
     if (f.reorder_mode == GESPMM_PLAN_REORDER) {
         a.analyse = stream_family && f.M > 1 && f.nnz > 0;
+        // (asked for by name, the column-slab tables are made for dense graphs — the plain call's cache-blocked family — too)
+        if (!a.analyse && f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED_SLABS && crc_family(f.sel_variant) && f.M > 1 && f.nnz > 0 && !f.host_analysis) {
+            a.analyse = true;
+            a.dense_try = f.slab_blocked;
+        }
     } else if (f.reorder_mode == GESPMM_PLAN_REORDER_AUTO) {
         // B beyond the L2s (below that every order hits), enough rows to cluster
         a.analyse = stream_family && big_enough && mean <= 96;
@@ -257,7 +262,8 @@ int slab_count_for(const PlanFacts& f) {
     if (!asked && !auto_ok) return 0;
     int P = env > 0 ? env : (int)((f.mean_floor() + 32) / 64);
     if (P < 2) P = asked ? 2 : 0;
-    return P > 16 ? 16 : P;
+    const int cap = env > 0 ? 64 : 16;  // (the view takes up to 64 ranges; the rule stops at 16)
+    return P > cap ? cap : P;
 }
 
 bool keep_slab_tables(const PlanFacts& f, double staged_fraction) {
@@ -512,6 +518,7 @@ extern "C" int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q_in, int64
                        !a->keep_staged;
     a->keep_records = a->build_records && (q->record_slot_fill < 0.0 || gespmm::keep_record_tables(f, q->record_slot_fill));
     a->records_batches = gespmm::records_batches_per_task(f);
+    a->slab_ranges = (a->keep_clustered || f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED_SLABS) ? gespmm::slab_count_for(f) : 0;
     std::memcpy(a_out, &aa, (size_t)(a_bytes < (int64_t)sizeof aa ? a_bytes : (int64_t)sizeof aa));
     return 0;
 }

@@ -483,7 +483,8 @@ typedef struct gespmm_plan_policy_answer {
     int32_t build_records, keep_records; /* its tables are built (clustered order kept, narrow width, short rows, no staged tables kept) /
                                             kept, given record_slot_fill */
     int32_t records_batches;   /* batches a wavefront task of those tables is cut at */
-    int32_t reserved0;
+    int32_t slab_ranges;       /* column-slab tables (GESPMM_PLAN_KERNEL_STAGED_SLABS): ascending column ranges the plan cuts its clustered matrix
+                                  into at this width — 0: no such tables (kept once >= 50 % of the entries find their B row staged) */
 } gespmm_plan_policy_answer;
 int gespmm_plan_policy(const gespmm_plan_policy_query* q, gespmm_plan_policy_answer* a);  /* the 0.2 layouts (up to staged_fraction / model_sample) */
 int gespmm_plan_policy_v2(const gespmm_plan_policy_query* q, int64_t q_bytes, gespmm_plan_policy_answer* a, int64_t a_bytes);

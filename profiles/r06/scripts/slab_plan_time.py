@@ -29,7 +29,7 @@ for kern in (("staged-slabs",) if os.environ.get("SLAB_ONLY") else ("auto", "seg
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
-    plan = spmm.SpmmPlan(rp, ci, K, N, values=val, kernel=kern)
+    plan = spmm.SpmmPlan(rp, ci, K, N, values=val, kernel=kern, reorder=True if os.environ.get("SLAB_REORDER") else "auto")
     torch.cuda.synchronize()
     pms = (time.perf_counter() - t0) * 1e3
     t = timed(lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan), 7)

@@ -234,3 +234,19 @@ def test_padded_record_kernel_rules():
     # asked for by name: any order, any mean degree (still 4 <= N <= 64, rows <= 1024)
     assert _lib.plan_policy(N=32, kernel=_lib.PLAN_KERNEL_RECORDS, reorder=_lib.PLAN_NO_REORDER, **{**prod, "hits_after": 0.04})["build_records"] == 1
     assert _lib.plan_policy(N=32, kernel=_lib.PLAN_KERNEL_RECORDS, **{**prod, "max_degree": 1500})["build_records"] == 0
+
+
+def test_column_slab_rule():
+    """plan_policy.cpp slab_count_for (profiles/r06/slabs/): dense clustered matrices at N = 128 are cut into round(mean degree / 64) ascending
+    column ranges (reddit-shaped communities: 8); rows of 50 entries keep the one-launch staged kernel (two to four ranges lose there); the
+    structureless dense graph keeps its storage order (nothing to cut); other widths are not served; asked for by name: any mean degree."""
+    reddit = dict(M=232965, K=232965, nnz=114615892, max_degree=7021, hits_before=0.026, expected_launches=1000000, wedge_probe=0.2)
+    assert _lib.plan_policy(N=128, hits_after=0.725, **reddit)["slab_ranges"] == 8
+    assert _lib.plan_policy(N=128, hits_after=0.033, **reddit)["slab_ranges"] == 0  # (order not kept: the cache-blocked path)
+    assert _lib.plan_policy(N=256, hits_after=0.725, **reddit)["slab_ranges"] == 0
+    assert _lib.plan_policy(N=128, hits_after=0.725, variant=_lib.VARIANT_CRC, **reddit)["slab_ranges"] == 0
+    prod = dict(M=2449029, K=2449029, nnz=123718280, max_degree=1009, hits_before=0.04, hits_after=0.85, expected_launches=1000000, wedge_probe=0.3)
+    assert _lib.plan_policy(N=128, **prod)["slab_ranges"] == 0
+    assert _lib.plan_policy(N=128, kernel=_lib.PLAN_KERNEL_STAGED_SLABS, **prod)["slab_ranges"] == 2
+    denser = dict(reddit, nnz=232965 * 1100)
+    assert _lib.plan_policy(N=128, hits_after=0.725, **denser)["slab_ranges"] == 16  # (the rule stops at 16 ranges)
