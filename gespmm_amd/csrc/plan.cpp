@@ -356,7 +356,9 @@ static hipError_t build_slab_tables(gespmm_plan* p, int P, hipStream_t st) {
     gespmm::StagedShape shape = gespmm::staged_shape(N);
     static const int rows_env = getenv("GESPMM_SLAB_ROWS") ? atoi(getenv("GESPMM_SLAB_ROWS")) : 0;  // experiments
     if (rows_env > 0) shape.rows = rows_env;
-    if (N != 128 || shape.waves != 16 || shape.slots != 160 || P < 2 || nnz <= 0 || !gespmm::staged_serves(M, K, N) ||
+    static const int lds_env = getenv("GESPMM_SLAB_LDS_KB") ? atoi(getenv("GESPMM_SLAB_LDS_KB")) : 0;  // experiments: 3 = three 48 KB blocks per CU
+    if (N == 128 && shape.waves == 16 && shape.slots == 160 && lds_env == 3) shape.slots = 96;
+    if (N != 128 || shape.waves != 16 || (shape.slots != 160 && shape.slots != 96) || P < 2 || nnz <= 0 || !gespmm::staged_serves(M, K, N) ||
         !gespmm::staged_stream_fits(M * P, nnz) || M * P >= (1ll << 30))
         return hipSuccess;
     hipError_t e = gespmm::device_build_slab_view(M, K, nnz, p->d_rowptr, p->d_colind, p->valued ? p->d_val : nullptr, p->d_perm, P,

@@ -488,7 +488,13 @@ hipError_t launch_spmm_staged(const StagedArgs& a_in, int64_t M, int64_t K, int6
     // (8 KB per wavefront — one 16-wavefront block per CU with twice the staged rows — was built and measured: 20-40 % slower on every
     //  graph, products-shaped 3.92 vs 2.79 ms, geometric 240 vs 193 us: two blocks per CU hide each other's staging round trips, one does
     //  not. profiles/r05/staged_lds_per_wave.log; the kernel stays generic in LK, only 4 is instantiated)
-    if (lds_kb != 4 && !(lds_kb == 5 && a.waves == 16)) return hipErrorInvalidValue;
+    if (lds_kb != 4 && !(lds_kb == 5 && a.waves == 16) && !(lds_kb == 3 && a.waves == 16)) return hipErrorInvalidValue;
+    if (lds_kb == 3) {  // (column-slab tables built for THREE 48 KB blocks per CU: 96 staged rows, 8 gathers per chunk — 33 VGPRs)
+        if (!(tc == 128 && a.waves == 16)) return hipErrorInvalidValue;
+        if (a.acc) hipLaunchKernelGGL((spmm_staged_kernel<2, 8, 0, false, 16, 3, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((spmm_staged_kernel<2, 8, 0, false, 16, 3, false>), grid, block, 0, st, a);
+        return hipGetLastError();
+    }
     if (a.acc) {  // (column-slab tables, second and later slabs: the 128-column shape only)
         if (!(tc == 128 && a.waves == 16 && lds_kb == 5)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((spmm_staged_kernel<2, 16, 0, false, 16, 5, true>), grid, block, 0, st, a);
