@@ -253,12 +253,16 @@ bool storage_order_wants_plan_copy(const PlanFacts& f, double hits_before) {
 // mean degree 492: 0.15 staged, 3.98 ms — behind the segmented-stream kernel's 2.97). Cut into P ascending column ranges with one
 // staging list per (block, range), the same kernel stages 0.29 / 0.42 / 0.58 / 0.66 / 0.71 of the entries at P = 2 / 3 / 5 / 8 / 12
 // (profiles/r06/reddit_slab_staged.log: products of the P ranges 3.38 / 3.00 / 2.40 / 2.23 / 2.25 ms) at the price of one pass over C
-// per extra range. P ~ mean degree / 64. Explicit choice: always (GESPMM_SLABS overrides the count); AUTO: mean degree >= 192 at N = 128.
+// per extra range. P ~ mean degree / 64. Explicit choice: always (GESPMM_SLABS overrides the count); AUTO: mean degree >= 96 at N = 128 —
+// planted-community graphs of the reddit stand-in's size at mean degree 64 / 96 / 128 / 160 / 192 / 256 / 350 / 492, AUTO without slab
+// tables against the tables at round(mean / 64) ranges (profiles/r06/slabs/slab_density.log): 315 vs 337 us (the one-launch staged kernel
+// keeps mean 64, as it keeps the products-shaped graph) · 590 vs 464 · 799 vs 613 · 977 vs 787 · 1258 vs 946 · 1604 vs 1249 · 2179 vs 1631 ·
+// 3024 vs 2212: x0.73-0.81 from 96 on, where the plan otherwise falls to the segmented-stream kernel.
 int slab_count_for(const PlanFacts& f) {
     static const int env = getenv("GESPMM_SLABS") ? atoi(getenv("GESPMM_SLABS")) : 0;
-    if (f.N != 128 || f.host_analysis) return 0;
+    if (f.N != 128 || f.host_analysis || env < 0) return 0;  // (GESPMM_SLABS=-1: never — the A/B of profiles/r06/slabs/slab_density.log)
     const bool asked = f.kernel_choice == GESPMM_PLAN_KERNEL_STAGED_SLABS;
-    const bool auto_ok = f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && f.variant == GESPMM_VARIANT_AUTO && f.mean_floor() >= 192;
+    const bool auto_ok = f.kernel_choice == GESPMM_PLAN_KERNEL_AUTO && f.variant == GESPMM_VARIANT_AUTO && f.mean_floor() >= 96;
     if (!asked && !auto_ok) return 0;
     int P = env > 0 ? env : (int)((f.mean_floor() + 32) / 64);
     if (P < 2) P = asked ? 2 : 0;

@@ -323,7 +323,7 @@ typedef struct gespmm_plan_options {
                                           from the partial sums in C — for dense clustered matrices (a reddit-shaped community refers to ~100 000
                                           B rows; 160 LDS slots per block cover a seventh of its entries, per range two thirds). N = 128, sum
                                           reducer, rows with non-decreasing columns (range order == CSR order: the same bits), no slab of a row
-                                          beyond 2048 entries — else the plan keeps its other kernels. AUTO takes it at mean degree >= 192 when
+                                          beyond 2048 entries — else the plan keeps its other kernels. AUTO takes it at mean degree >= 96 when
                                           >= 50 % of the entries find their B row staged */
 
 int gespmm_plan_create(gespmm_plan** plan, const int32_t* rowptr, const int32_t* colind, const float* val /* may be NULL */,

@@ -248,5 +248,7 @@ def test_column_slab_rule():
     prod = dict(M=2449029, K=2449029, nnz=123718280, max_degree=1009, hits_before=0.04, hits_after=0.85, expected_launches=1000000, wedge_probe=0.3)
     assert _lib.plan_policy(N=128, **prod)["slab_ranges"] == 0
     assert _lib.plan_policy(N=128, kernel=_lib.PLAN_KERNEL_STAGED_SLABS, **prod)["slab_ranges"] == 2
+    assert _lib.plan_policy(N=128, hits_after=0.8, **dict(reddit, nnz=232965 * 96))["slab_ranges"] == 2  # (slab_density.log: 590 -> 464 us)
+    assert _lib.plan_policy(N=128, hits_after=0.8, **dict(reddit, nnz=232965 * 64))["slab_ranges"] == 0  # (315 vs 337 us: the one-launch kernel)
     denser = dict(reddit, nnz=232965 * 1100)
     assert _lib.plan_policy(N=128, hits_after=0.725, **denser)["slab_ranges"] == 16  # (the rule stops at 16 ranges)
