@@ -174,6 +174,19 @@ struct LongRowHeader {
     int pad[2];
 };
 
+// The header is zeroed by a KERNEL, not by hipMemsetAsync: captured into a HIP graph (a caller's workspace under torch.cuda.graph) the
+// memset node did not reliably precede the kernels behind it on this runtime — about every second process replayed its graph with the
+// workspace's stale header, and the combine kernel stored the (empty) partial sums of "row 0" over a finished row
+// (profiles/r06/capture_flake_probe.log: row 0 of the second product zero in every replay of such a process, never without the
+// long-row pass). A kernel node keeps its place in the stream's order, captured or not.
+__global__ void spmm_longrow_reset_kernel(LongRowHeader* hdr) {
+    if (threadIdx.x == 0) {
+        hdr->nchunks = 0;
+        hdr->nrows = 0;
+        hdr->pad[0] = hdr->pad[1] = 0;
+    }
+}
+
 template <int V, int S, int W, bool VALUED, bool IDX64, int RED>
 __global__ __launch_bounds__(kThreads) void spmm_longrow_chunk_kernel(SpmmArgs a, int chunk, int max_chunks,
                                                                        const LongRowHeader* __restrict__ hdr,
@@ -857,7 +870,8 @@ hipError_t longrows_begin(SpmmArgs& a, int64_t nnz, void* ext_ws, size_t ext_byt
     ws.rowlist = reinterpret_cast<int4*>(base + off_rows);
     ws.chunklist = reinterpret_cast<int2*>(base + off_chunks);
     ws.partial = reinterpret_cast<float*>(base + off_partial);
-    e = hipMemsetAsync(base, 0, sizeof(LongRowHeader), st);
+    hipLaunchKernelGGL(spmm_longrow_reset_kernel, dim3(1), dim3(64), 0, st, ws.hdr);
+    e = hipGetLastError();
     a.lr_hdr = reinterpret_cast<int32_t*>(ws.hdr);
     a.lr_rows = reinterpret_cast<int32_t*>(ws.rowlist);
     a.lr_chunks = reinterpret_cast<int32_t*>(ws.chunklist);

@@ -109,3 +109,37 @@ def test_auto_takes_slabs_on_the_dense_community_graph_and_bits_equal_the_plain_
     sel = np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows])
     want = oracle.spmm(sub_ptr, cih[sel], vh[sel], Bh, "fma")
     assert np.array_equal(bits(got[torch.from_numpy(rows).cuda()].cpu().numpy()), bits(want))
+
+
+def test_the_launches_replay_from_a_hip_graph(pkg, oracle):
+    """One product = P launches on the caller's stream, nothing allocated: captured once, replayed on new contents of B (C NaN-filled before)."""
+    from gespmm_amd import spmm
+
+    rng = np.random.RandomState(21)
+    M = K = 2500
+    rowptr, colind = _community_csr(rng, M, K, comm=150, deg_in=120, deg_out=40)
+    rp, ci = _dev(rowptr), _dev(colind)
+    val_h = oracle.hash_val(colind.size, seed=4)
+    val = _dev(val_h)
+    plan = spmm.SpmmPlan(rp, ci, K, 128, values=val, reorder=True, kernel="staged-slabs")
+    assert "kernel=staged-slabs" in plan.describe(), plan.describe()
+    B = _dev(oracle.hash_B(K, 128, seed=1))
+    C = torch.empty((M, 128), device="cuda")
+    fn = lambda: spmm.csr_spmm(rp, ci, val, B, out=C, plan=plan)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    for seed in (2, 3):
+        B_h = oracle.hash_B(K, 128, seed=seed)
+        B.copy_(_dev(B_h))
+        C.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(C.cpu().numpy()), bits(oracle.spmm(rowptr, colind, val_h, B_h, "fma"))), seed
