@@ -50,8 +50,10 @@ def test_plan_launches_replay_from_a_graph(pkg, oracle, bundled, N, kernel, tag)
 
 
 def test_plain_calls_and_a_two_layer_propagation_replay_from_a_graph(pkg, oracle, bundled):
-    """The stateless entry points (no plan) under capture — incl. a matrix whose launch takes the long-row pass with scratch from the
-    library's pool (reserved by the warm-up launches) — and the shape of a GCN forward: two products of different widths in one graph."""
+    """The stateless entry points (no plan) under capture — incl. a launch that takes the long-row pass with the workspace the Python layer
+    hands it (a torch allocation: under capture a block of the graph's private pool; without a workspace the library switches the pass off
+    while capturing) — and the shape of a GCN forward: two products of different widths in one graph. (Until the end of round 6 this test
+    failed in about every second FRESH process: the pass zeroed its header with a captured memset — DESIGN 3.8b, profiles/r06/capture_flake/.)"""
     from gespmm_amd import _lib, spmm
 
     g = bundled["cora"]
