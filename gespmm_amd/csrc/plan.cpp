@@ -926,7 +926,7 @@ int gespmm_plan_tune(gespmm_plan* p, const float* B, float* C, int64_t N, int32_
     if (N != p->N) return GESPMM_EINVAL;  // the tables are made for one width
     // a storage-order plan has one launch path, and the caller's explicit choice stands: nothing to measure, but C = A * B as promised
     // (... and so does a plan that kept column-slab tables: they are not one of the candidates below, and the rule that kept them —
-    //  half of the entries staged on a matrix of mean degree >= 192 — is far from the margin: 2.29 against 2.97 ms where it fires)
+    //  half of the entries staged on a matrix of mean degree >= 96 — is far from the margin: x0.73-0.81 wherever it fires, slab_density.log)
     if (!p->reordered || p->kernel_choice != GESPMM_PLAN_KERNEL_AUTO || p->slab.ev)
         return plan_run(p, B, C, N, gespmm::kReduceSum, 0.0f, stream);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
