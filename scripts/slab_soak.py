@@ -63,7 +63,9 @@ def soak(first, count):
                 assert torch.equal(C.view(torch.int32), ref.view(torch.int32)), (seed, M, K, deg, plan.describe()[-200:])
                 checked += 1
             else:  # (a hub row beyond the per-range limit: the plan's streaming kernels, whose long-row pass re-associates — tolerance class)
-                assert torch.allclose(C, ref, rtol=1e-3, atol=1e-3), (seed, M, K, deg, plan.describe()[-200:])
+                va = torch.ones(nnz, device="cuda") if v is None else v.abs()
+                scale = torch.maximum(ref.abs(), spmm.csr_spmm(rp, ci, va, B.abs(), cfg=strict))  # sum |a b| per element (the tolerance class)
+                assert bool(((C - ref).abs() <= 1e-4 * scale + 1e-30).all()), (seed, M, K, deg, plan.describe()[-200:])
         del plan
     print("column-slab soak: seeds %d..%d, %d products compared bit for bit (%d plans on the slab tables), %.0f s: all equal" % (
         first, first + count - 1, checked, slabbed, time.time() - t0))
